@@ -1,0 +1,4 @@
+// Minimal stand-in for <gnuradio/attributes.h> (test infrastructure, oracle/_ref build only).
+#pragma once
+#define __GR_ATTR_EXPORT __attribute__((visibility("default")))
+#define __GR_ATTR_IMPORT __attribute__((visibility("default")))

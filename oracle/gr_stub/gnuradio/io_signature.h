@@ -1,0 +1,2 @@
+#pragma once
+#include <gnuradio/stub_runtime.h>

@@ -1,0 +1,204 @@
+"""ctypes front door to the CPU oracle (oracle/liboracle.so) and, where it has been
+built, to the reference's own C++ compiled by path (oracle/_ref/libairmodes_ref.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+REF_PATH = os.path.join(HERE, "_ref", "libairmodes_ref.so")
+
+PACKET_DTYPE = np.dtype([
+    ("data", "u1", 14), ("nbytes", "u1"), ("df", "u1"), ("numlowconf", "u1"),
+    ("reserved", "u1", 3), ("crc", "<u4"), ("ref", "<f4"), ("reserved2", "<u4"),
+    ("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8")])
+TAG_DTYPE = np.dtype([("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8"),
+                      ("inavg", "<f4"), ("how_late", "<u4")])
+assert PACKET_DTYPE.itemsize == 56 and TAG_DTYPE.itemsize == 32
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(LIB_PATH) or (
+            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "airmodes_oracle.c"))):
+        subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+    if os.path.isdir("/root/reference/lib") and (force or not os.path.exists(REF_PATH)):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.amo_threshold_lin.restype = C.c_float
+        L.amo_threshold_lin.argtypes = [C.c_float]
+        L.amo_mag2.argtypes = [_f32p, C.c_uint64, _f32p]
+        L.amo_frontend.argtypes = [_f32p, C.c_uint64, C.c_int, C.c_int, _f32p, _f32p]
+        L.amo_frontend_running.argtypes = [_f32p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, _f32p, _f32p]
+        L.amo_preamble_scan.restype = C.c_uint64
+        L.amo_preamble_scan.argtypes = [_f32p, _f32p, C.c_uint64, C.c_int, C.c_float, C.c_uint64,
+                                        _f32p, C.c_void_p, C.c_uint64]
+        L.amo_slice.argtypes = [_f32p, C.c_void_p, C.c_void_p]
+        L.amo_crc24.restype = C.c_uint32
+        L.amo_crc24.argtypes = [_u8p, C.c_int]
+        L.amo_demod.restype = C.c_uint64
+        L.amo_demod.argtypes = [_f32p, C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_void_p,
+                                C.c_uint64, C.POINTER(C.c_uint64)]
+        L.amo_format_message.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.exists(REF_PATH)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        R = C.CDLL(REF_PATH)
+        R.ref_crc24.restype = C.c_uint32
+        R.ref_crc24.argtypes = [_u8p, C.c_int]
+        R.ref_preamble_slicer.argtypes = [
+            _f32p, _f32p, C.c_uint64, C.c_float, C.c_float, C.c_uint64, _f32p,
+            np.ctypeslib.ndpointer(np.uint64), np.ctypeslib.ndpointer(np.float64),
+            np.ctypeslib.ndpointer(np.uint64), C.c_uint64, C.POINTER(C.c_uint64),
+            C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        _ref = R
+    return _ref
+
+
+def as_iq_f32(iq):
+    """complex64 (n,) or float32 (2n,) -> contiguous interleaved float32 (2n,)."""
+    a = np.ascontiguousarray(iq)
+    if np.iscomplexobj(a):
+        a = a.astype(np.complex64, copy=False).view(np.float32)
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+
+
+def threshold_lin(thr_db):
+    return float(lib().amo_threshold_lin(thr_db))
+
+
+def mag2(iq):
+    f = as_iq_f32(iq)
+    out = np.empty(f.size // 2, np.float32)
+    lib().amo_mag2(f, out.size, out)
+    return out
+
+
+def frontend(iq, spc, use_pmf=True, running_chunk=None):
+    f = as_iq_f32(iq)
+    n = f.size // 2
+    bb = np.empty(n, np.float32)
+    avg = np.empty(n, np.float32)
+    if running_chunk:
+        rc = lib().amo_frontend_running(f, n, spc, int(use_pmf), running_chunk, bb, avg)
+    else:
+        rc = lib().amo_frontend(f, n, spc, int(use_pmf), bb, avg)
+    if rc != 0:
+        raise RuntimeError("amo_frontend failed")
+    return bb, avg
+
+
+def preamble_scan(bb, avg, spc, thr_db, rate):
+    n = bb.size
+    cap = n // (240 * spc) + 2
+    bursts = np.zeros((cap, 240), np.float32)
+    tags = np.zeros(cap, TAG_DTYPE)
+    hits = lib().amo_preamble_scan(np.ascontiguousarray(bb, np.float32), np.ascontiguousarray(avg, np.float32),
+                                   n, spc, thr_db, int(rate), bursts.reshape(-1), tags.ctypes.data, cap)
+    assert hits <= cap
+    return bursts[:hits], tags[:hits]
+
+
+def slice_bursts(bursts, tags):
+    out = np.zeros(len(tags), PACKET_DTYPE)
+    n = 0
+    one = np.zeros(1, PACKET_DTYPE)
+    for i in range(len(tags)):
+        b = np.ascontiguousarray(bursts[i], np.float32)
+        t = tags[i:i + 1].copy()
+        if lib().amo_slice(b, t.ctypes.data, one.ctypes.data):
+            out[n] = one[0]
+            n += 1
+    return out[:n]
+
+
+def crc24(data):
+    d = np.frombuffer(bytes(data), np.uint8).copy()
+    return int(lib().amo_crc24(d, d.size))
+
+
+def demod(iq, rate, thr_db=7.0, use_pmf=True, return_tags=False):
+    f = as_iq_f32(iq)
+    n = f.size // 2
+    spc = max(int(rate / 2e6), 1)
+    cap = n // (240 * spc) + 2
+    out = np.zeros(cap, PACKET_DTYPE)
+    ntags = C.c_uint64(0)
+    npk = lib().amo_demod(f, n, float(rate), thr_db, int(use_pmf), out.ctypes.data, cap, C.byref(ntags))
+    assert npk <= cap
+    return (out[:npk], int(ntags.value)) if return_tags else out[:npk]
+
+
+def format_messages(packets, first=True):
+    """Message texts as the reference's slicer would post them, in order."""
+    buf = C.create_string_buffer(200)
+    msgs = []
+    for i in range(len(packets)):
+        p = packets[i:i + 1].copy()
+        w = lib().amo_format_message(p.ctypes.data, int(first and i == 0), buf, 200)
+        assert w > 0
+        msgs.append(buf.value.decode())
+    return msgs
+
+
+def ref_preamble_slicer(bb, avg, spc, thr_db, rate):
+    """The reference's OWN preamble_impl + slicer_impl (+modes_crc) on the two float
+    streams; canonical end-of-stream rule applied here.  Returns (bursts, tags, msgs)."""
+    n = bb.size
+    pad = 600 * spc
+    cap = (n + pad) // (240 * spc) + 4
+    bursts = np.zeros((cap, 240), np.float32)
+    secs = np.zeros(cap, np.uint64)
+    frac = np.zeros(cap, np.float64)
+    item = np.zeros(cap, np.uint64)
+    ntags = C.c_uint64(0)
+    mcap = cap * 96 + 64
+    msgs = C.create_string_buffer(mcap)
+    mlen = C.c_uint64(0)
+    nmsg = C.c_uint64(0)
+    rc = ref().ref_preamble_slicer(np.ascontiguousarray(bb, np.float32), np.ascontiguousarray(avg, np.float32),
+                                   n, float(rate), thr_db, pad, bursts.reshape(-1), secs, frac, item, cap,
+                                   C.byref(ntags), msgs, mcap, C.byref(mlen), C.byref(nmsg))
+    if rc != 0:
+        raise RuntimeError("ref_preamble_slicer rc=%d" % rc)
+    nt = int(ntags.value)
+    assert nt <= cap
+    tags = np.zeros(nt, TAG_DTYPE)
+    tags["secs"] = secs[:nt]
+    tags["frac"] = frac[:nt]
+    r = int(rate)
+    tags["sample"] = secs[:nt] * np.uint64(r) + np.rint(frac[:nt] * r).astype(np.uint64)
+    text = msgs.raw[:mlen.value].decode().split("\n")[:-1]
+    assert len(text) == nmsg.value
+    # canonical end-of-stream rule: hits need 240*spc items of room
+    K = n + 2 * spc - 1
+    ninputs = K - K % spc - spc
+    keep = (ninputs - tags["sample"].astype(np.int64)) >= 240 * spc
+    return bursts[:nt], tags, text, keep
