@@ -1,0 +1,263 @@
+"""ctypes binding of include/airmodes_hip.h (libairmodes_hip.so).
+
+This is the thin host-language shim north_star asks for: Python calls the HIP path through
+the C ABI and nothing else.  There is NO CPU fallback here: if the library is missing or no
+HIP device is usable, loading / context creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libairmodes_hip.so")
+
+AM_F_DEVICE_IN = 0x1
+AM_F_FLUSH = 0x2
+AM_F_DEVICE_OUT = 0x4
+
+AM_OK, AM_EINVAL, AM_ENODEV, AM_ENOMEM, AM_EHIP, AM_ECAPACITY, AM_ENOTSUP = 0, -1, -2, -3, -4, -5, -6
+
+PACKET_DTYPE = np.dtype([
+    ("data", "u1", 14), ("nbytes", "u1"), ("df", "u1"), ("numlowconf", "u1"),
+    ("reserved", "u1", 3), ("crc", "<u4"), ("ref", "<f4"), ("reserved2", "<u4"),
+    ("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8")])
+TAG_DTYPE = np.dtype([("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8"),
+                      ("inavg", "<f4"), ("how_late", "<u4")])
+CAND_DTYPE = np.dtype([("pos", "<u8"), ("shift", "<u4"), ("valid", "<u4")])
+assert PACKET_DTYPE.itemsize == 56 and TAG_DTYPE.itemsize == 32 and CAND_DTYPE.itemsize == 16
+
+
+class AirModesError(RuntimeError):
+    def __init__(self, code, text):
+        RuntimeError.__init__(self, "airmodes_hip error %d: %s" % (code, text))
+        self.code = code
+
+
+class Library(object):
+    """One loaded libairmodes_hip.so with typed entry points."""
+
+    def __init__(self, path=None):
+        path = path or os.environ.get("AIRMODES_HIP_LIB") or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise OSError("libairmodes_hip.so not found at %s -- build it with "
+                          "`python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % path)
+        self.path = path
+        L = C.CDLL(path)
+        vp, u64, u32, f32, f64, ci = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_double, C.c_int
+        pu64 = C.POINTER(C.c_uint64)
+        L.am_abi_version.restype = u32
+        L.am_create.restype = vp
+        L.am_create.argtypes = [ci, f64, f32, ci, ci, C.POINTER(ci)]
+        L.am_destroy.argtypes = [vp]
+        L.am_set_rate.argtypes = [vp, f64]
+        L.am_set_threshold.argtypes = [vp, f32]
+        L.am_get_rate.restype = f64
+        L.am_get_rate.argtypes = [vp]
+        L.am_get_threshold.restype = f32
+        L.am_get_threshold.argtypes = [vp]
+        L.am_get_pmf.argtypes = [vp]
+        L.am_reset.argtypes = [vp]
+        L.am_process_iq.argtypes = [vp, vp, u64, u32, vp, u64, pu64]
+        L.am_fetch_packets.argtypes = [vp, vp, u64, pu64]
+        L.am_last_num_tags.restype = u64
+        L.am_last_num_tags.argtypes = [vp]
+        L.am_frontend_work.argtypes = [vp, vp, u64, u32, vp, vp]
+        L.am_preamble_work.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
+        L.am_slicer_work.argtypes = [vp, vp, vp, u64, u32, vp, u64, pu64]
+        L.am_crc24.restype = u32
+        L.am_crc24.argtypes = [vp, ci]
+        L.am_format_message.argtypes = [vp, ci, C.c_char_p, C.c_size_t]
+        L.am_shard_halo.argtypes = [vp, pu64, pu64]
+        L.am_shard_scan.argtypes = [vp, vp, u64, u64, u64, u32, vp, u64, pu64]
+        L.am_shard_resolve.argtypes = [vp, vp, u64, u32, vp, u64, pu64]
+        L.am_last_error.restype = C.c_char_p
+        L.am_last_error.argtypes = [vp]
+        L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+        self.L = L
+        if L.am_abi_version() != 1:
+            raise OSError("ABI version mismatch in %s" % path)
+
+    # host-side helpers that need no context
+    def crc24(self, data):
+        d = np.frombuffer(bytes(data), np.uint8).copy()
+        return int(self.L.am_crc24(d.ctypes.data, d.size))
+
+    def format_message(self, packet, first):
+        p = np.asarray(packet, PACKET_DTYPE).reshape(1).copy()
+        buf = C.create_string_buffer(200)
+        w = self.L.am_format_message(p.ctypes.data, int(bool(first)), buf, 200)
+        if w < 0:
+            raise AirModesError(w, "am_format_message")
+        return buf.value.decode()
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def _iq_f32(iq):
+    a = np.ascontiguousarray(iq)
+    if np.iscomplexobj(a):
+        a = a.astype(np.complex64, copy=False).view(np.float32)
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+
+
+class Context(object):
+    """am_ctx wrapper: one receive path (one stream) on one GPU."""
+
+    def __init__(self, rate, threshold_db=7.0, use_pmf=True, use_dcblock=False, device=-1, lib=None):
+        self.lib = lib or default_library()
+        err = C.c_int(0)
+        self._h = self.lib.L.am_create(int(device), float(rate), float(threshold_db), int(bool(use_pmf)),
+                                       int(bool(use_dcblock)), C.byref(err))
+        if not self._h:
+            raise AirModesError(err.value, self.lib.L.am_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.am_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != AM_OK:
+            raise AirModesError(rc, self.lib.L.am_last_error(self._h).decode())
+
+    # setters / getters mirroring gr::air_modes::preamble and rx_path
+    def set_rate(self, rate):
+        self._chk(self.lib.L.am_set_rate(self._h, float(rate)))
+
+    def set_threshold(self, thr_db):
+        self._chk(self.lib.L.am_set_threshold(self._h, float(thr_db)))
+
+    def get_rate(self):
+        return float(self.lib.L.am_get_rate(self._h))
+
+    def get_threshold(self):
+        return float(self.lib.L.am_get_threshold(self._h))
+
+    def get_pmf(self):
+        return bool(self.lib.L.am_get_pmf(self._h))
+
+    def reset(self):
+        self._chk(self.lib.L.am_reset(self._h))
+
+    def last_num_tags(self):
+        return int(self.lib.L.am_last_num_tags(self._h))
+
+    def last_timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._chk(self.lib.L.am_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def _fetch(self, need):
+        out = np.zeros(need, PACKET_DTYPE)
+        n = C.c_uint64(0)
+        self._chk(self.lib.L.am_fetch_packets(self._h, out.ctypes.data, need, C.byref(n)))
+        return out[:n.value]
+
+    def process_iq(self, iq, flush=False, capacity=None):
+        """Host IQ (complex64 or interleaved float32) -> accepted packets of this chunk."""
+        f = _iq_f32(iq)
+        n = f.size // 2
+        return self._process(f.ctypes.data if n else None, n, AM_F_FLUSH if flush else 0, capacity)
+
+    def process_iq_device(self, dev_ptr, n_complex, flush=False, capacity=None):
+        """Device-resident interleaved float32 IQ (e.g. torch tensor .data_ptr())."""
+        return self._process(int(dev_ptr), int(n_complex), AM_F_DEVICE_IN | (AM_F_FLUSH if flush else 0), capacity)
+
+    def _process(self, ptr, n, flags, capacity):
+        cap = int(capacity) if capacity is not None else max(64, n // 2000 + 64)
+        out = np.zeros(cap, PACKET_DTYPE)
+        got = C.c_uint64(0)
+        rc = self.lib.L.am_process_iq(self._h, ptr, n, flags, out.ctypes.data, cap, C.byref(got))
+        if rc == AM_ECAPACITY:
+            return self._fetch(int(got.value))
+        self._chk(rc)
+        return out[:got.value]
+
+    # block-level entry points
+    def frontend_work(self, iq):
+        f = _iq_f32(iq)
+        n = f.size // 2
+        bb = np.empty(n, np.float32)
+        avg = np.empty(n, np.float32)
+        self._chk(self.lib.L.am_frontend_work(self._h, f.ctypes.data if n else None, n, 0,
+                                              bb.ctypes.data, avg.ctypes.data))
+        return bb, avg
+
+    def preamble_work(self, in_, inavg):
+        a = np.ascontiguousarray(in_, np.float32)
+        b = np.ascontiguousarray(inavg, np.float32)
+        assert a.size == b.size
+        n = a.size
+        spc = max(int(self.get_rate() / 2e6), 1)
+        cap = n // (240 * spc) + 2
+        bursts = np.zeros((cap, 240), np.float32)
+        tags = np.zeros(cap, TAG_DTYPE)
+        got = C.c_uint64(0)
+        self._chk(self.lib.L.am_preamble_work(self._h, a.ctypes.data, b.ctypes.data, n, 0, bursts.ctypes.data,
+                                              tags.ctypes.data, cap, C.byref(got)))
+        return bursts[:got.value], tags[:got.value]
+
+    def slicer_work(self, bursts, tags):
+        b = np.ascontiguousarray(bursts, np.float32).reshape(-1, 240)
+        t = np.ascontiguousarray(tags, TAG_DTYPE)
+        nb = t.size
+        out = np.zeros(max(nb, 1), PACKET_DTYPE)
+        got = C.c_uint64(0)
+        self._chk(self.lib.L.am_slicer_work(self._h, b.ctypes.data if nb else None, t.ctypes.data if nb else None,
+                                            nb, 0, out.ctypes.data, out.size, C.byref(got)))
+        return out[:got.value]
+
+    # time-sharded operation
+    def shard_halo(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self.lib.L.am_shard_halo(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def shard_scan(self, iq_with_halo, abs_start, abs_end, total_n, device_ptr=None, n_with_halo=None):
+        """Candidate records of chunk [abs_start, abs_end); iq_with_halo covers
+        [abs_start - left, abs_end + right) clipped to [0, total_n)."""
+        flags = 0
+        if device_ptr is not None:
+            ptr, flags = int(device_ptr), AM_F_DEVICE_IN
+        else:
+            f = _iq_f32(iq_with_halo)
+            ptr = f.ctypes.data if f.size else None
+        cap = max(1024, (abs_end - abs_start) // 8)
+        while True:
+            recs = np.zeros(cap, CAND_DTYPE)
+            got = C.c_uint64(0)
+            rc = self.lib.L.am_shard_scan(self._h, ptr, abs_start, abs_end, total_n, flags, recs.ctypes.data, cap,
+                                          C.byref(got))
+            if rc == AM_ECAPACITY:
+                cap = int(got.value)
+                continue
+            self._chk(rc)
+            return recs[:got.value]
+
+    def shard_resolve(self, all_recs, capacity=None):
+        r = np.ascontiguousarray(all_recs, CAND_DTYPE)
+        cap = int(capacity) if capacity is not None else max(64, r.size)
+        out = np.zeros(cap, PACKET_DTYPE)
+        got = C.c_uint64(0)
+        rc = self.lib.L.am_shard_resolve(self._h, r.ctypes.data if r.size else None, r.size, 0, out.ctypes.data, cap,
+                                         C.byref(got))
+        if rc == AM_ECAPACITY:
+            return self._fetch(int(got.value))
+        self._chk(rc)
+        return out[:got.value]

@@ -1,0 +1,96 @@
+// am_internal.h -- kernel launch interface between am_capi.hip (host logic) and
+// am_kernels.hip (gfx950 kernels).  Not part of the public ABI.
+#ifndef AM_INTERNAL_H
+#define AM_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "airmodes_hip.h"
+
+#define AM_CHIPS_AVG 48    /* reference level window in chips  (python/rx_path.py:54)      */
+#define AM_BURST 240       /* chips handed to the slicer       (lib/preamble_impl.cc:219)  */
+#define AM_WAVE 64
+
+/* ---- front end ---------------------------------------------------------------------- */
+#define AM_FE_THREADS 512
+#define AM_FE_LDS_BUDGET (80 * 1024)
+
+struct am_fe_args {
+    const float *iq;      /* interleaved I,Q; element 0 is absolute sample src_abs0        */
+    long long src_abs0;   /* absolute index of the first sample present in iq              */
+    long long src_abs1;   /* absolute end (exclusive) of the samples present               */
+    long long out_abs0;   /* absolute index of bb[0]/avg[0]; multiple of 48*spc            */
+    long long out_n;      /* number of outputs wanted                                      */
+    float *bb;
+    float *avg;
+    int spc;
+    int use_pmf;
+    int tile;             /* outputs per workgroup; multiple of 48*spc                     */
+    float s1;             /* float(1.0/spc)                                                */
+    float sL;             /* float(1.0/(48*spc))                                           */
+};
+size_t am_fe_lds_bytes(int spc, int tile);
+int am_fe_pick_tile(int spc);                  /* largest tile within AM_FE_LDS_BUDGET, 0 if none */
+hipError_t am_launch_frontend(const am_fe_args &a, hipStream_t s);
+
+/* ---- preamble detection / refinement / greedy chain ----------------------------------- */
+#define AM_DET_THREADS 256
+#define AM_DET_PER_THREAD 8
+#define AM_DET_PER_BLOCK (AM_DET_THREADS * AM_DET_PER_THREAD)
+
+struct am_scan_buffers {
+    /* per detect block */
+    uint32_t *cand_seg;    /* nblk * AM_DET_PER_BLOCK candidate positions (segmented)       */
+    uint32_t *blk_cnt;     /* nblk                                                          */
+    uint32_t *blk_off;     /* nblk + 1 (exclusive scan, last = total)                       */
+    /* per candidate (flat, position order) */
+    uint32_t *pos;         /* position where the first-stage test fired                     */
+    uint32_t *e;           /* shifted preamble start                                        */
+    uint32_t *tgt;         /* where the scan resumes after this candidate                   */
+    uint8_t *valid;
+    uint8_t *visited;
+    uint8_t *emit;
+    uint32_t *jump;        /* (levels+1) * (M+1) pointer-doubling tables                    */
+    uint32_t *emit_idx;    /* compacted indices of emitted candidates                       */
+    uint32_t *cblk_cnt;    /* compaction block counts / offsets                             */
+    uint32_t *cblk_off;
+    uint32_t *scalars;     /* [0] = final scan position, [1] = visited&valid count          */
+};
+
+hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint32_t j1, int spc,
+                            float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, uint32_t nblk,
+                            hipStream_t s);
+/* exclusive scan of n counts into off[0..n]; off[n] = total */
+hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hipStream_t s);
+hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
+                            const uint32_t *cand_seg, const uint32_t *blk_cnt,
+                            const uint32_t *blk_off, uint32_t nblk, uint32_t *pos, uint32_t *e,
+                            uint32_t *tgt, uint8_t *valid, hipStream_t s);
+hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
+                                uint32_t *jump0, uint8_t *visited, hipStream_t s);
+hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, hipStream_t s);
+hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, hipStream_t s);
+hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *e,
+                                const uint32_t *tgt, uint32_t M, uint32_t emit_max, uint8_t *emit,
+                                uint32_t *scalars, hipStream_t s);
+hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
+hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
+                                  uint32_t *out_idx, hipStream_t s);
+/* records from an exchanged candidate list (time-sharded mode) */
+hipError_t am_launch_cand_import(const am_cand *recs, uint32_t M, uint64_t base_abs, int spc,
+                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, uint8_t *valid,
+                                 hipStream_t s);
+hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const uint8_t *valid,
+                                 uint32_t M, uint64_t base_abs, am_cand *recs, hipStream_t s);
+
+/* ---- burst extraction + slicer + CRC --------------------------------------------------- */
+hipError_t am_launch_extract(const float *bb, const float *avg, int spc, const uint32_t *emit_idx,
+                             uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
+                             uint64_t base_abs, uint64_t rate, float *bursts, am_tag *tags,
+                             hipStream_t s);
+/* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
+hipError_t am_launch_slice(const float *bursts, const am_tag *tags, uint32_t n,
+                           const uint32_t *crc_pow, am_packet *packets, hipStream_t s);
+
+#endif

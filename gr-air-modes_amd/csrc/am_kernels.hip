@@ -1,0 +1,730 @@
+// am_kernels.hip -- gfx950 (MI355X, wave64) kernels of the Mode-S receive hot path.
+//
+// Everything here is HBM-bound streaming / sparse integer work: no MFMA.  Floating point
+// follows the reference expression by expression (one IEEE rounding per written operation);
+// the translation unit is built with -ffp-contract=off and contraction is also disabled by
+// pragma so that  re*re + im*im,  sum*scale,  avg*thr  are never fused.
+//
+// Reference behaviour implemented (paths relative to the gr-air-modes tree):
+//   front end        python/rx_path.py:38,49,54  (|.|^2, moving_average_ff(spc), (48*spc))
+//   detect/refine    lib/preamble_impl.cc:172-209
+//   greedy chain     lib/preamble_impl.cc:172,209,237  (scan order / skip semantics)
+//   extract + tag    lib/preamble_impl.cc:100-137,219-232
+//   slicer + CRC     lib/slicer_impl.cc:67-182, lib/modes_crc.cc:38-63
+// The summation order inside the two moving averages is the chip-aligned two-level order
+// of DESIGN.md section 3 (GNU Radio's own order depends on its scheduler).
+#include "am_internal.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+// LDS index padding: one spare word per 32 so that lanes walking their own chip (stride spc
+// words, spc = 32 at 64 Msps) hit different banks.
+#define PIDX(i) ((i) + ((i) >> 5))
+#define PADN(n) ((n) + ((n) >> 5) + 1)
+
+// ------------------------------------------------------------------------------------------
+// Front end: one workgroup = one tile of `tile` outputs (tile is a multiple of the 48-chip
+// block, tiles are aligned to the absolute sample index).  LDS holds the tile plus a left
+// halo of one 48-chip block (for the reference-level window) plus one chip (for the pulse
+// matched filter window):  X = |iq|^2 then bb,  S = in-chip suffix sums,  A = avg.
+// ------------------------------------------------------------------------------------------
+size_t am_fe_lds_bytes(int spc, int tile)
+{
+    const int L = AM_CHIPS_AVG * spc;
+    const int W = L + spc + tile;
+    size_t floats = (size_t)2 * PADN(W) + PADN(tile) + (size_t)3 * (W / spc + 1);
+    return floats * sizeof(float);
+}
+
+int am_fe_pick_tile(int spc)
+{
+    const int L = AM_CHIPS_AVG * spc;
+    int best = 0;
+    for (int t = L; t <= (1 << 20); t += L) {
+        if (am_fe_lds_bytes(spc, t) > AM_FE_LDS_BUDGET) break;
+        best = t;
+    }
+    if (best == 0 && am_fe_lds_bytes(spc, L) <= 160 * 1024) best = L;
+    return best;
+}
+
+__global__ void __launch_bounds__(AM_FE_THREADS) am_k_frontend(am_fe_args a)
+{
+    HIP_DYNAMIC_SHARED(float, smem);
+    const int spc = a.spc;
+    const int L = AM_CHIPS_AVG * spc;
+    const int LH = L + spc;          // left halo: one block of bb + one chip of |iq|^2
+    const int T = a.tile;
+    const int W = LH + T;
+    const int nch = W / spc;         // chips resident in LDS (chip 0 = the extra halo chip)
+    float *X = smem;
+    float *S = X + PADN(W);
+    float *A = S + PADN(W);
+    float *TOT = A + PADN(T);
+    float *PT = TOT + (nch + 1);
+    float *ST = PT + (nch + 1);
+    const int tid = threadIdx.x;
+    const int nt = blockDim.x;
+    const long long tile0 = a.out_abs0 + (long long)blockIdx.x * T;
+    const long long x0 = tile0 - LH;
+
+    // P1: coalesced IQ load, a1: m = fl(fl(I*I) + fl(Q*Q)); zeros outside the stream
+    const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
+    for (int i = tid; i < W; i += nt) {
+        const long long n = x0 + i;
+        float m = 0.0f;
+        if (n >= a.src_abs0 && n < a.src_abs1) {
+            const float2 v = iq2[n - a.src_abs0];
+            const float rr = v.x * v.x;
+            const float ii = v.y * v.y;
+            m = rr + ii;
+        }
+        X[PIDX(i)] = m;
+    }
+    __syncthreads();
+
+    // P2 (a3): pulse matched filter, window = one chip:
+    //   bb[n] = fl( (suf_prevchip[n-spc+1] + pre_chip[n]) * s1 ),  last sample of a chip: pre only
+    if (a.use_pmf && spc > 1) {
+        for (int q = tid; q < nch; q += nt) {
+            const int b = q * spc;
+            float acc = 0.0f;
+            for (int i = spc - 1; i >= 0; --i) {
+                acc = acc + X[PIDX(b + i)];
+                S[PIDX(b + i)] = acc;
+            }
+        }
+        __syncthreads();
+        for (int q = 1 + tid; q < nch; q += nt) {
+            const int b = q * spc;
+            float acc = 0.0f;
+            for (int i = 0; i < spc; ++i) {
+                acc = acc + X[PIDX(b + i)];
+                const float s = (i == spc - 1) ? acc : (S[PIDX(b - spc + i + 1)] + acc);
+                X[PIDX(b + i)] = s * a.s1;
+            }
+        }
+        __syncthreads();
+    }
+
+    // P3: chip totals (left->right) and in-chip suffix sums (right->left) of bb
+    for (int q = 1 + tid; q < nch; q += nt) {
+        const int b = q * spc;
+        float acc = 0.0f;
+        for (int i = 0; i < spc; ++i) acc = acc + X[PIDX(b + i)];
+        TOT[q] = acc;
+        acc = 0.0f;
+        for (int i = spc - 1; i >= 0; --i) {
+            acc = acc + X[PIDX(b + i)];
+            S[PIDX(b + i)] = acc;
+        }
+    }
+    __syncthreads();
+
+    // P4: per 48-chip block, exclusive prefix (PT) and exclusive suffix (ST) of chip totals
+    const int nblk = 1 + T / L;
+    for (int idx = tid; idx < 2 * nblk; idx += nt) {
+        const int qb = 1 + AM_CHIPS_AVG * (idx >> 1);
+        float acc = 0.0f;
+        if (idx & 1) {
+            for (int j = AM_CHIPS_AVG - 1; j >= 0; --j) { ST[qb + j] = acc; acc = acc + TOT[qb + j]; }
+        } else {
+            for (int j = 0; j < AM_CHIPS_AVG; ++j) { PT[qb + j] = acc; acc = acc + TOT[qb + j]; }
+        }
+    }
+    __syncthreads();
+
+    // P5 (a4): avg[n] = fl( (SUF[n-L+1] + PRE[n]) * sL ),  last sample of a block: PRE only
+    for (int q = 1 + AM_CHIPS_AVG + tid; q < nch; q += nt) {
+        const int b = q * spc;
+        const int j = (q - 1) % AM_CHIPS_AVG;
+        const float pt = PT[q];
+        float acc = 0.0f;
+        for (int i = 0; i < spc; ++i) {
+            acc = acc + X[PIDX(b + i)];
+            const float PRE = pt + acc;
+            float s;
+            if (j == AM_CHIPS_AVG - 1 && i == spc - 1) {
+                s = PRE;
+            } else {
+                const int al = b + i - L + 1;
+                const int qa = (i == spc - 1) ? (q - AM_CHIPS_AVG + 1) : (q - AM_CHIPS_AVG);
+                const float SUF = S[PIDX(al)] + ST[qa];
+                s = SUF + PRE;
+            }
+            A[PIDX(b + i - LH)] = s * a.sL;
+        }
+    }
+    __syncthreads();
+
+    // P6: coalesced stores
+    for (int i = tid; i < T; i += nt) {
+        const long long o = tile0 + i - a.out_abs0;
+        if (o < a.out_n) {
+            a.bb[o] = X[PIDX(LH + i)];
+            a.avg[o] = A[PIDX(i)];
+        }
+    }
+}
+
+hipError_t am_launch_frontend(const am_fe_args &a, hipStream_t s)
+{
+    if (a.out_n <= 0) return hipSuccess;
+    const size_t lds = am_fe_lds_bytes(a.spc, a.tile);
+    const unsigned grid = (unsigned)((a.out_n + a.tile - 1) / a.tile);
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(am_k_frontend),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc != hipSuccess) return rc;
+    hipLaunchKernelGGL(am_k_frontend, dim3(grid), dim3(AM_FE_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Detection (a6): first-stage predicate at every position, compacted in position order with
+// wave ballots.  Block b owns positions [j0 + b*2048, +2048) and a 2048-entry output segment,
+// so the segment can never overflow.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(AM_DET_THREADS)
+am_k_detect(const float *__restrict__ bb, const float *__restrict__ avg, uint32_t j0, uint32_t j1,
+            int spc, float thr_lin, uint32_t *__restrict__ cand_seg, uint32_t *__restrict__ blk_cnt)
+{
+    __shared__ uint32_t wl[AM_DET_THREADS / AM_WAVE][AM_DET_PER_THREAD * AM_WAVE];
+    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const int w = threadIdx.x / AM_WAVE;
+    const uint32_t base = j0 + blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
+    const uint32_t o1 = 2u * spc, o2 = 7u * spc, o3 = 9u * spc;
+    uint32_t cnt = 0;
+    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
+        const uint32_t j = base + it * AM_WAVE + lane;
+        bool c = false;
+        if (j < j1) {
+            const float x = bb[j];
+            const float thr = avg[j] * thr_lin;             // preamble_impl.cc:173
+            if (x > thr) {                                  // :174
+                if (!(bb[j + 1] > x) &&                     // :175
+                    !(bb[j + o1] < thr) && !(bb[j + o2] < thr) && !(bb[j + o3] < thr))   // :177-179
+                    c = true;
+            }
+        }
+        const unsigned long long m = __ballot(c);
+        if (c) wl[w][cnt + __popcll(m & ((1ull << lane) - 1ull))] = j;
+        cnt += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) wc[w] = cnt;
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+    for (int k = 0; k < AM_DET_THREADS / AM_WAVE; ++k) {
+        if (k < w) off += wc[k];
+        total += wc[k];
+    }
+    uint32_t *seg = cand_seg + (size_t)blockIdx.x * AM_DET_PER_BLOCK;
+    for (uint32_t i = lane; i < cnt; i += AM_WAVE) seg[off + i] = wl[w][i];
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
+}
+
+hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint32_t j1, int spc,
+                            float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, uint32_t nblk,
+                            hipStream_t s)
+{
+    if (nblk == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_detect, dim3(nblk), dim3(AM_DET_THREADS), 0, s, bb, avg, j0, j1, spc,
+                       thr_lin, cand_seg, blk_cnt);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan of block counts (single workgroup; the list is short: one entry per 2048
+// positions or per 2048 flags).
+// ------------------------------------------------------------------------------------------
+#define AM_SCAN_THREADS 1024
+__global__ void __launch_bounds__(AM_SCAN_THREADS)
+am_k_scan_u32(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t n)
+{
+    __shared__ uint32_t buf[2][AM_SCAN_THREADS];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += AM_SCAN_THREADS) {
+        const uint32_t i = c0 + tid;
+        const uint32_t v = (i < n) ? cnt[i] : 0u;
+        int cur = 0;
+        buf[0][tid] = v;
+        __syncthreads();
+        for (int d = 1; d < AM_SCAN_THREADS; d <<= 1) {
+            uint32_t x = buf[cur][tid];
+            if (tid >= d) x += buf[cur][tid - d];
+            buf[cur ^ 1][tid] = x;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[cur][tid];
+        const uint32_t base = carry;
+        if (i < n) off[i] = base + incl - v;
+        __syncthreads();
+        if (tid == AM_SCAN_THREADS - 1) carry = base + incl;
+        __syncthreads();
+    }
+    if (tid == 0) off[n] = carry;
+}
+
+hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_scan_u32, dim3(1), dim3(AM_SCAN_THREADS), 0, s, cnt, off, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Refinement (a7, a8): per candidate, lanes of a group evaluate the 4-pulse energy at the
+// spc+1 possible late shifts in parallel (each in the reference's double-precision,
+// chip-major order), the group ballot picks the first shift that is not "late", then the
+// lanes share the quiet-zone scan.  Group size G = power of two >= spc+1 (<= 64).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double am_preamble_energy(const float *__restrict__ p, int spc)
+{
+    double e = 0.0;
+    for (int i = 0; i < spc; ++i) e += (double)p[i];
+    for (int i = 0; i < spc; ++i) e += (double)p[2 * spc + i];
+    for (int i = 0; i < spc; ++i) e += (double)p[7 * spc + i];
+    for (int i = 0; i < spc; ++i) e += (double)p[9 * spc + i];
+    return e;
+}
+
+__global__ void __launch_bounds__(AM_DET_THREADS)
+am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc, float thr_lin,
+            int G, const uint32_t *__restrict__ cand_seg, const uint32_t *__restrict__ blk_cnt,
+            const uint32_t *__restrict__ blk_off, uint32_t *__restrict__ pos,
+            uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt, uint8_t *__restrict__ valid)
+{
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const int w = threadIdx.x / AM_WAVE;
+    const int gl = lane & (G - 1);              // lane within the group
+    const int gi = lane / G;                    // group within the wave
+    const int cpw = AM_WAVE / G;                // candidates per wave per step
+    const unsigned long long gmask =
+        (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (unsigned)(gi * G);
+    const uint32_t cnt = blk_cnt[blockIdx.x];
+    const uint32_t *seg = cand_seg + (size_t)blockIdx.x * AM_DET_PER_BLOCK;
+    const uint32_t out0 = blk_off[blockIdx.x];
+    const uint32_t step = (uint32_t)(AM_DET_THREADS / AM_WAVE) * cpw;
+    const uint32_t nsteps = (cnt + step - 1) / step;
+    for (uint32_t st = 0; st < nsteps; ++st) {
+        const uint32_t ci = st * step + (uint32_t)(w * cpw + gi);
+        const bool active = ci < cnt;
+        const uint32_t j = active ? seg[ci] : 0u;
+        // late-peak search (preamble_impl.cc:184-192): how_late = first s with
+        // !(E(j+s+1) > E(j+s)), at most spc
+        int how_late = -1;
+        for (int s0 = 0; s0 < spc; s0 += G - 1) {
+            const int s = s0 + gl;
+            double E = 0.0;
+            if (active && how_late < 0 && s <= spc) E = am_preamble_energy(bb + j + s, spc);
+            const double En = __shfl_down(E, 1, G);
+            const bool defined = active && how_late < 0 && s < spc && gl < G - 1;
+            const bool notlate = defined && !(En > E);
+            const unsigned long long m = __ballot(notlate) & gmask;
+            if (how_late < 0 && m) how_late = s0 + (__ffsll((long long)(m >> (unsigned)(gi * G))) - 1);
+        }
+        if (how_late < 0) how_late = spc;
+        const uint32_t e = j + (uint32_t)how_late;
+        // quiet zones (preamble_impl.cc:198-209)
+        bool bad = false;
+        if (active) {
+            const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
+            const float av = avg[e];
+            float ps = p0 + p1;
+            ps = ps + p2;
+            ps = ps + p3;
+            const float avgpeak = (float)((double)ps / 4.0);
+            const float sthr = av + (avgpeak - av) / thr_lin;
+            const int nz1 = 3 * spc + 1;              // offsets 3spc .. 6spc
+            const int nz = 8 * spc + 2;               // plus offsets 10spc .. 15spc
+            for (int o = gl; o < nz; o += G) {
+                const int offs = (o < nz1) ? (3 * spc + o) : (10 * spc + (o - nz1));
+                if (bb[e + offs] > sthr) bad = true;
+            }
+        }
+        const unsigned long long mb = __ballot(bad) & gmask;
+        if (active && gl == 0) {
+            const uint32_t g = out0 + ci;
+            const bool ok = (mb == 0ull);
+            pos[g] = j;
+            eo[g] = e;
+            valid[g] = ok ? 1 : 0;
+            tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+        }
+    }
+}
+
+hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
+                            const uint32_t *cand_seg, const uint32_t *blk_cnt,
+                            const uint32_t *blk_off, uint32_t nblk, uint32_t *pos, uint32_t *e,
+                            uint32_t *tgt, uint8_t *valid, hipStream_t s)
+{
+    if (nblk == 0) return hipSuccess;
+    int G = 2;
+    while (G < spc + 1 && G < 64) G <<= 1;
+    hipLaunchKernelGGL(am_k_refine, dim3(nblk), dim3(AM_DET_THREADS), 0, s, bb, avg, spc, thr_lin, G,
+                       cand_seg, blk_cnt, blk_off, pos, e, tgt, valid);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Greedy chain.  The reference scan visits candidates in position order; after visiting c it
+// resumes at tgt[c], so the next visited candidate is succ(c) = first candidate with
+// pos >= tgt[c].  The visited set is the orbit of the root under succ: computed with
+// pointer doubling (jump tables) and top-down marking.  Node M is the end sentinel.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ pos, uint32_t lo,
+                                                   uint32_t hi, uint32_t key)
+{
+    // first index in [lo, hi) with pos[idx] >= key (hi if none); gallop then bisect
+    uint32_t stepw = 1, l = lo, h = lo;
+    while (h < hi && pos[h] < key) { l = h + 1; h = (h + stepw < hi) ? h + stepw : hi; stepw <<= 1; }
+    if (h > hi) h = hi;
+    while (l < h) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (pos[mid] < key) l = mid + 1; else h = mid;
+    }
+    return l;
+}
+
+__global__ void __launch_bounds__(256)
+am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt, uint32_t M,
+                uint32_t cur0, uint32_t *__restrict__ jump0, uint8_t *__restrict__ visited)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < M) jump0[g] = am_lower_bound(pos, g + 1, M, tgt[g]);
+    if (g == M) jump0[M] = M;
+    if (g == 0) {
+        const uint32_t root = am_lower_bound(pos, 0, M, cur0);
+        if (root < M) visited[root] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+am_k_chain_double(const uint32_t *__restrict__ jk, uint32_t *__restrict__ jk1, uint32_t M)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g <= M) jk1[g] = jk[jk[g]];
+}
+
+__global__ void __launch_bounds__(256)
+am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < M && visited[g]) {
+        const uint32_t t = jk[g];
+        if (t < M) visited[t] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ valid,
+                const uint32_t *__restrict__ e, const uint32_t *__restrict__ tgt, uint32_t M,
+                uint32_t emit_max, uint8_t *__restrict__ emit, uint32_t *scalars)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    const bool vis = visited[g] != 0;
+    // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is
+    // not emitted (and nothing after it can be)
+    const bool em = vis && valid[g] && e[g] <= emit_max;
+    emit[g] = em ? 1 : 0;
+    if (vis) atomicMax(&scalars[0], tgt[g]);
+}
+
+static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
+                                uint32_t *jump0, uint8_t *visited, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M,
+                       cur0, jump0, visited);
+    return hipGetLastError();
+}
+hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_chain_double, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, jk, jk1, M);
+    return hipGetLastError();
+}
+hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_chain_mark, dim3(am_grid(M, 256)), dim3(256), 0, s, jk, visited, M);
+    return hipGetLastError();
+}
+hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *e,
+                                const uint32_t *tgt, uint32_t M, uint32_t emit_max, uint8_t *emit,
+                                uint32_t *scalars, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, 256)), dim3(256), 0, s, visited, valid, e, tgt, M,
+                       emit_max, emit, scalars);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordered compaction of a byte-flag array: per-block counts -> scan -> scatter.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(AM_DET_THREADS)
+am_k_flag_count(const uint8_t *__restrict__ flags, uint32_t M, uint32_t *__restrict__ blk_cnt)
+{
+    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const int w = threadIdx.x / AM_WAVE;
+    const uint32_t base = blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
+    uint32_t cnt = 0;
+    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
+        const uint32_t g = base + it * AM_WAVE + lane;
+        const bool c = g < M && flags[g] != 0;
+        cnt += (uint32_t)__popcll(__ballot(c));
+    }
+    if (lane == 0) wc[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < AM_DET_THREADS / AM_WAVE; ++k) t += wc[k];
+        blk_cnt[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(AM_DET_THREADS)
+am_k_flag_scatter(const uint8_t *__restrict__ flags, uint32_t M, const uint32_t *__restrict__ blk_off,
+                  uint32_t *__restrict__ out_idx)
+{
+    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const int w = threadIdx.x / AM_WAVE;
+    const uint32_t base = blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
+    uint32_t cnt = 0;
+    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
+        const uint32_t g = base + it * AM_WAVE + lane;
+        const bool c = g < M && flags[g] != 0;
+        cnt += (uint32_t)__popcll(__ballot(c));
+    }
+    if (lane == 0) wc[w] = cnt;
+    __syncthreads();
+    uint32_t off = blk_off[blockIdx.x];
+    for (int k = 0; k < w; ++k) off += wc[k];
+    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
+        const uint32_t g = base + it * AM_WAVE + lane;
+        const bool c = g < M && flags[g] != 0;
+        const unsigned long long m = __ballot(c);
+        if (c) out_idx[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = g;
+        off += (uint32_t)__popcll(m);
+    }
+}
+
+hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_flag_count, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, flags, M,
+                       blk_cnt);
+    return hipGetLastError();
+}
+hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
+                                  uint32_t *out_idx, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_flag_scatter, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, flags,
+                       M, blk_off, out_idx);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Candidate records <-> exchange format (time-sharded operation)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+am_k_cand_import(const am_cand *__restrict__ recs, uint32_t M, uint64_t base_abs, int spc,
+                 uint32_t *__restrict__ pos, uint32_t *__restrict__ e, uint32_t *__restrict__ tgt,
+                 uint8_t *__restrict__ valid)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    const am_cand r = recs[g];
+    const uint32_t p = (uint32_t)(r.pos - base_abs);
+    const uint32_t ee = p + r.shift;
+    pos[g] = p;
+    e[g] = ee;
+    valid[g] = r.valid ? 1 : 0;
+    tgt[g] = r.valid ? (ee + (uint32_t)(AM_BURST * spc)) : (ee + 1u);
+}
+
+__global__ void __launch_bounds__(256)
+am_k_cand_export(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
+                 const uint8_t *__restrict__ valid, uint32_t M, uint64_t base_abs,
+                 am_cand *__restrict__ recs)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    am_cand r;
+    r.pos = base_abs + pos[g];
+    r.shift = e[g] - pos[g];
+    r.valid = valid[g];
+    recs[g] = r;
+}
+
+hipError_t am_launch_cand_import(const am_cand *recs, uint32_t M, uint64_t base_abs, int spc,
+                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, uint8_t *valid,
+                                 hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_cand_import, dim3(am_grid(M, 256)), dim3(256), 0, s, recs, M, base_abs, spc, pos, e,
+                       tgt, valid);
+    return hipGetLastError();
+}
+hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const uint8_t *valid,
+                                 uint32_t M, uint64_t base_abs, am_cand *recs, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_cand_export, dim3(am_grid(M, 256)), dim3(256), 0, s, pos, e, valid, M, base_abs,
+                       recs);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Burst extraction + tag (a9): one wave per emitted preamble.
+//   out[c] = in[e + c*spc] - inavg[e]          preamble_impl.cc:219-221
+//   timestamp from the absolute item count     preamble_impl.cc:100-137 (file source: no rx_time)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int spc,
+             const uint32_t *__restrict__ emit_idx, uint32_t n_emit, const uint32_t *__restrict__ pos,
+             const uint32_t *__restrict__ eo, uint64_t base_abs, uint64_t rate,
+             float *__restrict__ bursts, am_tag *__restrict__ tags)
+{
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
+    if (i >= n_emit) return;
+    const uint32_t g = emit_idx[i];
+    const uint32_t e = eo[g];
+    const float av = avg[e];
+    for (int c = lane; c < AM_BURST; c += AM_WAVE)
+        bursts[(size_t)i * AM_BURST + c] = bb[e + (uint32_t)(c * spc)] - av;
+    if (lane == 0) {
+        am_tag t;
+        // item count as the preamble block numbers it: stream index + (history - 1)
+        t.sample = base_abs + e + (uint64_t)(2 * spc - 1);
+        t.secs = t.sample / rate;                                   // :124
+        t.frac = (double)(t.sample % rate) / (double)rate;          // :125
+        if (t.frac > 1.0f) { t.frac -= 1.0f; t.secs += 1; }         // :129-132
+        t.inavg = av;
+        t.how_late = e - pos[g];
+        tags[i] = t;
+    }
+}
+
+hipError_t am_launch_extract(const float *bb, const float *avg, int spc, const uint32_t *emit_idx,
+                             uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
+                             uint64_t base_abs, uint64_t rate, float *bursts, am_tag *tags,
+                             hipStream_t s)
+{
+    if (n_emit == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_emit, 4)), dim3(256), 0, s, bb, avg, spc, emit_idx, n_emit,
+                       pos, e, base_abs, rate, bursts, tags);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Slicer + CRC (a10-a12): one wave per burst, lane l slices bits l and l+64.
+// The syndrome is formed as the XOR of x^(nbits-1-j) mod G over the set bits j (CRC is
+// linear), reduced across the wave with xor-shuffles.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int am_chip_pair_slice(float c0, float c1, float lo, float hi, double half_lo)
+{
+    // slicer_impl.cc:74-98; returns decision | confidence << 1
+    const bool in0 = (c0 > lo) && (c0 < hi);
+    const bool in1 = (c1 > lo) && (c1 < hi);
+    int dec, conf;
+    if (in0 && !in1) { dec = 1; conf = 1; }
+    else if (in1 && !in0) { dec = 0; conf = 1; }
+    else if (in0 && in1) { dec = (c0 > c1) ? 1 : 0; conf = 0; }
+    else {
+        dec = (c0 > c1) ? 1 : 0;
+        const float loser = dec ? c1 : c0;
+        conf = ((double)loser < half_lo) ? 1 : 0;
+    }
+    return dec | (conf << 1);
+}
+
+__device__ __forceinline__ uint32_t am_bitrev8(uint32_t v)
+{
+    v = ((v & 0xF0u) >> 4) | ((v & 0x0Fu) << 4);
+    v = ((v & 0xCCu) >> 2) | ((v & 0x33u) << 2);
+    v = ((v & 0xAAu) >> 1) | ((v & 0x55u) << 1);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, uint32_t n,
+           const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets)
+{
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
+    if (i >= n) return;                                   // wave-uniform
+    const float *b = bursts + (size_t)i * AM_BURST;
+    float s = b[0] + b[2];                                // slicer_impl.cc:128-131
+    s = s + b[7];
+    s = s + b[9];
+    const float ref = (float)((double)s / 4.0);
+    const float hi = (float)((double)ref * 1.414);        // :71
+    const float lo = (float)((double)ref * 0.707);        // :72
+    const double half_lo = (double)lo * 0.5;              // :92,:95
+    const float *d = b + 16;                              // :133
+    const int r0 = am_chip_pair_slice(d[2 * lane], d[2 * lane + 1], lo, hi, half_lo);
+    int r1 = 2;                                           // bits >= 112 do not exist
+    if (lane < 112 - 64) r1 = am_chip_pair_slice(d[2 * (lane + 64)], d[2 * (lane + 64) + 1], lo, hi, half_lo);
+    unsigned long long m0 = __ballot(r0 & 1);
+    unsigned long long m1 = __ballot(r1 & 1);
+    unsigned long long l0 = __ballot(!(r0 & 2));
+    unsigned long long l1 = __ballot(!(r1 & 2));
+    const uint32_t hdr = am_bitrev8((uint32_t)(m0 & 0x1Full)) >> 3;       // :135-139
+    const bool longpkt = (hdr == 16 || hdr == 17 || hdr == 20 || hdr == 21);   // :140
+    const int nbits = longpkt ? 112 : 56;
+    if (!longpkt) {
+        m0 &= (1ull << 56) - 1ull; m1 = 0ull;
+        l0 &= (1ull << 56) - 1ull; l1 = 0ull;
+    }
+    int nlow = __popcll(l0) + __popcll(l1);
+    if (nlow > 24) nlow = 24;                             // :157 (counter saturates)
+    // syndrome
+    uint32_t part = 0;
+    if ((m0 >> lane) & 1ull) part ^= crc_pow[nbits - 1 - lane];
+    if (lane < 48 && ((m1 >> lane) & 1ull)) part ^= crc_pow[nbits - 1 - (lane + 64)];
+    for (int o = 32; o >= 1; o >>= 1) part ^= (uint32_t)__shfl_xor((int)part, o, AM_WAVE);
+    if (lane == 0) {
+        am_packet p;
+        for (int k = 0; k < 8; ++k) p.data[k] = (uint8_t)am_bitrev8((uint32_t)((m0 >> (8 * k)) & 0xFFull));
+        for (int k = 0; k < 6; ++k) p.data[8 + k] = (uint8_t)am_bitrev8((uint32_t)((m1 >> (8 * k)) & 0xFFull));
+        const uint32_t mt = (uint32_t)(p.data[0] >> 3) & 0x1Fu;              // :168
+        bool ok = (m0 | m1) != 0ull;                                         // :162-166
+        if (!longpkt && mt != 11 && nlow > 0) ok = false;                    // :170
+        if (mt == 11 && nlow >= 10) ok = false;                              // :171
+        if (part != 0 && (mt == 11 || mt == 17)) ok = false;                 // :182
+        p.nbytes = (uint8_t)(nbits / 8);
+        p.df = (uint8_t)mt;
+        p.numlowconf = (uint8_t)nlow;
+        p.reserved[0] = ok ? 1 : 0;
+        p.reserved[1] = 0;
+        p.reserved[2] = 0;
+        p.crc = part;
+        p.ref = ref;
+        p.reserved2 = 0;
+        const am_tag t = tags[i];
+        p.sample = t.sample;
+        p.secs = t.secs;
+        p.frac = t.frac;
+        packets[i] = p;
+    }
+}
+
+hipError_t am_launch_slice(const float *bursts, const am_tag *tags, uint32_t n, const uint32_t *crc_pow,
+                           am_packet *packets, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_slice, dim3(am_grid(n, 4)), dim3(256), 0, s, bursts, tags, n, crc_pow, packets);
+    return hipGetLastError();
+}

@@ -1,0 +1,185 @@
+/*
+ * airmodes_hip.h -- C ABI of libairmodes_hip.so, the MI355X (gfx950) implementation of the
+ * gr-air-modes receive hot path:  IQ -> |.|^2 -> moving-average threshold -> Mode-S preamble
+ * detection -> PPM bit slicing with confidence -> CRC-24 syndrome -> packet list.
+ *
+ * This header is the drop-in boundary.  Each entry point names the reference interface it
+ * replaces (paths relative to the gr-air-modes tree).  Plain pointers and sizes only; no
+ * C++ or torch types; no exceptions cross the boundary.  All functions returning int return
+ * AM_OK (0) or a negative AM_E* code; am_last_error() gives the text.
+ *
+ * Threading: a context is NOT thread-safe (one context per stream per GPU, as a GNU Radio
+ * block instance is single-threaded inside work()); setters take effect at the next call.
+ * Ownership: the caller owns every buffer it passes; the context owns its device buffers
+ * and the carry-over stream state and is released by am_destroy().
+ */
+#ifndef AIRMODES_HIP_H
+#define AIRMODES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AM_ABI_VERSION 1
+
+/* error codes */
+#define AM_OK          0
+#define AM_EINVAL     (-1)   /* bad argument (null pointer, non-multiple-of-2MHz rate, ...) */
+#define AM_ENODEV     (-2)   /* no usable HIP device                                        */
+#define AM_ENOMEM     (-3)   /* host or device allocation failed                            */
+#define AM_EHIP       (-4)   /* a HIP runtime call failed (see am_last_error)               */
+#define AM_ECAPACITY  (-5)   /* output did not fit; *n_out holds the required count         */
+#define AM_ENOTSUP    (-6)   /* option not implemented (use_dcblock)                        */
+
+/* flags for the *_work / am_process_iq calls */
+#define AM_F_DEVICE_IN  0x1u  /* input pointers are device memory on the context's GPU      */
+#define AM_F_FLUSH      0x2u  /* end of stream: examine the tail under the reference's
+                                 end-of-buffer rule (preamble_impl.cc:150,212)              */
+#define AM_F_DEVICE_OUT 0x4u  /* am_frontend_work only: bb/avg are device pointers          */
+
+/* One accepted Mode-S reply: what slicer_impl.cc:186-194 serialises into its text message
+ * (data, crc, reference_level, timestamp) plus the integer sample count behind the
+ * timestamp.  56 bytes, little endian, natural alignment.
+ * Replaces: struct modes_packet (include/gr_air_modes/types.h:29-40). */
+typedef struct am_packet {
+    uint8_t  data[14];     /* payload bits, MSB first; bytes beyond nbytes are zero        */
+    uint8_t  nbytes;       /* 7 = short (56 bit), 14 = long (112 bit)                      */
+    uint8_t  df;           /* downlink format = data[0] >> 3  (modes_packet.message_type)  */
+    uint8_t  numlowconf;   /* number of low-confidence bits, saturating at 24              */
+    uint8_t  reserved[3];
+    uint32_t crc;          /* 24-bit syndrome: crc(data[0..nbytes-3)) ^ last 3 bytes       */
+    float    ref;          /* reference_level (mean of the four preamble chips)            */
+    uint32_t reserved2;
+    uint64_t sample;       /* preamble item count: stream index + 2*spc - 1                */
+    uint64_t secs;         /* sample / rate                (tag_to_timestamp, :124)        */
+    double   frac;         /* (sample % rate) / rate       (tag_to_timestamp, :125)        */
+} am_packet;
+
+/* One preamble hit: the "preamble_found" stream tag (preamble_impl.cc:224-232) whose value
+ * is the (uint64 secs, double frac) tuple, attached to sample 0 of a 240-float burst. */
+typedef struct am_tag {
+    uint64_t sample;
+    uint64_t secs;
+    double   frac;
+    float    inavg;        /* reference level subtracted from the burst (:220)             */
+    uint32_t how_late;     /* late-peak shifts applied (:184-192)                          */
+} am_tag;
+
+typedef struct am_ctx am_ctx;
+
+uint32_t am_abi_version(void);
+
+/* ---- context = the rx_path hier block ------------------------------------------------
+ * Replaces: rx_path.__init__(rate, threshold, queue, use_pmf, use_dcblock)
+ *           (python/rx_path.py:27-65) and the two block factories
+ *           gr::air_modes::preamble::make(float channel_rate, float threshold_db)
+ *           (include/gr_air_modes/preamble.h:39), gr::air_modes::slicer::make(queue)
+ *           (include/gr_air_modes/slicer.h:41).
+ * rate must be a positive multiple of 2 MHz (integer samples per chip).
+ * use_dcblock != 0 -> NULL + AM_ENOTSUP (python/radio.py:118 default is off).
+ * device < 0 selects the current HIP device.  Returns NULL on failure; *err (optional)
+ * receives the code. */
+am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock,
+                  int *err);
+void am_destroy(am_ctx *ctx);
+
+/* Replaces: preamble::set_rate / set_threshold / get_rate / get_threshold
+ *           (include/gr_air_modes/preamble.h:41-44; lib/preamble_impl.cc:56-76) and
+ *           rx_path.set_rate / set_threshold / get_threshold / get_pmf (rx_path.py:67-87).
+ * am_set_rate also drops the carried stream state (window lengths change). */
+int    am_set_rate(am_ctx *ctx, double rate);
+int    am_set_threshold(am_ctx *ctx, float threshold_db);
+double am_get_rate(const am_ctx *ctx);
+float  am_get_threshold(const am_ctx *ctx);
+int    am_get_pmf(const am_ctx *ctx);
+/* start a new stream: sample counter, carry-over samples and greedy-scan state are cleared */
+int    am_reset(am_ctx *ctx);
+
+/* ---- the fused hot path ---------------------------------------------------------------
+ * Replaces, for one chunk of the input stream, everything rx_path wires together
+ * (python/rx_path.py:38-65): complex_to_mag_squared -> moving_average_ff(spc) ->
+ * moving_average_ff(48*spc) -> preamble::general_work (lib/preamble_impl.cc:139-246) ->
+ * slicer::work (lib/slicer_impl.cc:102-198) -> modes_check_crc (lib/modes_crc.cc:55-63).
+ *
+ * iq: n_complex interleaved (I,Q) float32 pairs = what blocks.file_source(gr_complex)
+ * delivers (python/radio.py:231); host memory, or device memory with AM_F_DEVICE_IN.
+ * Chunks may have any length; results do not depend on how the stream is chunked.
+ * Decisions that need look-ahead are deferred to a later call; AM_F_FLUSH ends the stream.
+ * out/cap: caller's packet array (host).  *n_out = packets produced by this call, in
+ * stream order.  AM_ECAPACITY if cap is too small (nothing is lost: call
+ * am_fetch_packets with a larger array). */
+int am_process_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
+                  am_packet *out, uint64_t cap, uint64_t *n_out);
+int am_fetch_packets(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
+/* preamble hits (tags) seen by the last am_process_iq call, accepted or not */
+uint64_t am_last_num_tags(const am_ctx *ctx);
+
+/* ---- block-level entry points (for block-by-block parity tests) -------------------------
+ * am_frontend_work: the three third-party blocks in front of the preamble detector
+ *   (rx_path.py:38,49,54) on a whole stream that starts at sample 0: bb = pulse-matched
+ *   power, avg = reference level, n floats each.
+ * am_preamble_work: gr::air_modes::preamble_impl::general_work run to completion over the
+ *   two float streams `in` and `inavg` (n items each, stream starts at item 0; the block's
+ *   history of 2*spc-1 zeros is implied).  bursts: cap*240 floats; tags: cap entries.
+ * am_slicer_work: gr::air_modes::slicer_impl::work over nbursts tagged bursts.
+ *   Only accepted packets are written to out. */
+int am_frontend_work(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
+                     float *bb, float *avg);
+int am_preamble_work(am_ctx *ctx, const float *in, const float *inavg, uint64_t n,
+                     uint32_t flags, float *bursts, am_tag *tags, uint64_t cap,
+                     uint64_t *n_out);
+int am_slicer_work(am_ctx *ctx, const float *bursts, const am_tag *tags, uint64_t nbursts,
+                   uint32_t flags, am_packet *out, uint64_t cap, uint64_t *n_out);
+
+/* ---- host-side helpers ------------------------------------------------------------------
+ * am_crc24: modes_check_crc(data, length) (lib/modes_crc.cc:55-63): CRC-24, generator
+ *   0xFFF409, zero initial value, over the first nbytes bytes.
+ * am_format_message: the text slicer_impl.cc:186-192 posts to the gr::msg_queue:
+ *   "<hex payload> <crc %06x> <reference_level> <secs> <frac>".  first != 0 formats the
+ *   reference level with 6 significant digits (the first message a slicer instance emits),
+ *   otherwise 10 (every later one) -- the member ostringstream keeps setprecision(10).
+ *   Returns the length written (excluding NUL) or AM_ECAPACITY. */
+uint32_t am_crc24(const uint8_t *data, int nbytes);
+int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
+
+/* ---- time-sharded operation (one context per GPU, one contiguous time chunk each) -------
+ * The greedy preamble scan is sequential only through a sparse candidate list, so a stream
+ * cut into G chunks is processed as: every rank runs am_shard_scan on its chunk (with the
+ * neighbours' boundary samples attached), the fixed-size candidate records are exchanged
+ * (all-gather), and every rank runs am_shard_resolve on the concatenated list, emitting the
+ * packets whose preamble starts inside its own chunk.
+ *
+ * am_shard_halo: number of complex samples a chunk needs from its left / right neighbour.
+ * am_shard_scan: iq holds samples [abs_start - left, abs_end + right) of the global stream
+ *   (left/right as returned by am_shard_halo, clipped at the stream ends; total_n = length
+ *   of the global stream).  Produces this chunk's candidate records into recs (host or
+ *   device per flags; AM_F_DEVICE_IN applies to iq, AM_F_DEVICE_OUT to recs).
+ * am_shard_resolve: all_recs = the G chunks' records concatenated in chunk order. */
+typedef struct am_cand {
+    uint64_t pos;          /* absolute stream index where the first-stage test fired       */
+    uint32_t shift;        /* late shifts: the preamble starts at pos + shift              */
+    uint32_t valid;        /* 1 = passed the quiet-zone validation                         */
+} am_cand;
+
+int am_shard_halo(const am_ctx *ctx, uint64_t *left, uint64_t *right);
+int am_shard_scan(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end,
+                  uint64_t total_n, uint32_t flags, am_cand *recs, uint64_t cap,
+                  uint64_t *n_recs);
+int am_shard_resolve(am_ctx *ctx, const am_cand *all_recs, uint64_t n_all, uint32_t flags,
+                     am_packet *out, uint64_t cap, uint64_t *n_out);
+
+/* last error text of the context (or of am_create when ctx == NULL) */
+const char *am_last_error(const am_ctx *ctx);
+
+/* timing of the last am_process_iq / am_shard_scan call, measured with HIP events on the
+ * context's own stream: device milliseconds for the whole call and for the dominant
+ * (front-end + detection) kernel.  Used by bench.py for the roofline line. */
+int am_last_timing(const am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRMODES_HIP_H */
