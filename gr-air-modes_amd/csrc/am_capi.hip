@@ -63,7 +63,7 @@ struct am_ctx {
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
     bool shard_ready = false;
 
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_total_ms = 0.0f, last_dom_ms = 0.0f;
 };
 
@@ -89,7 +89,7 @@ int fail(am_ctx *c, int code, const char *what, hipError_t rc = hipSuccess)
 int ensure(am_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return AM_OK;
-    if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + bytes / 8 + 4096;
     hipError_t rc = hipMalloc(&b.p, want);
     if (rc != hipSuccess) { b.p = nullptr; return fail(c, AM_ENOMEM, "hipMalloc", rc); }
@@ -105,7 +105,7 @@ int ensure(am_ctx *c, DevBuf &b, size_t bytes)
 
 void release(DevBuf &b)
 {
-    if (b.p) hipFree(b.p);
+    if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
 }
@@ -183,7 +183,6 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
     HIPCHK(c, am_launch_detect(bb, avg, j0, j1, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p,
                                (uint32_t *)c->blk_cnt.p, nblk, c->stream));
     HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nblk, c->stream));
-    if (c->ev[1]) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     uint32_t M = 0;
     HIPCHK(c, hipMemcpyAsync(&M, (uint32_t *)c->blk_off.p + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost,
                              c->stream));
@@ -206,7 +205,8 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
 // e lies in [own_lo, own_hi] and is <= emit_max are extracted (bb/avg must cover them).
 // cur0 = position at which the scan starts.  Fills h_packets / h_tags (+ h_bursts).
 int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M, uint32_t cur0,
-                        uint32_t emit_max, uint64_t base_abs, bool keep_bursts, uint32_t *final_cur)
+                        uint32_t emit_max, uint64_t base_abs, bool keep_bursts, uint32_t *final_cur,
+                        uint32_t own_lo = 0, uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
 {
     c->h_packets.clear();
     c->h_tags.clear();
@@ -231,9 +231,9 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
         HIPCHK(c, am_launch_chain_double(jump + (size_t)k * stride, jump + (size_t)(k + 1) * stride, M, c->stream));
     for (int k = levels; k >= 0; k--)
         HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, c->stream));
-    HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->e.p,
-                                   (uint32_t *)c->tgt.p, M, emit_max, (uint8_t *)c->emit.p,
-                                   (uint32_t *)c->scalars.p, c->stream));
+    HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
+                                   (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
+                                   (uint8_t *)c->emit.p, (uint32_t *)c->scalars.p, c->stream));
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
@@ -253,7 +253,7 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
                                      (uint32_t *)c->emit_idx.p, c->stream));
     HIPCHK(c, am_launch_extract(bb, avg, c->spc, (uint32_t *)c->emit_idx.p, n_emit, (uint32_t *)c->pos.p,
-                                (uint32_t *)c->e.p, base_abs, c->rate_i, (float *)c->bursts.p,
+                                (uint32_t *)c->e.p, base_abs, e_off, c->rate_i, (float *)c->bursts.p,
                                 (am_tag *)c->tags.p, c->stream));
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, n_emit, (uint32_t *)c->crc_pow.p,
                               (am_packet *)c->packets.p, c->stream));
@@ -348,7 +348,7 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             code = AM_EHIP;
             break;
         }
-        for (int i = 0; i < 3; i++) hipEventCreate(&c->ev[i]);
+        for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
         c->use_pmf = use_pmf ? 1 : 0;
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
@@ -373,14 +373,14 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
 void am_destroy(am_ctx *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs};
     for (DevBuf *b : all) release(*b);
-    for (int i = 0; i < 3; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -428,6 +428,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     const uint64_t LH = L + S;
     if (c->carry_n + n > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "chunk larger than 2^31 samples");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
 
     // 1. one contiguous device view of [src_abs0, S1): carried tail + new samples
@@ -476,8 +477,10 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
         HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         int rc = run_frontend(c, src, src_abs0, S1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         const uint32_t j0 = (uint32_t)(P0 - out_abs0), j1 = (uint32_t)(P1 - out_abs0);
         uint32_t M = 0;
         rc = run_candidates(c, bb, avg, j0, j1, &M);
@@ -512,8 +515,8 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
-    hipEventElapsedTime(&c->last_dom_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
+    (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
     return hand_out(c, out, cap, n_out);
 }
 
@@ -680,6 +683,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     if (nsrc > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "chunk larger than 2^31 samples");
     if (nsrc && !iq) return fail(c, AM_EINVAL, "null iq");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const float *src = iq;
     if (!(flags & AM_F_DEVICE_IN) && nsrc) {
@@ -703,8 +707,10 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
         HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         rc = run_candidates(c, bb, avg, (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M);
         if (rc != AM_OK) return rc;
     }
@@ -729,8 +735,8 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
-    hipEventElapsedTime(&c->last_dom_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
+    (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
     return AM_OK;
 }
 
@@ -754,34 +760,33 @@ int am_shard_resolve(am_ctx *c, const am_cand *all_recs, uint64_t n_all, uint32_
                                  c->stream));
         drecs = (const am_cand *)c->recs.p;
     }
-    // Positions are re-based on this chunk's array origin; candidates of earlier chunks wrap
-    // to huge uint32 values, so the chain is resolved on a monotone re-based copy instead:
-    // base the whole list on the first candidate's block.
+    // Re-base the global list on its first candidate so that positions fit in 32 bits, resolve
+    // the greedy chain over ALL candidates (identically on every rank), and extract / slice
+    // only the hits whose first-stage position lies in this rank's chunk.
     am_cand first;
     HIPCHK(c, hipMemcpyAsync(&first, drecs, sizeof(first), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint64_t gbase = first.pos;
     if (c->shard_total - gbase > 0xFFFF0000ull) return fail(c, AM_EINVAL, "stream span exceeds 2^32 samples");
+    uint64_t em = 0;
+    if (!flush_limits(c->shard_total, c->spc, &em) || em < gbase) return AM_OK;
+    if (c->shard_end <= gbase) return AM_OK;                  // nothing of this chunk in the list
     ENSURE(c, c->pos, ((size_t)M + 1) * sizeof(uint32_t));
     ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
     ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
     ENSURE(c, c->valid, (size_t)M + 1);
     HIPCHK(c, am_launch_cand_import(drecs, M, gbase, c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->e.p,
                                     (uint32_t *)c->tgt.p, (uint8_t *)c->valid.p, c->stream));
-    // resolve the global chain, then keep only the hits that start inside this chunk
-    uint64_t em = 0;
-    if (!flush_limits(c->shard_total, c->spc, &em)) return AM_OK;
-    if (em < gbase) return AM_OK;
-    // Two-pass: (1) chain with a global emit bound, flags for every hit; (2) mask hits outside
-    // [shard_start, shard_end) by bounding e through the emit kernel's limit and a low bound
-    // applied on the host after slicing is wasteful, so the device arrays are shifted instead:
-    // extraction reads bb/avg at (gbase - shard_base) + e.
+    const uint32_t own_lo = c->shard_start > gbase ? (uint32_t)(c->shard_start - gbase) : 0u;
+    const uint32_t own_hi = (uint32_t)(c->shard_end - gbase);
+    const long long e_off = (long long)gbase - (long long)c->shard_base;
     uint32_t fin = 0;
-    const float *bb = (const float *)c->bb.p + 0;
-    const float *avg = (const float *)c->avg.p + 0;
-    (void)bb; (void)avg;
-    return fail(c, AM_ENOTSUP, "am_shard_resolve: not finished");
-    (void)fin; (void)out; (void)cap;
+    int rc = run_chain_and_slice(c, (const float *)c->bb.p, (const float *)c->avg.p, M, 0u,
+                                 (uint32_t)(em - gbase), gbase, false, &fin, own_lo, own_hi, e_off);
+    if (rc != AM_OK) return rc;
+    c->last_tags = c->h_packets.size();
+    collect_accepted(c);
+    return hand_out(c, out, cap, n_out);
 }
 
 const char *am_last_error(const am_ctx *c) { return c ? c->err : g_create_err; }

@@ -424,15 +424,17 @@ am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M)
 
 __global__ void __launch_bounds__(256)
 am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ valid,
-                const uint32_t *__restrict__ e, const uint32_t *__restrict__ tgt, uint32_t M,
-                uint32_t emit_max, uint8_t *__restrict__ emit, uint32_t *scalars)
+                const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
+                const uint32_t *__restrict__ tgt, uint32_t M, uint32_t emit_max, uint32_t own_lo,
+                uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *scalars)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
     const bool vis = visited[g] != 0;
     // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is
-    // not emitted (and nothing after it can be)
-    const bool em = vis && valid[g] && e[g] <= emit_max;
+    // not emitted (and nothing after it can be).  [own_lo, own_hi) restricts the output to
+    // the hits this GPU's time chunk owns (everything in single-GPU operation).
+    const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
     emit[g] = em ? 1 : 0;
     if (vis) atomicMax(&scalars[0], tgt[g]);
 }
@@ -456,13 +458,14 @@ hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M
     hipLaunchKernelGGL(am_k_chain_mark, dim3(am_grid(M, 256)), dim3(256), 0, s, jk, visited, M);
     return hipGetLastError();
 }
-hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *e,
-                                const uint32_t *tgt, uint32_t M, uint32_t emit_max, uint8_t *emit,
-                                uint32_t *scalars, hipStream_t s)
+hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
+                                const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
+                                uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *scalars,
+                                hipStream_t s)
 {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, 256)), dim3(256), 0, s, visited, valid, e, tgt, M,
-                       emit_max, emit, scalars);
+    hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, 256)), dim3(256), 0, s, visited, valid, pos, e, tgt, M,
+                       emit_max, own_lo, own_hi, emit, scalars);
     return hipGetLastError();
 }
 
@@ -593,7 +596,7 @@ hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const u
 __global__ void __launch_bounds__(256)
 am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int spc,
              const uint32_t *__restrict__ emit_idx, uint32_t n_emit, const uint32_t *__restrict__ pos,
-             const uint32_t *__restrict__ eo, uint64_t base_abs, uint64_t rate,
+             const uint32_t *__restrict__ eo, uint64_t base_abs, long long e_off, uint64_t rate,
              float *__restrict__ bursts, am_tag *__restrict__ tags)
 {
     const int lane = threadIdx.x & (AM_WAVE - 1);
@@ -601,9 +604,10 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int sp
     if (i >= n_emit) return;
     const uint32_t g = emit_idx[i];
     const uint32_t e = eo[g];
-    const float av = avg[e];
+    const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
+    const float av = avg[ei];
     for (int c = lane; c < AM_BURST; c += AM_WAVE)
-        bursts[(size_t)i * AM_BURST + c] = bb[e + (uint32_t)(c * spc)] - av;
+        bursts[(size_t)i * AM_BURST + c] = bb[ei + (size_t)(c * spc)] - av;
     if (lane == 0) {
         am_tag t;
         // item count as the preamble block numbers it: stream index + (history - 1)
@@ -619,12 +623,12 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int sp
 
 hipError_t am_launch_extract(const float *bb, const float *avg, int spc, const uint32_t *emit_idx,
                              uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
-                             uint64_t base_abs, uint64_t rate, float *bursts, am_tag *tags,
-                             hipStream_t s)
+                             uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
+                             am_tag *tags, hipStream_t s)
 {
     if (n_emit == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_emit, 4)), dim3(256), 0, s, bb, avg, spc, emit_idx, n_emit,
-                       pos, e, base_abs, rate, bursts, tags);
+                       pos, e, base_abs, e_off, rate, bursts, tags);
     return hipGetLastError();
 }
 

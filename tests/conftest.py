@@ -1,0 +1,44 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "gr-air-modes_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools"),
+          os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+HIP_LIB = os.path.join(ROOT, "gr-air-modes_amd", "csrc", "libairmodes_hip.so")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "libairmodes_emu.so")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """The product sources compiled against tests/emu (CPU fibers): kernel logic on a box
+    without a GPU.  Test-only; never loaded by the product package."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")])
+    from air_modes import _capi
+    return _capi.Library(EMU_LIB)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The real library on a real GPU.  Fails loudly (no fallback) when it is missing."""
+    if not os.path.exists(HIP_LIB):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gr-air-modes_amd", "csrc")])
+    from air_modes import _capi
+    return _capi.Library(HIP_LIB)

@@ -1,0 +1,140 @@
+"""Shared parity checks: the same assertions run against the CPU-fiber emulation of the
+kernels (no GPU, `-m "not gpu"`) and against the real HIP library (`-m gpu`)."""
+import glob
+import os
+
+import numpy as np
+
+import oracle
+import synth
+from air_modes import _capi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def u32(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "g_*.npz")))
+
+
+def load_golden(path):
+    z = np.load(path)
+    return dict(iq=z["iq"], rate=float(z["rate"]), thr=float(z["thr_db"]), pmf=bool(int(z["use_pmf"])),
+                ref_bursts=z["ref_bursts"], ref_sample=z["ref_tag_sample"], ref_secs=z["ref_tag_secs"],
+                ref_frac=z["ref_tag_frac"], ref_msgs=[str(m) for m in z["ref_msgs"]],
+                bb_sha=str(z["bb_sha256"]), avg_sha=str(z["avg_sha256"]))
+
+
+def messages(lib, packets):
+    return [lib.format_message(packets[i], i == 0) for i in range(len(packets))]
+
+
+def check_golden(lib, path):
+    """Product path vs what the REFERENCE's own C++ produced (tests/golden)."""
+    g = load_golden(path)
+    spc = int(g["rate"] / 2e6)
+    ctx = _capi.Context(g["rate"], g["thr"], g["pmf"], lib=lib)
+    bb, avg = ctx.frontend_work(g["iq"])
+    obb, oavg = oracle.frontend(g["iq"], spc, g["pmf"])
+    assert np.array_equal(u32(bb), u32(obb)) and np.array_equal(u32(avg), u32(oavg))
+    bursts, tags = ctx.preamble_work(bb, avg)
+    assert len(tags) == len(g["ref_sample"])
+    assert np.array_equal(tags["sample"], g["ref_sample"])
+    assert np.array_equal(tags["secs"], g["ref_secs"])
+    assert np.array_equal(tags["frac"], g["ref_frac"])
+    assert np.array_equal(u32(bursts), u32(g["ref_bursts"]))
+    pk = ctx.slicer_work(bursts, tags)
+    assert messages(lib, pk) == g["ref_msgs"]
+    pk2 = ctx.process_iq(g["iq"], flush=True)
+    assert messages(lib, pk2) == g["ref_msgs"]
+    ctx.close()
+
+
+def check_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True):
+    """Stage-by-stage and end-to-end, product path vs oracle, on a seeded capture."""
+    spc = int(rate / 2e6)
+    iq, _ = synth.synth_capture(rate, n, lam, seed)
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    bb, avg = ctx.frontend_work(iq)
+    obb, oavg = oracle.frontend(iq, spc, pmf)
+    assert np.array_equal(u32(bb), u32(obb)), "bb differs"
+    assert np.array_equal(u32(avg), u32(oavg)), "avg differs"
+    bursts, tags = ctx.preamble_work(obb, oavg)
+    ob, ot = oracle.preamble_scan(obb, oavg, spc, thr, rate)
+    assert len(tags) == len(ot) and np.array_equal(tags, ot), "tags differ"
+    assert np.array_equal(u32(bursts), u32(ob)), "bursts differ"
+    pk = ctx.slicer_work(ob, ot)
+    opk = oracle.slice_bursts(ob, ot)
+    assert np.array_equal(pk, opk), "slicer differs"
+    whole = ctx.process_iq(iq, flush=True)
+    want = oracle.demod(iq, rate, thr, pmf)
+    assert np.array_equal(whole, want), "end-to-end differs"
+    assert messages(lib, whole) == oracle.format_messages(want)
+    ctx.close()
+    return len(want)
+
+
+def check_chunked(lib, rate, iq, edges, thr=7.0, pmf=True, want=None):
+    """Results must not depend on how the stream is cut into am_process_iq calls."""
+    if want is None:
+        want = oracle.demod(iq, rate, thr, pmf)
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    parts = []
+    n = len(iq)
+    edges = [0] + [e for e in edges if 0 < e < n] + [n]
+    for a, b in zip(edges[:-1], edges[1:]):
+        parts.append(ctx.process_iq(iq[a:b], flush=(b == n)))
+    got = np.concatenate(parts) if parts else np.zeros(0, _capi.PACKET_DTYPE)
+    ctx.close()
+    assert np.array_equal(got, want), "chunked result differs (%d vs %d packets)" % (len(got), len(want))
+    return len(got)
+
+
+def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None):
+    """Time-sharded operation (G chunks, candidate exchange) == whole-stream result."""
+    n = len(iq)
+    if want is None:
+        want = oracle.demod(iq, rate, thr, pmf)
+    ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
+    hl, hr = ctxs[0].shard_halo()
+    bounds = [(g * n) // G for g in range(G + 1)]
+    recs = []
+    for g in range(G):
+        a, b = bounds[g], bounds[g + 1]
+        recs.append(ctxs[g].shard_scan(iq[max(0, a - hl):min(n, b + hr)], a, b, n))
+    allr = np.concatenate(recs)
+    got = np.concatenate([ctxs[g].shard_resolve(allr) for g in range(G)])
+    for c in ctxs:
+        c.close()
+    assert np.array_equal(got, want), "sharded result differs (%d vs %d packets)" % (len(got), len(want))
+    return len(got)
+
+
+def edge_inputs(rate, seed=5):
+    """Edge cases: empty, shorter than one burst, exactly at the room limit, all zeros,
+    huge / tiny / non-finite samples."""
+    spc = int(rate / 2e6)
+    rng = np.random.default_rng(seed)
+    base, _ = synth.synth_capture(rate, 6000 * spc, 3e6 / (240 * spc) * 0.3 * spc, seed)
+    cases = {
+        "empty": np.zeros(0, np.complex64),
+        "one_sample": base[:1],
+        "short": base[:100 * spc],
+        "just_under_burst": base[:242 * spc - 1],
+        "zeros": np.zeros(3000 * spc, np.complex64),
+        "normal": base,
+        "ragged_len": base[:5000 * spc + (spc // 2 + 1)],
+    }
+    big = base * np.complex64(3e18)          # |.|^2 overflows to inf in places
+    cases["overflow"] = big
+    tiny = base * np.complex64(1e-22)        # |.|^2 is denormal / underflows
+    cases["denormal"] = tiny
+    nan = base.copy()
+    idx = rng.integers(0, len(nan), 25)
+    nan[idx] = np.complex64(complex(float("nan"), 1.0))
+    nan[rng.integers(0, len(nan), 25)] = np.complex64(complex(float("inf"), -1.0))
+    cases["nan_inf"] = nan
+    return cases

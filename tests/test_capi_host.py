@@ -1,0 +1,107 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol the
+public header declares; the reference-shaped Python surface behaves."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import conftest
+
+
+def header_symbols():
+    with open(os.path.join(conftest.ROOT, "include", "airmodes_hip.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_all_symbols():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(conftest.ROOT, "gr-air-modes_amd", "csrc")])
+    lib = ctypes.CDLL(conftest.HIP_LIB)
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libairmodes_hip.so does not export %s" % s
+    lib.am_abi_version.restype = ctypes.c_uint32
+    assert lib.am_abi_version() == 1
+    # host-only helpers are callable without a GPU
+    lib.am_crc24.restype = ctypes.c_uint32
+    b = bytes.fromhex("8D4840D6202CC371C32CE0")
+    assert lib.am_crc24(b, len(b)) == 0x576098
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a HIP device the product path must raise, not fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from air_modes import _capi
+    lib = _capi.Library(conftest.HIP_LIB)
+    with pytest.raises(_capi.AirModesError):
+        _capi.Context(4e6, 7.0, True, lib=lib)
+
+
+def test_missing_library_is_an_error(tmp_path):
+    from air_modes import _capi
+    with pytest.raises(OSError):
+        _capi.Library(str(tmp_path / "nope.so"))
+
+
+def test_packet_layout_matches_header():
+    from air_modes import _capi
+    d = _capi.PACKET_DTYPE
+    assert d.itemsize == 56
+    assert [d.fields[k][1] for k in ("data", "nbytes", "df", "numlowconf", "crc", "ref", "sample", "secs", "frac")] == \
+        [0, 14, 15, 16, 20, 24, 32, 40, 48]
+    assert _capi.TAG_DTYPE.itemsize == 32 and _capi.CAND_DTYPE.itemsize == 16
+
+
+def test_msg_queue_semantics():
+    import air_modes
+    q = air_modes.msg_queue()
+    assert q.empty_p() and q.count() == 0 and q.delete_head_nowait() is None
+    q.handle(air_modes.message.make_from_string("a b c"))
+    q.insert_tail(air_modes.message.make_from_string("d"))
+    assert q.count() == 2 and not q.empty_p()
+    assert q.delete_head().to_string() == "a b c"
+    assert q.delete_head_nowait().to_string() == "d"
+    q.insert_tail(air_modes.message("x"))
+    q.flush()
+    assert q.empty_p()
+
+
+def test_rx_path_surface_via_emulation(emu_lib):
+    """rx_path(rate, threshold, queue, use_pmf, use_dcblock) + setters, messages on the queue
+    in the reference's text format incl. the first-message precision quirk."""
+    import air_modes
+    import oracle
+    import synth
+    q = air_modes.msg_queue()
+    rx = air_modes.rx_path(4e6, 7.0, q, use_pmf=True, use_dcblock=False, lib=emu_lib)
+    assert rx.get_threshold() == 7.0 and rx.get_pmf(None) is True
+    rx.set_pmf(False)                        # no-op, like the reference
+    assert rx.get_pmf(None) is True
+    iq, _ = synth.synth_capture(4e6, 150000, 2500.0, seed=12)
+    rx.work(iq[:40000])
+    rx.work(iq[40000:], flush=True)
+    got = []
+    while not q.empty_p():
+        got.append(q.delete_head().to_string())
+    want = oracle.format_messages(oracle.demod(iq, 4e6))
+    assert got == want and len(got) > 5
+    first, second = got[0].split(), got[1].split()
+    assert len(first) == 5 and len(first[0]) in (14, 28) and len(first[1]) == 6
+    assert len(first[2].replace(".", "").replace("-", "").lstrip("0")) <= 6      # %.6g
+    assert rx.packets == len(got) and rx.samples == len(iq)
+    # block-level objects
+    pre = air_modes.preamble(4e6, 7.0, lib=emu_lib)
+    assert pre.get_rate() == 4e6 and pre.get_threshold() == 7.0
+    bb, avg = oracle.frontend(iq, 2, True)
+    bursts, tags = pre.work(bb, avg)
+    q2 = air_modes.msg_queue()
+    sl = air_modes.slicer(q2, lib=emu_lib)
+    pk = sl.work(bursts, tags)
+    assert q2.count() == len(pk) == len(got)

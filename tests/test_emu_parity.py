@@ -1,0 +1,84 @@
+"""Kernel logic without a GPU: the unmodified product sources compiled against the CPU fiber
+emulation of the HIP launch model (tests/emu), compared bit-for-bit with the oracle and with
+the reference-generated golden vectors.  The same checks run on the real GPU in
+test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import oracle
+import parity_common as pc
+import synth
+from air_modes import _capi
+
+
+@pytest.mark.parametrize("path", pc.golden_cases(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden(emu_lib, path):
+    pc.check_golden(emu_lib, path)
+
+
+@pytest.mark.parametrize("rate,n,lam,seed,pmf", [(2e6, 200000, 2000.0, 31, True), (4e6, 200000, 2000.0, 32, True),
+                                                 (4e6, 150000, 2000.0, 33, False), (20e6, 400000, 6000.0, 34, True),
+                                                 (64e6, 700000, 20000.0, 35, True)])
+def test_stages(emu_lib, rate, n, lam, seed, pmf):
+    assert pc.check_stages(emu_lib, rate, n, lam, seed, pmf=pmf) > 5
+
+
+@pytest.mark.parametrize("rate", [2e6, 4e6, 20e6, 64e6])
+def test_edge_inputs(emu_lib, rate):
+    for name, iq in pc.edge_inputs(rate).items():
+        want = oracle.demod(iq, rate)
+        ctx = _capi.Context(rate, 7.0, True, lib=emu_lib)
+        got = ctx.process_iq(iq, flush=True)
+        assert np.array_equal(got, want), name
+        if len(iq):
+            bb, avg = ctx.frontend_work(iq)
+            obb, oavg = oracle.frontend(iq, int(rate / 2e6), True)
+            assert np.array_equal(pc.u32(bb), pc.u32(obb)), name
+            assert np.array_equal(pc.u32(avg), pc.u32(oavg)), name
+        ctx.close()
+
+
+@settings(max_examples=12, deadline=None)
+@given(st.lists(st.integers(1, 119999), min_size=0, max_size=6), st.sampled_from([2e6, 4e6, 20e6]))
+def test_chunk_invariance_property(emu_lib, cuts, rate):
+    n = 120000
+    iq, _ = synth.synth_capture(rate, n, 4e6 / 240 * 0.25, seed=77)
+    pc.check_chunked(emu_lib, rate, iq, sorted(set(cuts)))
+
+
+def test_chunk_invariance_tiny_chunks(emu_lib):
+    rate = 4e6
+    iq, _ = synth.synth_capture(rate, 30000, 3000.0, seed=78)
+    pc.check_chunked(emu_lib, rate, iq, list(range(997, 30000, 997)))
+
+
+@pytest.mark.parametrize("rate,n,G", [(2e6, 200000, 2), (2e6, 200000, 5), (20e6, 500000, 3), (64e6, 900000, 4)])
+def test_sharded(emu_lib, rate, n, G):
+    iq, _ = synth.synth_capture(rate, n, 8000.0, seed=91)
+    assert pc.check_sharded(emu_lib, rate, iq, G) > 3
+
+
+def test_setters_and_errors(emu_lib):
+    ctx = _capi.Context(4e6, 7.0, True, lib=emu_lib)
+    assert ctx.get_rate() == 4e6 and ctx.get_threshold() == 7.0 and ctx.get_pmf()
+    ctx.set_threshold(5.0)
+    assert ctx.get_threshold() == 5.0
+    ctx.set_rate(20e6)
+    assert ctx.get_rate() == 20e6
+    with pytest.raises(_capi.AirModesError):
+        ctx.set_rate(3e6)                       # fractional samples per chip: out of scope
+    with pytest.raises(_capi.AirModesError):
+        _capi.Context(4e6, 7.0, True, use_dcblock=True, lib=emu_lib)
+    iq, _ = synth.synth_capture(20e6, 100000, 3000.0, seed=3)
+    got = ctx.process_iq(iq, flush=True)
+    assert np.array_equal(got, oracle.demod(iq, 20e6, 5.0, True))
+    ctx.close()
+
+
+def test_crc_and_format_helpers(emu_lib):
+    assert emu_lib.crc24(bytes.fromhex("8D4840D6202CC371C32CE0")) == int("576098", 16)
+    for h in ("02E197B0A9A3B1", "8D40621D58C382D690C8AC2863A7"):
+        assert emu_lib.crc24(bytes.fromhex(h)) == oracle.crc24(bytes.fromhex(h))
