@@ -34,6 +34,27 @@ class AirModesError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (same soname as /opt/rocm's); if libairmodes_hip.so were loaded first it
+    would bind to the system copy, a later `import torch` would bring up a second runtime and
+    one of the two would see no device.  So when torch is installed but not yet imported, its
+    runtime library is loaded first (without importing torch) and ours binds to it by soname."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 class Library(object):
     """One loaded libairmodes_hip.so with typed entry points."""
 
@@ -44,6 +65,7 @@ class Library(object):
                           "`python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % path)
         self.path = path
+        _share_hip_runtime_with_torch()
         L = C.CDLL(path)
         vp, u64, u32, f32, f64, ci = C.c_void_p, C.c_uint64, C.c_uint32, C.c_float, C.c_double, C.c_int
         pu64 = C.POINTER(C.c_uint64)
