@@ -37,6 +37,7 @@ struct am_ctx {
     float thr_lin = 0.0f;
     int use_pmf = 0;
     int tile = 0;
+    bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     char err[256] = "";
 
     // stream state (absolute sample indices)
@@ -170,8 +171,32 @@ int run_frontend(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_ab
     return AM_OK;
 }
 
-// Candidate detection + refinement over positions [j0, j1) of device arrays bb/avg.
-// Leaves the flat records (pos, e, tgt, valid) on the device; *M_out = their number.
+// Scan of the per-segment candidate counts, read-back of the total, refinement of every
+// candidate.  Leaves the flat records (pos, e, tgt, valid) on the device; *M_out = their number.
+int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint32_t seg_stride, uint32_t *M_out)
+{
+    *M_out = 0;
+    if (nseg == 0) return AM_OK;
+    HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg, c->stream));
+    uint32_t M = 0;
+    HIPCHK(c, hipMemcpyAsync(&M, (uint32_t *)c->blk_off.p + nseg, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (M) {
+        ENSURE(c, c->pos, ((size_t)M + 1) * sizeof(uint32_t));
+        ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
+        ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
+        ENSURE(c, c->valid, (size_t)M + 1);
+        HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
+                                   (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p, (uint32_t *)c->e.p,
+                                   (uint32_t *)c->tgt.p, (uint8_t *)c->valid.p, c->stream));
+    }
+    *M_out = M;
+    return AM_OK;
+}
+
+// Candidate detection + refinement over positions [j0, j1) of existing device arrays bb/avg
+// (block-level entry point: the generic detection kernel).
 int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, uint32_t j1, uint32_t *M_out)
 {
     *M_out = 0;
@@ -182,23 +207,34 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
     ENSURE(c, c->blk_off, ((size_t)nblk + 1) * sizeof(uint32_t));
     HIPCHK(c, am_launch_detect(bb, avg, j0, j1, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p,
                                (uint32_t *)c->blk_cnt.p, nblk, c->stream));
-    HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nblk, c->stream));
-    uint32_t M = 0;
-    HIPCHK(c, hipMemcpyAsync(&M, (uint32_t *)c->blk_off.p + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (M) {
-        ENSURE(c, c->pos, ((size_t)M + 1) * sizeof(uint32_t));
-        ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
-        ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
-        ENSURE(c, c->valid, (size_t)M + 1);
-        HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p,
-                                   (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nblk,
-                                   (uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
-                                   (uint8_t *)c->valid.p, c->stream));
+    return run_refine(c, bb, avg, nblk, AM_DET_PER_BLOCK, M_out);
+}
+
+// IQ -> bb, avg and the refined candidate records for positions [j0, j1): the fused
+// specialisation when this samples-per-chip has one, the generic kernel pair otherwise.
+int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_abs1, uint64_t out_abs0,
+                             uint64_t out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, uint32_t *M_out)
+{
+    *M_out = 0;
+    const unsigned T2 = c->force_generic ? 0u : am_fe2_tile(c->spc);
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    if (T2 == 0) {
+        int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
+        if (rc != AM_OK) return rc;
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        return run_candidates(c, bb, avg, j0, j1, M_out);
     }
-    *M_out = M;
-    return AM_OK;
+    const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
+    ENSURE(c, c->cand_seg, (size_t)ntiles * T2 * sizeof(uint32_t));
+    ENSURE(c, c->blk_cnt, ((size_t)ntiles + 8) * sizeof(uint32_t));
+    ENSURE(c, c->blk_off, ((size_t)ntiles + 9) * sizeof(uint32_t));
+    unsigned nt = 0, tl = 0;
+    HIPCHK(c, am_launch_fe2(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
+                            (long long)out_n, bb, avg, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
+                            (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
+                            (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    return run_refine(c, bb, avg, nt, tl, M_out);
 }
 
 // Greedy chain over the M flat records + extraction + slicing.  Only hits whose shifted start
@@ -350,6 +386,10 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         }
         for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
         c->use_pmf = use_pmf ? 1 : 0;
+        {
+            const char *g = getenv("AIRMODES_GENERIC");
+            c->force_generic = g && g[0] == '1';
+        }
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
             break;
@@ -477,13 +517,9 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
         HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        int rc = run_frontend(c, src, src_abs0, S1, out_abs0, out_n, bb, avg);
-        if (rc != AM_OK) return rc;
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         const uint32_t j0 = (uint32_t)(P0 - out_abs0), j1 = (uint32_t)(P1 - out_abs0);
         uint32_t M = 0;
-        rc = run_candidates(c, bb, avg, j0, j1, &M);
+        int rc = run_front_and_candidates(c, src, src_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M);
         if (rc != AM_OK) return rc;
         const uint32_t cur0 = c->chain_cur > out_abs0 ? (uint32_t)std::min<uint64_t>(c->chain_cur - out_abs0, 0xFFFFFFF0u) : 0u;
         const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - out_abs0);
@@ -547,7 +583,13 @@ int am_frontend_work(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, flo
         dbb = (float *)c->bb.p;
         davg = (float *)c->avg.p;
     }
-    int rc = run_frontend(c, src, 0, n, 0, n, dbb, davg);
+    int rc;
+    if (!c->force_generic && am_fe2_tile(c->spc)) {
+        uint32_t M = 0;      // fused kernel with an empty detection range: bb/avg only
+        rc = run_front_and_candidates(c, src, 0, n, 0, n, dbb, davg, 0, 0, &M);
+    } else {
+        rc = run_frontend(c, src, 0, n, 0, n, dbb, davg);
+    }
     if (rc != AM_OK) return rc;
     if (!(flags & AM_F_DEVICE_OUT)) {
         HIPCHK(c, hipMemcpyAsync(bb, dbb, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -707,11 +749,8 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
         HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
         HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
-        HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-        int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
-        if (rc != AM_OK) return rc;
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        rc = run_candidates(c, bb, avg, (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M);
+        int rc = run_front_and_candidates(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg,
+                                          (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M);
         if (rc != AM_OK) return rc;
     }
     c->shard_base = out_abs0;

@@ -34,6 +34,14 @@ size_t am_fe_lds_bytes(int spc, int tile);
 int am_fe_pick_tile(int spc);                  /* largest tile within AM_FE_LDS_BUDGET, 0 if none */
 hipError_t am_launch_frontend(const am_fe_args &a, hipStream_t s);
 
+/* fused front end + detection, specialised per samples-per-chip (am_fe2.hip).
+ * am_fe2_tile(spc): tile length of the specialisation, 0 if spc has none (generic kernels). */
+unsigned am_fe2_tile(int spc);
+hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
+                         long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
+                         float sL, float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, unsigned *ntiles,
+                         unsigned *tile_len, hipStream_t s);
+
 /* ---- preamble detection / refinement / greedy chain ----------------------------------- */
 #define AM_DET_THREADS 256
 #define AM_DET_PER_THREAD 8
@@ -64,9 +72,9 @@ hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint
 /* exclusive scan of n counts into off[0..n]; off[n] = total */
 hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hipStream_t s);
 hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
-                            const uint32_t *cand_seg, const uint32_t *blk_cnt,
-                            const uint32_t *blk_off, uint32_t nblk, uint32_t *pos, uint32_t *e,
-                            uint32_t *tgt, uint8_t *valid, hipStream_t s);
+                            const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
+                            uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
+                            uint8_t *valid, hipStream_t s);
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
                                 uint32_t *jump0, uint8_t *visited, hipStream_t s);
 hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, hipStream_t s);

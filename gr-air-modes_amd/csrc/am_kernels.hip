@@ -278,10 +278,8 @@ hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hi
 }
 
 // ------------------------------------------------------------------------------------------
-// Refinement (a7, a8): per candidate, lanes of a group evaluate the 4-pulse energy at the
-// spc+1 possible late shifts in parallel (each in the reference's double-precision,
-// chip-major order), the group ballot picks the first shift that is not "late", then the
-// lanes share the quiet-zone scan.  Group size G = power of two >= spc+1 (<= 64).
+// Refinement (a7, a8): per candidate, the 4-pulse energy (double precision, chip-major order
+// as in the reference) at the late shifts it actually visits, then the quiet-zone scan.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double am_preamble_energy(const float *__restrict__ p, int spc)
 {
@@ -293,82 +291,61 @@ __device__ __forceinline__ double am_preamble_energy(const float *__restrict__ p
     return e;
 }
 
-__global__ void __launch_bounds__(AM_DET_THREADS)
+__global__ void __launch_bounds__(256)
 am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc, float thr_lin,
-            int G, const uint32_t *__restrict__ cand_seg, const uint32_t *__restrict__ blk_cnt,
-            const uint32_t *__restrict__ blk_off, uint32_t *__restrict__ pos,
-            uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt, uint8_t *__restrict__ valid)
+            const uint32_t *__restrict__ cand_seg, uint32_t seg_stride,
+            const uint32_t *__restrict__ blk_off, uint32_t nblk, uint32_t M,
+            uint32_t *__restrict__ pos, uint32_t *__restrict__ eo,
+            uint32_t *__restrict__ tgt, uint8_t *__restrict__ valid)
 {
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    const int w = threadIdx.x / AM_WAVE;
-    const int gl = lane & (G - 1);              // lane within the group
-    const int gi = lane / G;                    // group within the wave
-    const int cpw = AM_WAVE / G;                // candidates per wave per step
-    const unsigned long long gmask =
-        (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (unsigned)(gi * G);
-    const uint32_t cnt = blk_cnt[blockIdx.x];
-    const uint32_t *seg = cand_seg + (size_t)blockIdx.x * AM_DET_PER_BLOCK;
-    const uint32_t out0 = blk_off[blockIdx.x];
-    const uint32_t step = (uint32_t)(AM_DET_THREADS / AM_WAVE) * cpw;
-    const uint32_t nsteps = (cnt + step - 1) / step;
-    for (uint32_t st = 0; st < nsteps; ++st) {
-        const uint32_t ci = st * step + (uint32_t)(w * cpw + gi);
-        const bool active = ci < cnt;
-        const uint32_t j = active ? seg[ci] : 0u;
-        // late-peak search (preamble_impl.cc:184-192): how_late = first s with
-        // !(E(j+s+1) > E(j+s)), at most spc
-        int how_late = -1;
-        for (int s0 = 0; s0 < spc; s0 += G - 1) {
-            const int s = s0 + gl;
-            double E = 0.0;
-            if (active && how_late < 0 && s <= spc) E = am_preamble_energy(bb + j + s, spc);
-            const double En = __shfl_down(E, 1, G);
-            const bool defined = active && how_late < 0 && s < spc && gl < G - 1;
-            const bool notlate = defined && !(En > E);
-            const unsigned long long m = __ballot(notlate) & gmask;
-            if (how_late < 0 && m) how_late = s0 + (__ffsll((long long)(m >> (unsigned)(gi * G))) - 1);
-        }
-        if (how_late < 0) how_late = spc;
-        const uint32_t e = j + (uint32_t)how_late;
-        // quiet zones (preamble_impl.cc:198-209)
-        bool bad = false;
-        if (active) {
-            const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
-            const float av = avg[e];
-            float ps = p0 + p1;
-            ps = ps + p2;
-            ps = ps + p3;
-            const float avgpeak = (float)((double)ps / 4.0);
-            const float sthr = av + (avgpeak - av) / thr_lin;
-            const int nz1 = 3 * spc + 1;              // offsets 3spc .. 6spc
-            const int nz = 8 * spc + 2;               // plus offsets 10spc .. 15spc
-            for (int o = gl; o < nz; o += G) {
-                const int offs = (o < nz1) ? (3 * spc + o) : (10 * spc + (o - nz1));
-                if (bb[e + offs] > sthr) bad = true;
-            }
-        }
-        const unsigned long long mb = __ballot(bad) & gmask;
-        if (active && gl == 0) {
-            const uint32_t g = out0 + ci;
-            const bool ok = (mb == 0ull);
-            pos[g] = j;
-            eo[g] = e;
-            valid[g] = ok ? 1 : 0;
-            tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
-        }
+    // One lane per candidate.  The reference recomputes both energies on every pass of its
+    // do-while (preamble_impl.cc:184-192); the "now" energy of pass k+1 is the "late" energy of
+    // pass k (same samples, same order, same double roundings), so it is carried over.
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    // segment that holds flat candidate g: last b with blk_off[b] <= g
+    uint32_t lo = 0, hi = nblk;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blk_off[mid] <= g) lo = mid; else hi = mid;
     }
+    const uint32_t j = cand_seg[(size_t)lo * seg_stride + (g - blk_off[lo])];
+    int how_late = 0;
+    double e_now = am_preamble_energy(bb + j, spc);
+    for (;;) {
+        const double e_next = am_preamble_energy(bb + j + how_late + 1, spc);
+        const bool late = e_next > e_now;
+        if (late) { how_late++; e_now = e_next; }
+        if (!(late && how_late < spc)) break;
+    }
+    const uint32_t e = j + (uint32_t)how_late;
+    // quiet zones (preamble_impl.cc:198-209)
+    const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
+    const float av = avg[e];
+    float ps = p0 + p1;
+    ps = ps + p2;
+    ps = ps + p3;
+    const float avgpeak = (float)((double)ps / 4.0);
+    const float sthr = av + (avgpeak - av) / thr_lin;
+    bool ok = true;
+    const float *z1 = bb + e + 3 * spc;              // offsets 3spc .. 6spc
+    for (int o = 0; o <= 3 * spc && ok; ++o) if (z1[o] > sthr) ok = false;
+    const float *z2 = bb + e + 10 * spc;             // offsets 10spc .. 15spc
+    for (int o = 0; o <= 5 * spc && ok; ++o) if (z2[o] > sthr) ok = false;
+    pos[g] = j;
+    eo[g] = e;
+    valid[g] = ok ? 1 : 0;
+    tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
 }
 
 hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
-                            const uint32_t *cand_seg, const uint32_t *blk_cnt,
-                            const uint32_t *blk_off, uint32_t nblk, uint32_t *pos, uint32_t *e,
-                            uint32_t *tgt, uint8_t *valid, hipStream_t s)
+                            const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
+                            uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
+                            uint8_t *valid, hipStream_t s)
 {
-    if (nblk == 0) return hipSuccess;
-    int G = 2;
-    while (G < spc + 1 && G < 64) G <<= 1;
-    hipLaunchKernelGGL(am_k_refine, dim3(nblk), dim3(AM_DET_THREADS), 0, s, bb, avg, spc, thr_lin, G,
-                       cand_seg, blk_cnt, blk_off, pos, e, tgt, valid);
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_refine, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg, spc, thr_lin, cand_seg,
+                       seg_stride, blk_off, nblk, M, pos, e, tgt, valid);
     return hipGetLastError();
 }
 
@@ -429,14 +406,22 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
                 uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *scalars)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    const bool vis = visited[g] != 0;
+    const bool in = g < M;
+    const bool vis = in && visited[g] != 0;
     // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is
     // not emitted (and nothing after it can be).  [own_lo, own_hi) restricts the output to
     // the hits this GPU's time chunk owns (everything in single-GPU operation).
-    const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
-    emit[g] = em ? 1 : 0;
-    if (vis) atomicMax(&scalars[0], tgt[g]);
+    if (in) {
+        const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
+        emit[g] = em ? 1 : 0;
+    }
+    // where the scan resumes after everything visited here: the largest target (one atomic per wave)
+    uint32_t t = vis ? tgt[g] : 0u;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)t, o, AM_WAVE);
+        t = other > t ? other : t;
+    }
+    if ((threadIdx.x & (AM_WAVE - 1)) == 0 && t) atomicMax(&scalars[0], t);
 }
 
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }

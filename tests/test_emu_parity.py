@@ -20,8 +20,10 @@ def test_golden(emu_lib, path):
 
 
 @pytest.mark.parametrize("rate,n,lam,seed,pmf", [(2e6, 200000, 2000.0, 31, True), (4e6, 200000, 2000.0, 32, True),
-                                                 (4e6, 150000, 2000.0, 33, False), (20e6, 400000, 6000.0, 34, True),
-                                                 (64e6, 700000, 20000.0, 35, True)])
+                                                 (4e6, 150000, 2000.0, 33, False), (8e6, 200000, 3000.0, 36, True),
+                                                 (10e6, 250000, 3000.0, 37, True), (16e6, 300000, 4000.0, 38, True),
+                                                 (20e6, 400000, 6000.0, 34, True), (32e6, 400000, 6000.0, 39, True),
+                                                 (40e6, 500000, 6000.0, 40, True), (64e6, 700000, 20000.0, 35, True)])
 def test_stages(emu_lib, rate, n, lam, seed, pmf):
     assert pc.check_stages(emu_lib, rate, n, lam, seed, pmf=pmf) > 5
 
@@ -59,6 +61,17 @@ def test_chunk_invariance_tiny_chunks(emu_lib):
 def test_sharded(emu_lib, rate, n, G):
     iq, _ = synth.synth_capture(rate, n, 8000.0, seed=91)
     assert pc.check_sharded(emu_lib, rate, iq, G) > 3
+
+
+def test_generic_kernels_still_match(emu_lib, monkeypatch):
+    """Rates without a fused specialisation use the rate-generic kernels; force them for the
+    common rates too so both code paths stay pinned to the oracle."""
+    monkeypatch.setenv("AIRMODES_GENERIC", "1")
+    for rate, n in ((2e6, 120000), (20e6, 300000), (64e6, 500000)):
+        assert pc.check_stages(emu_lib, rate, n, 6000.0, 41) > 3
+    monkeypatch.delenv("AIRMODES_GENERIC")
+    assert pc.check_stages(emu_lib, 6e6, 200000, 3000.0, 42) > 3       # spc = 3: generic only
+    assert pc.check_stages(emu_lib, 50e6, 500000, 8000.0, 43) > 3      # spc = 25: generic only
 
 
 def test_setters_and_errors(emu_lib):

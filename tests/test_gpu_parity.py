@@ -28,13 +28,25 @@ def test_golden(lib, path):
 
 
 @pytest.mark.parametrize("rate,n,lam,seed,pmf", [(2e6, 1000000, 1500.0, 31, True), (4e6, 1000000, 1500.0, 32, True),
-                                                 (4e6, 500000, 2000.0, 33, False), (20e6, 3000000, 5000.0, 34, True),
+                                                 (4e6, 500000, 2000.0, 33, False), (8e6, 1000000, 2000.0, 37, True),
+                                                 (10e6, 1000000, 2000.0, 38, True), (16e6, 2000000, 3000.0, 39, True),
+                                                 (20e6, 3000000, 5000.0, 34, True), (32e6, 3000000, 5000.0, 40, True),
+                                                 (40e6, 3000000, 5000.0, 44, True),
                                                  (64e6, 6400000, 20000.0, 35, True), (100e6, 3000000, 10000.0, 36, True)])
 def test_stages(lib, rate, n, lam, seed, pmf):
     assert pc.check_stages(lib, rate, n, lam, seed, pmf=pmf) > 5
 
 
-@pytest.mark.parametrize("rate", [2e6, 4e6, 20e6, 64e6])
+def test_generic_kernels_still_match(lib, monkeypatch):
+    monkeypatch.setenv("AIRMODES_GENERIC", "1")
+    for rate, n in ((2e6, 1000000), (20e6, 2000000), (64e6, 4000000)):
+        assert pc.check_stages(lib, rate, n, 6000.0, 41) > 3
+    monkeypatch.delenv("AIRMODES_GENERIC")
+    assert pc.check_stages(lib, 6e6, 1000000, 3000.0, 42) > 3
+    assert pc.check_stages(lib, 50e6, 2000000, 8000.0, 43) > 3
+
+
+@pytest.mark.parametrize("rate", [2e6, 4e6, 8e6, 10e6, 16e6, 20e6, 32e6, 40e6, 64e6])
 def test_edge_inputs(lib, rate):
     for name, iq in pc.edge_inputs(rate).items():
         want = oracle.demod(iq, rate)
