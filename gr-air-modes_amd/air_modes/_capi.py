@@ -24,7 +24,7 @@ PACKET_DTYPE = np.dtype([
     ("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8")])
 TAG_DTYPE = np.dtype([("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8"),
                       ("inavg", "<f4"), ("how_late", "<u4")])
-CAND_DTYPE = np.dtype([("pos", "<u8"), ("shift", "<u4"), ("valid", "<u4")])
+CAND_DTYPE = np.dtype([("pos", "<u8"), ("shift_valid", "<u4"), ("inavg", "<f4")])
 assert PACKET_DTYPE.itemsize == 56 and TAG_DTYPE.itemsize == 32 and CAND_DTYPE.itemsize == 16
 
 

@@ -49,7 +49,8 @@ struct am_ctx {
     DevBuf carry, carry2;
 
     // work buffers (grow only)
-    DevBuf src, bb, avg, cand_seg, blk_cnt, blk_off, pos, e, tgt, valid, visited, emit, jump, emit_idx,
+    DevBuf src, bb, avg, cand_seg, seg_e, seg_inavg, seg_valid, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
+        visited, emit, jump, emit_idx,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs;
 
     // results of the last scan
@@ -171,9 +172,11 @@ int run_frontend(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_ab
     return AM_OK;
 }
 
-// Scan of the per-segment candidate counts, read-back of the total, refinement of every
-// candidate.  Leaves the flat records (pos, e, tgt, valid) on the device; *M_out = their number.
-int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint32_t seg_stride, uint32_t *M_out)
+// Scan of the per-segment candidate counts and read-back of the total; then either the
+// refinement kernel (generic path: candidates only) or the gather of the records the fused
+// kernel already produced.  Leaves the flat records (pos, e, tgt, inavg, valid) on the device.
+int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint32_t seg_stride, bool fused,
+               uint32_t *M_out)
 {
     *M_out = 0;
     if (nseg == 0) return AM_OK;
@@ -186,10 +189,18 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->pos, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
+        ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
         ENSURE(c, c->valid, (size_t)M + 1);
-        HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
-                                   (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p, (uint32_t *)c->e.p,
-                                   (uint32_t *)c->tgt.p, (uint8_t *)c->valid.p, c->stream));
+        if (fused)
+            HIPCHK(c, am_launch_flatten((uint32_t *)c->cand_seg.p, (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p,
+                                        (uint8_t *)c->seg_valid.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
+                                        c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
+                                        (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream));
+        else
+            HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
+                                       (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p,
+                                       (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, (float *)c->inavg.p,
+                                       (uint8_t *)c->valid.p, c->stream));
     }
     *M_out = M;
     return AM_OK;
@@ -207,7 +218,7 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
     ENSURE(c, c->blk_off, ((size_t)nblk + 1) * sizeof(uint32_t));
     HIPCHK(c, am_launch_detect(bb, avg, j0, j1, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p,
                                (uint32_t *)c->blk_cnt.p, nblk, c->stream));
-    return run_refine(c, bb, avg, nblk, AM_DET_PER_BLOCK, M_out);
+    return run_refine(c, bb, avg, nblk, AM_DET_PER_BLOCK, false, M_out);
 }
 
 // IQ -> bb, avg and the refined candidate records for positions [j0, j1): the fused
@@ -225,16 +236,21 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         return run_candidates(c, bb, avg, j0, j1, M_out);
     }
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
-    ENSURE(c, c->cand_seg, (size_t)ntiles * T2 * sizeof(uint32_t));
+    const size_t nslots = (size_t)ntiles * T2;
+    ENSURE(c, c->cand_seg, nslots * sizeof(uint32_t));
+    ENSURE(c, c->seg_e, nslots * sizeof(uint32_t));
+    ENSURE(c, c->seg_inavg, nslots * sizeof(float));
+    ENSURE(c, c->seg_valid, nslots);
     ENSURE(c, c->blk_cnt, ((size_t)ntiles + 8) * sizeof(uint32_t));
     ENSURE(c, c->blk_off, ((size_t)ntiles + 9) * sizeof(uint32_t));
     unsigned nt = 0, tl = 0;
     HIPCHK(c, am_launch_fe2(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
                             (long long)out_n, bb, avg, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                             (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
+                            (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p,
                             (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    return run_refine(c, bb, avg, nt, tl, M_out);
+    return run_refine(c, bb, avg, nt, tl, true, M_out);
 }
 
 // Greedy chain over the M flat records + extraction + slicing.  Only hits whose shifted start
@@ -288,7 +304,8 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
     ENSURE(c, c->packets, (size_t)n_emit * sizeof(am_packet));
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
                                      (uint32_t *)c->emit_idx.p, c->stream));
-    HIPCHK(c, am_launch_extract(bb, avg, c->spc, (uint32_t *)c->emit_idx.p, n_emit, (uint32_t *)c->pos.p,
+    HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_emit,
+                                (uint32_t *)c->pos.p,
                                 (uint32_t *)c->e.p, base_abs, e_off, c->rate_i, (float *)c->bursts.p,
                                 (am_tag *)c->tags.p, c->stream));
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, n_emit, (uint32_t *)c->crc_pow.p,
@@ -414,7 +431,8 @@ void am_destroy(am_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->blk_cnt, &c->blk_off,
+    DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->seg_e, &c->seg_inavg,
+                     &c->seg_valid, &c->inavg, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs};
@@ -512,11 +530,15 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         const uint64_t need0 = out_abs0 > LH ? out_abs0 - LH : 0;
         if (src_abs0 > need0) return fail(c, AM_EINVAL, "internal: stream history was not carried");
         const uint64_t pad = zero_pad(c->spc);
+        const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
-        ENSURE(c, c->avg, (out_n + pad) * sizeof(float));
-        float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
+        float *bb = (float *)c->bb.p, *avg = nullptr;
         HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+        if (generic) {          // the fused kernel carries the reference level in the candidate records
+            ENSURE(c, c->avg, (out_n + pad) * sizeof(float));
+            avg = (float *)c->avg.p;
+            HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+        }
         const uint32_t j0 = (uint32_t)(P0 - out_abs0), j1 = (uint32_t)(P1 - out_abs0);
         uint32_t M = 0;
         int rc = run_front_and_candidates(c, src, src_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M);
@@ -744,11 +766,15 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     const uint64_t pad = zero_pad(c->spc);
     uint32_t M = 0;
     if (P1 > P0 && out_n) {
+        const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
-        ENSURE(c, c->avg, (out_n + pad) * sizeof(float));
-        float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
+        float *bb = (float *)c->bb.p, *avg = nullptr;
         HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
-        HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+        if (generic) {
+            ENSURE(c, c->avg, (out_n + pad) * sizeof(float));
+            avg = (float *)c->avg.p;
+            HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+        }
         int rc = run_front_and_candidates(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg,
                                           (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M);
         if (rc != AM_OK) return rc;
@@ -767,8 +793,8 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
             ENSURE(c, c->recs, (size_t)M * sizeof(am_cand));
             drecs = (am_cand *)c->recs.p;
         }
-        HIPCHK(c, am_launch_cand_export((uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint8_t *)c->valid.p, M,
-                                        out_abs0, drecs, c->stream));
+        HIPCHK(c, am_launch_cand_export((uint32_t *)c->pos.p, (uint32_t *)c->e.p, (const float *)c->inavg.p,
+                                        (uint8_t *)c->valid.p, M, out_abs0, drecs, c->stream));
         if (!(flags & AM_F_DEVICE_OUT))
             HIPCHK(c, hipMemcpyAsync(recs, drecs, (size_t)M * sizeof(am_cand), hipMemcpyDeviceToHost, c->stream));
     }
@@ -814,13 +840,14 @@ int am_shard_resolve(am_ctx *c, const am_cand *all_recs, uint64_t n_all, uint32_
     ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
     ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
     ENSURE(c, c->valid, (size_t)M + 1);
+    ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
     HIPCHK(c, am_launch_cand_import(drecs, M, gbase, c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->e.p,
-                                    (uint32_t *)c->tgt.p, (uint8_t *)c->valid.p, c->stream));
+                                    (uint32_t *)c->tgt.p, (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream));
     const uint32_t own_lo = c->shard_start > gbase ? (uint32_t)(c->shard_start - gbase) : 0u;
     const uint32_t own_hi = (uint32_t)(c->shard_end - gbase);
     const long long e_off = (long long)gbase - (long long)c->shard_base;
     uint32_t fin = 0;
-    int rc = run_chain_and_slice(c, (const float *)c->bb.p, (const float *)c->avg.p, M, 0u,
+    int rc = run_chain_and_slice(c, (const float *)c->bb.p, nullptr, M, 0u,
                                  (uint32_t)(em - gbase), gbase, false, &fin, own_lo, own_hi, e_off);
     if (rc != AM_OK) return rc;
     c->last_tags = c->h_packets.size();

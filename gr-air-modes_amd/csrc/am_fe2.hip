@@ -8,8 +8,11 @@
 //       suffix/prefix sums in registers, bb -> registers; barrier; bb -> X in place
 //   P3  chip totals (left->right and right->left) -> small LDS arrays
 //   P4  per 48-chip block: exclusive prefix / suffix of chip totals (sequential, canonical order)
-//   P5  reference level avg[n] in registers + first-stage preamble test (a6) -> LDS bitmap
-//   P6  bb (coalesced, from X), ordered candidate list (bitmap + block scan), avg (staged via X)
+//   P5  reference level avg[n] in registers + first-stage preamble test (a6), branch-free from
+//       wide LDS loads of the runs 2, 7 and 9 chips ahead -> candidate bitmap
+//   P6  bb out (coalesced, from X), ordered candidate list (bitmap + block scan)
+//   P7  refinement (a7, a8) of this tile's candidates straight from LDS: late-peak search,
+//       quiet zones, reference level at the shifted start -> candidate records
 //
 // LDS holds ONE float per sample (X), so a 12 K-sample tile fits twice per CU; the left halo is
 // one 48-chip block + one chip (13 % at 64 Msps) and is served from L2 because consecutive
@@ -18,12 +21,14 @@
 // lib/preamble_impl.cc:172-179.
 #include "am_internal.h"
 
+#include <stdlib.h>
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
 
 #define FE2_NT 384
-#define FE2_RH_CHIPS 10                      /* detection looks ahead 9 chips + 1 sample */
+#define FE2_RH_CHIPS 17                      /* refinement looks ahead 16 chips + 1 sample */
 #define FE2_LH_CHIPS (AM_CHIPS_AVG + 1)      /* 48-chip block + one chip                 */
 #define FE2_HALO_THREADS (AM_CHIPS_AVG + FE2_RH_CHIPS)
 
@@ -81,19 +86,44 @@ __device__ __forceinline__ void fe2_pmf_chip(const float (&mp)[SPC], const float
     }
 }
 
+// tile -> global, 16 bytes per lane (the output arrays are 16-byte aligned and tiles start at
+// multiples of 4 samples); the ragged end of the stream falls back to scalar stores
+template <int T>
+__device__ __forceinline__ void fe2_store_tile(const float *X, int lhp, float *dst, long long o0, long long out_n,
+                                               int tid)
+{
+    static_assert(T % 4 == 0, "tile length");
+#pragma unroll 4
+    for (int i4 = tid; i4 < T / 4; i4 += FE2_NT) {
+        const long long o = o0 + 4 * i4;
+        const float4 t = *reinterpret_cast<const float4 *>(&X[fe2_pidx(lhp + 4 * i4)]);
+        if (o + 3 < out_n) {
+            *reinterpret_cast<float4 *>(&dst[o]) = t;
+        } else {
+            if (o < out_n) dst[o] = t.x;
+            if (o + 1 < out_n) dst[o + 1] = t.y;
+            if (o + 2 < out_n) dst[o + 2] = t.z;
+        }
+    }
+}
+
 struct am_fe2_args {
     const float *iq;
     long long src_abs0, src_abs1;   // absolute range of samples present in iq
-    long long out_abs0;             // absolute index of bb[0]/avg[0] (multiple of 48*spc)
+    long long out_abs0;             // absolute index of bb[0] (multiple of 48*spc)
     long long out_n;                // outputs wanted
-    float *bb;
-    float *avg;
+    float *bb;                      // dense pulse-matched power (read by burst extraction); may be null
+    float *avg;                     // dense reference level; only written when non-null (block-level API)
     uint32_t j0, j1;                // positions (array coordinates) whose preamble test is wanted
-    uint32_t *cand_seg;             // ntiles * T
+    uint32_t *seg_pos;              // per tile: T candidate positions ...
+    uint32_t *seg_e;                // ... shifted starts
+    float *seg_inavg;               // ... reference level at the shifted start
+    uint8_t *seg_valid;             // ... quiet-zone verdict
     uint32_t *blk_cnt;              // ntiles
     unsigned ntiles;
     int use_pmf;
     float s1, sL, thr_lin;
+    unsigned ablate;                // profiling only (AIRMODES_FE2_ABLATE): skip phases, results invalid
 };
 
 template <int SPC, int CPT>
@@ -108,14 +138,15 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     constexpr int NBLK = 1 + (FE2_NT * CPT) / AM_CHIPS_AVG;           // 48-chip blocks incl. halo block
     constexpr bool RUN_AL = (R % 4 == 0);
     constexpr bool CHIP_AL = (SPC % 4 == 0);
+    constexpr bool SHIFT_AL = RUN_AL && ((2 * SPC) % 4 == 0) && ((7 * SPC) % 4 == 0) && ((9 * SPC) % 4 == 0);
     constexpr int NWORDS = (T + 31) / 32;
     constexpr int WPT = (NWORDS + FE2_NT - 1) / FE2_NT;               // bitmap words per thread
     static_assert((FE2_NT * CPT) % AM_CHIPS_AVG == 0, "tile must be whole 48-chip blocks");
+    static_assert(FE2_HALO_THREADS <= FE2_NT, "halo chips are handled one per thread");
 
     HIP_DYNAMIC_SHARED(float, smem);
     float *X = smem;                                        // [LHP + T + RH] padded
-    float *HB = X + fe2_padn(LHP + T + RH);                 // halo bb staging: 58 chips
-    float *TOT = HB + FE2_HALO_THREADS * SPC;               // chip totals, left->right   [NCH]
+    float *TOT = X + fe2_padn(LHP + T + RH);                // chip totals, left->right   [NCH]
     float *RTOT = TOT + NCH;                                // chip totals, right->left   [NCH]
     float *PT = RTOT + NCH;
     float *ST = PT + NCH;
@@ -133,60 +164,77 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     const long long x0 = tile0 - LH;                        // absolute index of logical LDS index LHP-LH
 
     // ---- P1: IQ -> |.|^2 -> X ---------------------------------------------------------------
+    // All of a thread's loads are issued back to back before the first use (one HBM round trip
+    // per tile instead of one per load).  To keep them in one basic block the loads are
+    // unconditional from a clamped (always valid) address and out-of-stream lanes are zeroed
+    // afterwards: a branch around a load would force an s_waitcnt at its join.
     {
         constexpr int W = LH + T + RH;
+        constexpr int NPAIR = (W + 1) / 2;
+        constexpr int NP = (NPAIR + FE2_NT - 1) / FE2_NT;
         const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
+        const long long len = a.src_abs1 - a.src_abs0;
         const long long rel0 = x0 - a.src_abs0;
-        if ((rel0 & 1) == 0 && (reinterpret_cast<uintptr_t>(a.iq) & 15u) == 0) {
-            // two complex samples (16 bytes) per lane per load
+        const bool vec = (rel0 & 1) == 0 && (reinterpret_cast<uintptr_t>(a.iq) & 15u) == 0 && len >= 2;
+        if (a.ablate & 16u) {
+            for (int i = tid; i < fe2_padn(LHP + T + RH); i += FE2_NT) X[i] = 1.0f;
+        } else if (vec) {
             const float4 *iq4 = reinterpret_cast<const float4 *>(a.iq);
-            for (int p = tid; p < W / 2; p += FE2_NT) {
+            const long long npf = len >> 1;                      // whole 16-byte pairs in the stream
+            float4 v[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                long long pi = (rel0 >> 1) + (tid + k * FE2_NT);
+                pi = pi < 0 ? 0 : (pi >= npf ? npf - 1 : pi);
+                v[k] = iq4[pi];
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = tid + k * FE2_NT;
                 const long long n = x0 + 2 * p;
-                float m0 = 0.0f, m1 = 0.0f;
-                if (n >= a.src_abs0 && n + 1 < a.src_abs1) {
-                    const float4 v = iq4[(n - a.src_abs0) >> 1];
-                    const float r0 = v.x * v.x, i0 = v.y * v.y, r1 = v.z * v.z, i1 = v.w * v.w;
-                    m0 = r0 + i0;
-                    m1 = r1 + i1;
-                } else {
-                    if (n >= a.src_abs0 && n < a.src_abs1) {
-                        const float2 v = iq2[n - a.src_abs0];
-                        const float rr = v.x * v.x, ii = v.y * v.y;
+                if (p < NPAIR) {
+                    const bool ok = n >= a.src_abs0 && n + 1 < a.src_abs1;
+                    const float r0 = v[k].x * v[k].x, i0 = v[k].y * v[k].y;
+                    const float r1 = v[k].z * v[k].z, i1 = v[k].w * v[k].w;
+                    float m0 = ok ? (r0 + i0) : 0.0f;            // a1: fl(fl(I*I) + fl(Q*Q))
+                    const float m1 = ok ? (r1 + i1) : 0.0f;
+                    if (!ok && n == a.src_abs1 - 1 && n >= a.src_abs0) {   // odd stream length: last sample
+                        const float2 t = iq2[n - a.src_abs0];
+                        const float rr = t.x * t.x, ii = t.y * t.y;
                         m0 = rr + ii;
                     }
-                    if (n + 1 >= a.src_abs0 && n + 1 < a.src_abs1) {
-                        const float2 v = iq2[n + 1 - a.src_abs0];
-                        const float rr = v.x * v.x, ii = v.y * v.y;
-                        m1 = rr + ii;
-                    }
+                    const int li = LHP - LH + 2 * p;
+                    X[fe2_pidx(li)] = m0;
+                    if (2 * p + 1 < W) X[fe2_pidx(li + 1)] = m1;
                 }
-                const int li = LHP - LH + 2 * p;
-                X[fe2_pidx(li)] = m0;
-                X[fe2_pidx(li + 1)] = m1;
-            }
-            if ((W & 1) && tid == 0) {
-                const long long n = x0 + (W - 1);
-                float m = 0.0f;
-                if (n >= a.src_abs0 && n < a.src_abs1) {
-                    const float2 v = iq2[n - a.src_abs0];
-                    const float rr = v.x * v.x, ii = v.y * v.y;
-                    m = rr + ii;
-                }
-                X[fe2_pidx(LHP - LH + W - 1)] = m;
             }
         } else {
-            for (int i = tid; i < W; i += FE2_NT) {
-                const long long n = x0 + i;
-                float m = 0.0f;
-                if (n >= a.src_abs0 && n < a.src_abs1) {
-                    const float2 v = iq2[n - a.src_abs0];
-                    const float rr = v.x * v.x, ii = v.y * v.y;
-                    m = rr + ii;
+            float2 v0[NP], v1[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                long long i0 = rel0 + 2 * (tid + k * FE2_NT), i1 = i0 + 1;
+                i0 = i0 < 0 ? 0 : (i0 >= len ? len - 1 : i0);
+                i1 = i1 < 0 ? 0 : (i1 >= len ? len - 1 : i1);
+                v0[k].x = 0.0f; v0[k].y = 0.0f; v1[k] = v0[k];
+                if (len > 0) { v0[k] = iq2[i0]; v1[k] = iq2[i1]; }     // uniform condition
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                const int p = tid + k * FE2_NT;
+                const long long n = x0 + 2 * p;
+                if (p < NPAIR) {
+                    const bool ok0 = n >= a.src_abs0 && n < a.src_abs1;
+                    const bool ok1 = n + 1 >= a.src_abs0 && n + 1 < a.src_abs1;
+                    const float r0 = v0[k].x * v0[k].x, q0 = v0[k].y * v0[k].y;
+                    const float r1 = v1[k].x * v1[k].x, q1 = v1[k].y * v1[k].y;
+                    const int li = LHP - LH + 2 * p;
+                    X[fe2_pidx(li)] = ok0 ? (r0 + q0) : 0.0f;
+                    if (2 * p + 1 < W) X[fe2_pidx(li + 1)] = ok1 ? (r1 + q1) : 0.0f;
                 }
-                X[fe2_pidx(LHP - LH + i)] = m;
             }
         }
         for (int w = tid; w < NWORDS; w += FE2_NT) BM[w] = 0u;
+        if (tid == 0) PT[FE2_LH_CHIPS + FE2_NT * CPT] = 0.0f;  // first chip after the tile opens a block
     }
     __syncthreads();
 
@@ -196,7 +244,7 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     const int run_base = LHP + tid * R;                    // == chip_base(c0)
 
     float bbv[R];                                          // this thread's run of bb
-    // halo chip handled additionally by threads 0..57: 48 left-halo chips, 10 right-halo chips
+    // halo chip handled additionally by threads 0..64: 48 left-halo chips, 17 right-halo chips
     const int hq = (tid < AM_CHIPS_AVG) ? (1 + tid) : (FE2_LH_CHIPS + FE2_NT * CPT + (tid - AM_CHIPS_AVG));
     const bool has_halo = tid < FE2_HALO_THREADS;
     // absolute index of the last valid sample + 1, as a logical LDS index (bb beyond it reads 0)
@@ -206,7 +254,7 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     fe2_lds_load<R, RUN_AL>(X, run_base, bbv);             // |.|^2 of the run
     float hb[SPC] = {};
     if (has_halo) fe2_lds_load<SPC, false>(X, chip_base(hq), hb);
-    if (a.use_pmf && SPC > 1) {
+    if (a.use_pmf && SPC > 1 && !(a.ablate & 1u)) {
         float mp[SPC];
         fe2_lds_load<SPC, CHIP_AL && RUN_AL>(X, run_base - SPC, mp);
         float out[R];
@@ -263,13 +311,24 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     if (has_halo) fe2_lds_store<SPC, false>(X, chip_base(hq), hb);
 
     // ---- P4: exclusive prefix / suffix of chip totals inside each 48-chip block ----------------
+    // (the 48 totals are fetched in one batch; the additions keep the canonical sequential order)
+    if (!(a.ablate & 2u))
     for (int idx = tid; idx < 2 * NBLK; idx += FE2_NT) {
         const int qb = 1 + AM_CHIPS_AVG * (idx >> 1);
+        float t[AM_CHIPS_AVG];
+#pragma unroll
+        for (int j = 0; j < AM_CHIPS_AVG; ++j) t[j] = TOT[qb + j];
         float acc = 0.0f;
         if (idx & 1) {
-            for (int j = AM_CHIPS_AVG - 1; j >= 0; --j) { ST[qb + j] = acc; acc = acc + TOT[qb + j]; }
+#pragma unroll
+            for (int j = AM_CHIPS_AVG - 1; j >= 0; --j) { const float v = t[j]; t[j] = acc; acc = acc + v; }
+#pragma unroll
+            for (int j = 0; j < AM_CHIPS_AVG; ++j) ST[qb + j] = t[j];
         } else {
-            for (int j = 0; j < AM_CHIPS_AVG; ++j) { PT[qb + j] = acc; acc = acc + TOT[qb + j]; }
+#pragma unroll
+            for (int j = 0; j < AM_CHIPS_AVG; ++j) { const float v = t[j]; t[j] = acc; acc = acc + v; }
+#pragma unroll
+            for (int j = 0; j < AM_CHIPS_AVG; ++j) PT[qb + j] = t[j];
         }
     }
     __syncthreads();
@@ -277,6 +336,10 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     // ---- P5: reference level (a4) + first-stage preamble test (a6) ------------------------------
     float avgv[R];
     const uint32_t jt0 = (uint32_t)(tile0 - a.out_abs0);   // array coordinate of the tile start
+    if (a.ablate & 2u) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) avgv[i] = bbv[i];
+    } else
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int q = c0 + k;
@@ -304,29 +367,59 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
             avgv[k * SPC + i] = s * a.sL;
         }
     }
+    if (a.avg && !(a.ablate & 8u)) {
+        // block-level API only (am_frontend_work): dense reference level, one 4*R-byte run per lane
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const float x = bbv[i];
-        const float thr = avgv[i] * a.thr_lin;                           // preamble_impl.cc:173
-        if (x > thr) {                                                   // :174
+        for (int i = 0; i < R; ++i) {
+            const long long o = (long long)jt0 + tid * R + i;
+            if (o < a.out_n) a.avg[o] = avgv[i];
+        }
+    }
+    // a6, branch-free: the pulses 2, 7 and 9 chips ahead are the same run shifted, fetched with
+    // wide LDS loads; the result is one bit per sample
+    uint32_t cmask[(R + 31) / 32] = {};
+    if (!(a.ablate & 64u)) {
+        bool c[R];
+        const float nxt = X[fe2_pidx(run_base + R)];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const float x = bbv[i];
+            const float thr = avgv[i] * a.thr_lin;                       // preamble_impl.cc:173
+            const float nx = (i + 1 < R) ? bbv[(i + 1 < R) ? i + 1 : i] : nxt;
             const uint32_t j = jt0 + (uint32_t)(tid * R + i);
-            if (j >= a.j0 && j < a.j1) {
-                const int li = run_base + i;
-                const float nx = (i + 1 < R) ? bbv[(i + 1 < R) ? i + 1 : i] : X[fe2_pidx(li + 1)];
-                if (!(nx > x) &&                                         // :175
-                    !(X[fe2_pidx(li + 2 * SPC)] < thr) && !(X[fe2_pidx(li + 7 * SPC)] < thr) &&
-                    !(X[fe2_pidx(li + 9 * SPC)] < thr))                  // :177-179
-                    atomicOr(&BM[(tid * R + i) >> 5], 1u << ((tid * R + i) & 31));
+            c[i] = (x > thr) && !(nx > x) && j >= a.j0 && j < a.j1;     // :174, :175
+            avgv[i] = thr;                                               // only the threshold is needed below
+        }
+        constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float t[R];
+            fe2_lds_load<R, SHIFT_AL>(X, run_base + offs[o], t);
+#pragma unroll
+            for (int i = 0; i < R; ++i) c[i] = c[i] && !(t[i] < avgv[i]);   // :177-179
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) if (c[i]) cmask[i >> 5] |= 1u << (i & 31);
+        if constexpr (R == 32) {
+            BM[tid] = cmask[0];
+        } else {
+#pragma unroll
+            for (int w = 0; w < (R + 31) / 32; ++w) {
+                if (cmask[w]) {
+                    const int bit0 = tid * R + 32 * w;          // first sample this word describes
+                    const unsigned long long wide = (unsigned long long)cmask[w] << (bit0 & 31);
+                    atomicOr(&BM[bit0 >> 5], (uint32_t)wide);
+                    if ((uint32_t)(wide >> 32)) atomicOr(&BM[(bit0 >> 5) + 1], (uint32_t)(wide >> 32));
+                }
             }
         }
     }
     __syncthreads();
 
-    // ---- P6a: bb out (coalesced), ordered candidate list ------------------------------------------
-    for (int i = tid; i < T; i += FE2_NT) {
-        const long long o = (long long)jt0 + i;
-        if (o < a.out_n) a.bb[o] = X[fe2_pidx(LHP + i)];
-    }
+    // ---- P6: bb out (coalesced), ordered candidate list ---------------------------------------------
+    if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
+    uint32_t total = 0;
+    uint32_t *seg = a.seg_pos + (size_t)tile * T;
     {
         uint32_t words[WPT];
         uint32_t cnt = 0;
@@ -345,12 +438,11 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
         }
         if (lane == AM_WAVE - 1) WS[wv] = incl;
         __syncthreads();
-        uint32_t off = incl - cnt, total = 0;
+        uint32_t off = incl - cnt;
         for (int k = 0; k < FE2_NT / AM_WAVE; ++k) {
             if (k < wv) off += WS[k];
             total += WS[k];
         }
-        uint32_t *seg = a.cand_seg + (size_t)tile * T;
 #pragma unroll
         for (int k = 0; k < WPT; ++k) {
             uint32_t wbits = words[k];
@@ -363,14 +455,93 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
         }
         if (tid == 0) a.blk_cnt[tile] = total;
     }
-    __syncthreads();                                       // X (bb) has been written out
+    if (total == 0) return;                                // uniform: nothing to refine
+    __syncthreads();                                       // seg[] written by other waves is visible
 
-    // ---- P6b: avg out, staged through X for coalesced stores ---------------------------------------
-    fe2_lds_store<R, RUN_AL>(X, run_base, avgv);
-    __syncthreads();
-    for (int i = tid; i < T; i += FE2_NT) {
-        const long long o = (long long)jt0 + i;
-        if (o < a.out_n) a.avg[o] = X[fe2_pidx(LHP + i)];
+    // ---- P7: refinement of this tile's candidates from LDS (a7, a8) -----------------------------------
+    for (uint32_t ci = tid; ci < total; ci += FE2_NT) {
+        const uint32_t j = seg[ci];
+        const int li = LHP + (int)(j - jt0);
+        // late-peak search (preamble_impl.cc:184-192); the "now" energy of a pass is the "late"
+        // energy of the previous one (same samples, same order), so it is carried over
+        auto energy = [&](int at) {
+            double e = 0.0;
+            constexpr int chips[4] = {0, 2, 7, 9};
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                float t[SPC];
+                fe2_lds_load<SPC, false>(X, at + chips[cc] * SPC, t);
+#pragma unroll
+                for (int i = 0; i < SPC; ++i) e += (double)t[i];
+            }
+            return e;
+        };
+        int how_late = 0;
+        double e_now = energy(li);
+        for (;;) {
+            const double e_next = energy(li + how_late + 1);
+            const bool late = e_next > e_now;
+            if (late) { how_late++; e_now = e_next; }
+            if (!(late && how_late < SPC)) break;
+        }
+        const int le = li + how_late;
+        // reference level at the shifted start: avg[e] in the canonical two-level order
+        float av;
+        {
+            const int rel = le - (LHP - LH);
+            const int q = rel / SPC, io = rel - q * SPC;           // chip and offset inside it
+            const int jb = (q - 1) % AM_CHIPS_AVG;
+            float t[SPC];
+            fe2_lds_load<SPC, false>(X, chip_base(q), t);
+            float pc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < SPC; ++i) pc = (i <= io) ? (pc + t[i]) : pc;
+            const float PRE = PT[q] + pc;
+            float ssum;
+            if (io == SPC - 1) {
+                ssum = (jb == AM_CHIPS_AVG - 1) ? PRE : ((RTOT[q - AM_CHIPS_AVG + 1] + ST[q - AM_CHIPS_AVG + 1]) + PRE);
+            } else {
+                float u[SPC];
+                fe2_lds_load<SPC, false>(X, chip_base(q - AM_CHIPS_AVG), u);
+                float sc = 0.0f;
+#pragma unroll
+                for (int i = SPC - 1; i >= 0; --i) sc = (i > io) ? (sc + u[i]) : sc;
+                ssum = (sc + ST[q - AM_CHIPS_AVG]) + PRE;
+            }
+            av = ssum * a.sL;
+            if ((long long)le >= end_li) av = 0.0f;                // beyond the end of the stream
+        }
+        // quiet zones (preamble_impl.cc:198-209)
+        const float p0 = X[fe2_pidx(le)], p1 = X[fe2_pidx(le + 2 * SPC)];
+        const float p2 = X[fe2_pidx(le + 7 * SPC)], p3 = X[fe2_pidx(le + 9 * SPC)];
+        float ps = p0 + p1;
+        ps = ps + p2;
+        ps = ps + p3;
+        const float avgpeak = (float)((double)ps / 4.0);
+        const float sthr = av + (avgpeak - av) / a.thr_lin;
+        bool bad = false;
+        {
+            constexpr int N1 = 3 * SPC + 1, N2 = 5 * SPC + 1;      // offsets 3spc..6spc, 10spc..15spc
+            constexpr int CH = 16;
+            for (int o = 0; o < N1 && !bad; o += CH) {
+                float t[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) t[k] = X[fe2_pidx(le + 3 * SPC + ((o + k < N1) ? o + k : N1 - 1))];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) bad = bad || (t[k] > sthr);
+            }
+            for (int o = 0; o < N2 && !bad; o += CH) {
+                float t[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) t[k] = X[fe2_pidx(le + 10 * SPC + ((o + k < N2) ? o + k : N2 - 1))];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) bad = bad || (t[k] > sthr);
+            }
+        }
+        const size_t so = (size_t)tile * T + ci;
+        a.seg_e[so] = j + (uint32_t)how_late;
+        a.seg_inavg[so] = av;
+        a.seg_valid[so] = bad ? 0 : 1;
     }
 }
 
@@ -381,8 +552,7 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     constexpr int RH = FE2_RH_CHIPS * SPC;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;
     constexpr int NWORDS = (T + 31) / 32;
-    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)FE2_HALO_THREADS * SPC + (size_t)4 * NCH +
-                        NWORDS + 16) * sizeof(float);
+    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16) * sizeof(float);
     am_fe2_args a = a_in;
     a.ntiles = (unsigned)((a.out_n + T - 1) / T);
     *ntiles = a.ntiles;
@@ -415,13 +585,18 @@ unsigned am_fe2_tile(int spc)
 
 hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
-                         float sL, float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, unsigned *ntiles,
-                         unsigned *tile_len, hipStream_t s)
+                         float sL, float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg,
+                         uint8_t *seg_valid, uint32_t *blk_cnt, unsigned *ntiles, unsigned *tile_len, hipStream_t s)
 {
     am_fe2_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
-    a.bb = bb; a.avg = avg; a.j0 = j0; a.j1 = j1; a.cand_seg = cand_seg; a.blk_cnt = blk_cnt; a.ntiles = 0;
+    a.bb = bb; a.avg = avg; a.j0 = j0; a.j1 = j1; a.seg_pos = seg_pos; a.seg_e = seg_e; a.seg_inavg = seg_inavg;
+    a.seg_valid = seg_valid; a.blk_cnt = blk_cnt; a.ntiles = 0;
     a.use_pmf = use_pmf; a.s1 = s1; a.sL = sL; a.thr_lin = thr_lin;
+    {
+        const char *ab = getenv("AIRMODES_FE2_ABLATE");
+        a.ablate = ab ? (unsigned)atoi(ab) : 0u;
+    }
     switch (spc) {
     // (SPC, chips per thread): run = SPC*CPT samples per thread, chosen so that the per-chip
     // side arrays and the sample array together stay <= 80 KB of LDS (two workgroups per CU)

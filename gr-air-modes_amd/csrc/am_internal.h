@@ -39,8 +39,13 @@ hipError_t am_launch_frontend(const am_fe_args &a, hipStream_t s);
 unsigned am_fe2_tile(int spc);
 hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
-                         float sL, float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, unsigned *ntiles,
-                         unsigned *tile_len, hipStream_t s);
+                         float sL, float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg,
+                         uint8_t *seg_valid, uint32_t *blk_cnt, unsigned *ntiles, unsigned *tile_len, hipStream_t s);
+/* segmented records of the fused kernel -> flat, position-ordered arrays */
+hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, const float *seg_inavg,
+                             const uint8_t *seg_valid, uint32_t seg_stride, const uint32_t *blk_off,
+                             uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *e, uint32_t *tgt,
+                             float *inavg, uint8_t *valid, hipStream_t s);
 
 /* ---- preamble detection / refinement / greedy chain ----------------------------------- */
 #define AM_DET_THREADS 256
@@ -74,7 +79,7 @@ hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hi
 hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
                             const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
-                            uint8_t *valid, hipStream_t s);
+                            float *inavg, uint8_t *valid, hipStream_t s);
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
                                 uint32_t *jump0, uint8_t *visited, hipStream_t s);
 hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, hipStream_t s);
@@ -88,13 +93,14 @@ hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32
                                   uint32_t *out_idx, hipStream_t s);
 /* records from an exchanged candidate list (time-sharded mode) */
 hipError_t am_launch_cand_import(const am_cand *recs, uint32_t M, uint64_t base_abs, int spc,
-                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, uint8_t *valid,
+                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
                                  hipStream_t s);
-hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const uint8_t *valid,
-                                 uint32_t M, uint64_t base_abs, am_cand *recs, hipStream_t s);
+hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const float *inavg,
+                                 const uint8_t *valid, uint32_t M, uint64_t base_abs, am_cand *recs,
+                                 hipStream_t s);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
-hipError_t am_launch_extract(const float *bb, const float *avg, int spc, const uint32_t *emit_idx,
+hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
                              uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
                              uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
                              am_tag *tags, hipStream_t s);

@@ -281,14 +281,54 @@ hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hi
 // Refinement (a7, a8): per candidate, the 4-pulse energy (double precision, chip-major order
 // as in the reference) at the late shifts it actually visits, then the quiet-zone scan.
 // ------------------------------------------------------------------------------------------
+// 16 loads are put in flight before they are consumed; the additions keep the reference's
+// strict left-to-right double-precision order (preamble_impl.cc:91-98).
+__device__ __forceinline__ double am_energy_chip(const float *__restrict__ p, int spc, double e)
+{
+    int i = 0;
+    for (; i + 16 <= spc; i += 16) {
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = p[i + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) e += (double)t[k];
+    }
+    for (; i + 4 <= spc; i += 4) {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = p[i + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e += (double)t[k];
+    }
+    for (; i < spc; ++i) e += (double)p[i];
+    return e;
+}
+
 __device__ __forceinline__ double am_preamble_energy(const float *__restrict__ p, int spc)
 {
     double e = 0.0;
-    for (int i = 0; i < spc; ++i) e += (double)p[i];
-    for (int i = 0; i < spc; ++i) e += (double)p[2 * spc + i];
-    for (int i = 0; i < spc; ++i) e += (double)p[7 * spc + i];
-    for (int i = 0; i < spc; ++i) e += (double)p[9 * spc + i];
+    e = am_energy_chip(p, spc, e);
+    e = am_energy_chip(p + 2 * spc, spc, e);
+    e = am_energy_chip(p + 7 * spc, spc, e);
+    e = am_energy_chip(p + 9 * spc, spc, e);
     return e;
+}
+
+// any(z[0..n) > thr), 16 loads in flight per step
+__device__ __forceinline__ bool am_any_above(const float *__restrict__ z, int n, float thr)
+{
+    int o = 0;
+    for (; o + 16 <= n; o += 16) {
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = z[o + k];
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hit = hit || (t[k] > thr);
+        if (hit) return true;
+    }
+    for (; o < n; ++o) if (z[o] > thr) return true;
+    return false;
 }
 
 __global__ void __launch_bounds__(256)
@@ -296,7 +336,7 @@ am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc
             const uint32_t *__restrict__ cand_seg, uint32_t seg_stride,
             const uint32_t *__restrict__ blk_off, uint32_t nblk, uint32_t M,
             uint32_t *__restrict__ pos, uint32_t *__restrict__ eo,
-            uint32_t *__restrict__ tgt, uint8_t *__restrict__ valid)
+            uint32_t *__restrict__ tgt, float *__restrict__ inavg, uint8_t *__restrict__ valid)
 {
     // One lane per candidate.  The reference recomputes both energies on every pass of its
     // do-while (preamble_impl.cc:184-192); the "now" energy of pass k+1 is the "late" energy of
@@ -327,25 +367,59 @@ am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc
     ps = ps + p3;
     const float avgpeak = (float)((double)ps / 4.0);
     const float sthr = av + (avgpeak - av) / thr_lin;
-    bool ok = true;
-    const float *z1 = bb + e + 3 * spc;              // offsets 3spc .. 6spc
-    for (int o = 0; o <= 3 * spc && ok; ++o) if (z1[o] > sthr) ok = false;
-    const float *z2 = bb + e + 10 * spc;             // offsets 10spc .. 15spc
-    for (int o = 0; o <= 5 * spc && ok; ++o) if (z2[o] > sthr) ok = false;
+    const bool ok = !am_any_above(bb + e + 3 * spc, 3 * spc + 1, sthr) &&      // offsets 3spc .. 6spc
+                    !am_any_above(bb + e + 10 * spc, 5 * spc + 1, sthr);       // offsets 10spc .. 15spc
     pos[g] = j;
     eo[g] = e;
+    inavg[g] = av;
     valid[g] = ok ? 1 : 0;
     tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+}
+
+// Fused path: the records already exist per tile segment; gather them into flat arrays.
+__global__ void __launch_bounds__(256)
+am_k_flatten(const uint32_t *__restrict__ seg_pos, const uint32_t *__restrict__ seg_e,
+             const float *__restrict__ seg_inavg, const uint8_t *__restrict__ seg_valid, uint32_t seg_stride,
+             const uint32_t *__restrict__ blk_off, uint32_t nseg, uint32_t M, int spc,
+             uint32_t *__restrict__ pos, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
+             float *__restrict__ inavg, uint8_t *__restrict__ valid)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blk_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    const size_t so = (size_t)lo * seg_stride + (g - blk_off[lo]);
+    const uint32_t e = seg_e[so];
+    const bool ok = seg_valid[so] != 0;
+    pos[g] = seg_pos[so];
+    eo[g] = e;
+    inavg[g] = seg_inavg[so];
+    valid[g] = ok ? 1 : 0;
+    tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);
+}
+
+hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, const float *seg_inavg,
+                             const uint8_t *seg_valid, uint32_t seg_stride, const uint32_t *blk_off,
+                             uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *e, uint32_t *tgt,
+                             float *inavg, uint8_t *valid, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_flatten, dim3((M + 255) / 256), dim3(256), 0, s, seg_pos, seg_e, seg_inavg, seg_valid,
+                       seg_stride, blk_off, nseg, M, spc, pos, e, tgt, inavg, valid);
+    return hipGetLastError();
 }
 
 hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
                             const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
-                            uint8_t *valid, hipStream_t s)
+                            float *inavg, uint8_t *valid, hipStream_t s)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_refine, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg, spc, thr_lin, cand_seg,
-                       seg_stride, blk_off, nblk, M, pos, e, tgt, valid);
+                       seg_stride, blk_off, nblk, M, pos, e, tgt, inavg, valid);
     return hipGetLastError();
 }
 
@@ -415,13 +489,21 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
         const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
         emit[g] = em ? 1 : 0;
     }
-    // where the scan resumes after everything visited here: the largest target (one atomic per wave)
+    // where the scan resumes after everything visited here: the largest target.  Same-address
+    // atomics serialise (~11 ns each), so reduce per workgroup first: one atomic per 256 nodes.
+    __shared__ uint32_t wmax[256 / AM_WAVE];
     uint32_t t = vis ? tgt[g] : 0u;
     for (int o = 32; o >= 1; o >>= 1) {
         const uint32_t other = (uint32_t)__shfl_xor((int)t, o, AM_WAVE);
         t = other > t ? other : t;
     }
-    if ((threadIdx.x & (AM_WAVE - 1)) == 0 && t) atomicMax(&scalars[0], t);
+    if ((threadIdx.x & (AM_WAVE - 1)) == 0) wmax[threadIdx.x / AM_WAVE] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = 0;
+        for (int k = 0; k < 256 / AM_WAVE; ++k) m = wmax[k] > m ? wmax[k] : m;
+        if (m) atomicMax(&scalars[0], m);
+    }
 }
 
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -528,48 +610,51 @@ hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32
 __global__ void __launch_bounds__(256)
 am_k_cand_import(const am_cand *__restrict__ recs, uint32_t M, uint64_t base_abs, int spc,
                  uint32_t *__restrict__ pos, uint32_t *__restrict__ e, uint32_t *__restrict__ tgt,
-                 uint8_t *__restrict__ valid)
+                 float *__restrict__ inavg, uint8_t *__restrict__ valid)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
     const am_cand r = recs[g];
     const uint32_t p = (uint32_t)(r.pos - base_abs);
-    const uint32_t ee = p + r.shift;
+    const uint32_t ee = p + (r.shift_valid & 0x7FFFFFFFu);
+    const bool ok = (r.shift_valid >> 31) != 0;
     pos[g] = p;
     e[g] = ee;
-    valid[g] = r.valid ? 1 : 0;
-    tgt[g] = r.valid ? (ee + (uint32_t)(AM_BURST * spc)) : (ee + 1u);
+    inavg[g] = r.inavg;
+    valid[g] = ok ? 1 : 0;
+    tgt[g] = ok ? (ee + (uint32_t)(AM_BURST * spc)) : (ee + 1u);
 }
 
 __global__ void __launch_bounds__(256)
 am_k_cand_export(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
-                 const uint8_t *__restrict__ valid, uint32_t M, uint64_t base_abs,
-                 am_cand *__restrict__ recs)
+                 const float *__restrict__ inavg, const uint8_t *__restrict__ valid, uint32_t M,
+                 uint64_t base_abs, am_cand *__restrict__ recs)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
     am_cand r;
     r.pos = base_abs + pos[g];
-    r.shift = e[g] - pos[g];
-    r.valid = valid[g];
+    r.shift_valid = (e[g] - pos[g]) | (valid[g] ? 0x80000000u : 0u);
+    r.inavg = inavg[g];
     recs[g] = r;
 }
 
 hipError_t am_launch_cand_import(const am_cand *recs, uint32_t M, uint64_t base_abs, int spc,
-                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, uint8_t *valid,
+                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
                                  hipStream_t s)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_cand_import, dim3(am_grid(M, 256)), dim3(256), 0, s, recs, M, base_abs, spc, pos, e,
-                       tgt, valid);
+                       tgt, inavg, valid);
     return hipGetLastError();
 }
-hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const uint8_t *valid,
-                                 uint32_t M, uint64_t base_abs, am_cand *recs, hipStream_t s)
+hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const float *inavg,
+                                 const uint8_t *valid, uint32_t M, uint64_t base_abs, am_cand *recs,
+                                 hipStream_t s)
 {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_cand_export, dim3(am_grid(M, 256)), dim3(256), 0, s, pos, e, valid, M, base_abs,
-                       recs);
+    hipLaunchKernelGGL(am_k_cand_export, dim3(am_grid(M, 256)), dim3(256), 0, s, pos, e, inavg, valid, M,
+                       base_abs, recs);
     return hipGetLastError();
 }
 
@@ -579,7 +664,7 @@ hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const u
 //   timestamp from the absolute item count     preamble_impl.cc:100-137 (file source: no rx_time)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int spc,
+am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
              const uint32_t *__restrict__ emit_idx, uint32_t n_emit, const uint32_t *__restrict__ pos,
              const uint32_t *__restrict__ eo, uint64_t base_abs, long long e_off, uint64_t rate,
              float *__restrict__ bursts, am_tag *__restrict__ tags)
@@ -590,7 +675,7 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int sp
     const uint32_t g = emit_idx[i];
     const uint32_t e = eo[g];
     const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
-    const float av = avg[ei];
+    const float av = inavg[g];                              // reference level at the shifted start
     for (int c = lane; c < AM_BURST; c += AM_WAVE)
         bursts[(size_t)i * AM_BURST + c] = bb[ei + (size_t)(c * spc)] - av;
     if (lane == 0) {
@@ -606,13 +691,13 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ avg, int sp
     }
 }
 
-hipError_t am_launch_extract(const float *bb, const float *avg, int spc, const uint32_t *emit_idx,
+hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
                              uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
                              uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
                              am_tag *tags, hipStream_t s)
 {
     if (n_emit == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_emit, 4)), dim3(256), 0, s, bb, avg, spc, emit_idx, n_emit,
+    hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_emit, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_emit,
                        pos, e, base_abs, e_off, rate, bursts, tags);
     return hipGetLastError();
 }

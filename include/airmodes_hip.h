@@ -160,8 +160,9 @@ int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
  * am_shard_resolve: all_recs = the G chunks' records concatenated in chunk order. */
 typedef struct am_cand {
     uint64_t pos;          /* absolute stream index where the first-stage test fired       */
-    uint32_t shift;        /* late shifts: the preamble starts at pos + shift              */
-    uint32_t valid;        /* 1 = passed the quiet-zone validation                         */
+    uint32_t shift_valid;  /* bits 0..30: late shifts (preamble starts at pos + shift);
+                              bit 31: passed the quiet-zone validation                     */
+    float    inavg;        /* reference level at the shifted start                         */
 } am_cand;
 
 int am_shard_halo(const am_ctx *ctx, uint64_t *left, uint64_t *right);
