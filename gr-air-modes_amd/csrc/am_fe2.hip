@@ -455,36 +455,106 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
         }
         if (tid == 0) a.blk_cnt[tile] = total;
     }
-    if (total == 0) return;                                // uniform: nothing to refine
+    if (total == 0 || (a.ablate & 128u)) return;          // uniform: nothing to refine
     __syncthreads();                                       // seg[] written by other waves is visible
 
     // ---- P7: refinement of this tile's candidates from LDS (a7, a8) -----------------------------------
+    // The reference slides a candidate right while the 4-pulse energy still grows
+    // (preamble_impl.cc:184-192): late(q) := E(q+1) > E(q).  A lane-per-candidate loop would make
+    // every wave run as long as its slowest lane (a few candidates slide the full spc steps), and
+    // neighbouring candidates would recompute the same energies.  Instead:
+    //   P7a  late(q) is evaluated ONCE for every position q that some candidate can reach
+    //        (q in [p, p+spc-1]), one lane per position, all lanes busy -> bitmap LB
+    //   P7b  per candidate: shifts = number of consecutive late bits from p (capped at spc), then
+    //        the reference level at the shifted start and the quiet-zone test.
+    uint32_t *NL = WS + 16;                                // positions that need a late() flag
+    uint32_t *NLP = NL + (NWORDS + 1);                     // exclusive prefix of popcounts
+    uint32_t *LB = NLP + (NWORDS + 2);                     // late flags
+    auto energy = [&](int at) {
+        double e = 0.0;
+        constexpr int chips[4] = {0, 2, 7, 9};
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            float t[SPC];
+            fe2_lds_load<SPC, false>(X, at + chips[cc] * SPC, t);
+#pragma unroll
+            for (int i = 0; i < SPC; ++i) e += (double)t[i];
+        }
+        return e;
+    };
+    {
+        // needed positions = candidate bitmap dilated by spc-1 towards higher positions
+        uint32_t cnt = 0;
+        uint32_t nlw[WPT + 1];
+        constexpr int WPT2 = (NWORDS + 1 + FE2_NT - 1) / FE2_NT;
+        static_assert(WPT2 <= WPT + 1, "word ownership");
+#pragma unroll
+        for (int k = 0; k < WPT2; ++k) {
+            const int w = tid * WPT2 + k;
+            uint32_t d32 = 0;
+            if (w <= NWORDS) {
+                const unsigned long long hi = (w < NWORDS) ? BM[w] : 0u;
+                const unsigned long long lo = (w > 0) ? BM[w - 1] : 0u;
+                unsigned long long v = (hi << 32) | lo;
+                // OR of shifts 0 .. SPC-1
+                int covered = 1;
+#pragma unroll
+                for (int step = 1; step * 2 <= SPC; step *= 2) { v |= v << step; covered = step * 2; }
+                if (covered < SPC) v |= v << (SPC - covered);
+                d32 = (uint32_t)(v >> 32);
+                NL[w] = d32;
+                LB[w] = 0u;
+            }
+            nlw[k] = d32;
+            cnt += (uint32_t)__popcll((unsigned long long)d32);
+        }
+        const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
+        uint32_t incl = cnt;
+        for (int d = 1; d < AM_WAVE; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
+            if (lane >= d) incl += up;
+        }
+        __syncthreads();                                   // WS reuse: everyone has read the candidate totals
+        if (lane == AM_WAVE - 1) WS[wv] = incl;
+        __syncthreads();
+        uint32_t off = incl - cnt;
+        for (int k = 0; k < wv; ++k) off += WS[k];
+#pragma unroll
+        for (int k = 0; k < WPT2; ++k) {
+            const int w = tid * WPT2 + k;
+            if (w <= NWORDS) NLP[w] = off;
+            off += (uint32_t)__popcll((unsigned long long)nlw[k]);
+        }
+        if (tid == FE2_NT - 1) NLP[NWORDS + 1] = off;      // total number of needed positions
+    }
+    __syncthreads();
+    {
+        const uint32_t nneed = NLP[NWORDS + 1];
+        for (uint32_t k = tid; k < nneed; k += FE2_NT) {
+            // compact index k -> word (last w with NLP[w] <= k) -> bit (the (k - NLP[w])-th set bit)
+            int lo = 0, hi = NWORDS + 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (NLP[mid] <= k) lo = mid; else hi = mid;
+            }
+            uint32_t wbits = NL[lo];
+            for (uint32_t r = k - NLP[lo]; r > 0; --r) wbits &= wbits - 1u;
+            const int q = lo * 32 + (__ffsll((long long)wbits) - 1);   // local position
+            const double e0 = energy(LHP + q);
+            const double e1 = energy(LHP + q + 1);
+            if (e1 > e0) atomicOr(&LB[q >> 5], 1u << (q & 31));
+        }
+    }
+    __syncthreads();
+
     for (uint32_t ci = tid; ci < total; ci += FE2_NT) {
         const uint32_t j = seg[ci];
-        const int li = LHP + (int)(j - jt0);
-        // late-peak search (preamble_impl.cc:184-192); the "now" energy of a pass is the "late"
-        // energy of the previous one (same samples, same order), so it is carried over
-        auto energy = [&](int at) {
-            double e = 0.0;
-            constexpr int chips[4] = {0, 2, 7, 9};
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                float t[SPC];
-                fe2_lds_load<SPC, false>(X, at + chips[cc] * SPC, t);
-#pragma unroll
-                for (int i = 0; i < SPC; ++i) e += (double)t[i];
-            }
-            return e;
-        };
-        int how_late = 0;
-        double e_now = energy(li);
-        for (;;) {
-            const double e_next = energy(li + how_late + 1);
-            const bool late = e_next > e_now;
-            if (late) { how_late++; e_now = e_next; }
-            if (!(late && how_late < SPC)) break;
-        }
-        const int le = li + how_late;
+        const int pl = (int)(j - jt0);                     // local position of the candidate
+        const int w0 = pl >> 5;
+        const unsigned long long win = (((unsigned long long)LB[w0 + 1] << 32) | LB[w0]) >> (pl & 31);
+        int how_late = __ffsll((long long)~win) - 1;       // consecutive late flags from the candidate
+        if (how_late > SPC) how_late = SPC;
+        const int le = LHP + pl + how_late;
         // reference level at the shifted start: avg[e] in the canonical two-level order
         float av;
         {
@@ -552,7 +622,8 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     constexpr int RH = FE2_RH_CHIPS * SPC;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;
     constexpr int NWORDS = (T + 31) / 32;
-    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16) * sizeof(float);
+    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + 3 * (NWORDS + 2)) *
+                       sizeof(float);
     am_fe2_args a = a_in;
     a.ntiles = (unsigned)((a.out_n + T - 1) / T);
     *ntiles = a.ntiles;
