@@ -75,56 +75,13 @@ def main():
             return ctx.process_iq_device(d_iq.data_ptr(), n, flush=True)
     else:
         # time-sharded: rank r owns samples [r*n, (r+1)*n) of one stream of world*n samples
-        total = world * n
-        hl, hr = ctx.shard_halo()
+        from air_modes.sharded import ShardedReceiver
         own = torch.from_numpy(iq.view(np.float32)).to(dev)
-        buf = torch.zeros((hl + n + hr) * 2, dtype=torch.float32, device=dev)
-        buf[hl * 2:(hl + n) * 2] = own
-        slab = torch.empty((hl + hr) * 2, dtype=torch.float32, device=dev)
-        slabs = [torch.empty_like(slab) for _ in range(world)]
-        a0, a1 = rank * n, (rank + 1) * n
-        lo = max(0, a0 - hl)
-        cap = max(4096, n // 8)
-        d_recs = torch.zeros(cap * 2, dtype=torch.int64, device=dev)         # am_cand = 16 bytes
-        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-        cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        import ctypes as C
+        rx = ShardedReceiver(ctx, rank, world, n)
+        torch.cuda.synchronize()
 
         def step():
-            # 1. halo exchange over xGMI: everyone publishes [its tail hl | its head hr]
-            slab[:hl * 2] = own[(n - hl) * 2:]
-            slab[hl * 2:] = own[:hr * 2]
-            dist.all_gather(slabs, slab)
-            if rank > 0:
-                buf[:hl * 2] = slabs[rank - 1][:hl * 2]
-            if rank < world - 1:
-                buf[(hl + n) * 2:] = slabs[rank + 1][hl * 2:]
-            torch.cuda.synchronize()
-            # 2. local scan -> candidate records (left on the device)
-            got = C.c_uint64(0)
-            off = (hl - (a0 - lo)) * 2
-            hi = min(total, a1 + hr)
-            rc = ctx.lib.L.am_shard_scan(ctx._h, buf.data_ptr() + off * 4, a0, a1, total,
-                                         _capi.AM_F_DEVICE_IN | _capi.AM_F_DEVICE_OUT, d_recs.data_ptr(), cap,
-                                         C.byref(got))
-            ctx._chk(rc)
-            m = int(got.value)
-            # 3. all-gather of the sparse candidate lists (counts, then padded records)
-            cnt[0] = m
-            dist.all_gather(cnts, cnt)
-            ms = [int(c.item()) for c in cnts]
-            mmax = max(max(ms), 1)
-            parts = [torch.empty(mmax * 2, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(parts, d_recs[:mmax * 2].contiguous())
-            allr = torch.cat([parts[r][:ms[r] * 2] for r in range(world)]).contiguous()
-            torch.cuda.synchronize()
-            # 4. identical greedy-chain resolve everywhere; each rank slices its own hits
-            out = np.zeros(max(64, n // 2000 + 64), _capi.PACKET_DTYPE)
-            g2 = C.c_uint64(0)
-            rc = ctx.lib.L.am_shard_resolve(ctx._h, allr.data_ptr(), sum(ms), _capi.AM_F_DEVICE_IN,
-                                            out.ctypes.data, out.size, C.byref(g2))
-            ctx._chk(rc)
-            return out[:g2.value]
+            return rx.step(own)
 
     pk = None
     for _ in range(args.warmup):

@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     const unsigned per = (nb + 7u) / 8u;
     const unsigned tile = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
     if (tile >= nb) return;                                 // whole workgroup (uniform)
+    if (a.ablate & 1024u) { if (tid == 0) a.blk_cnt[tile] = 0; return; }
     const long long tile0 = a.out_abs0 + (long long)tile * T;
     const long long x0 = tile0 - LH;                        // absolute index of logical LDS index LHP-LH
 
@@ -540,13 +541,14 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
             uint32_t wbits = NL[lo];
             for (uint32_t r = k - NLP[lo]; r > 0; --r) wbits &= wbits - 1u;
             const int q = lo * 32 + (__ffsll((long long)wbits) - 1);   // local position
-            const double e0 = energy(LHP + q);
-            const double e1 = energy(LHP + q + 1);
+            double e0 = 0.0, e1 = 0.0;
+            if (!(a.ablate & 512u)) { e0 = energy(LHP + q); e1 = energy(LHP + q + 1); }
             if (e1 > e0) atomicOr(&LB[q >> 5], 1u << (q & 31));
         }
     }
     __syncthreads();
 
+    if (a.ablate & 256u) return;
     for (uint32_t ci = tid; ci < total; ci += FE2_NT) {
         const uint32_t j = seg[ci];
         const int pl = (int)(j - jt0);                     // local position of the candidate
@@ -625,15 +627,17 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + 3 * (NWORDS + 2)) *
                        sizeof(float);
     am_fe2_args a = a_in;
+    size_t lds_req = lds;
+    if (const char *x = getenv("AIRMODES_FE2_LDS_EXTRA")) lds_req += (size_t)atoi(x);   // occupancy experiments
     a.ntiles = (unsigned)((a.out_n + T - 1) / T);
     *ntiles = a.ntiles;
     *tile_len = T;
     if (a.ntiles == 0) return hipSuccess;
     hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe2<SPC, CPT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
     if (rc != hipSuccess) return rc;
     const unsigned grid = ((a.ntiles + 7u) / 8u) * 8u;     // whole XCD rounds (extra groups exit)
-    hipLaunchKernelGGL((am_k_fe2<SPC, CPT>), dim3(grid), dim3(FE2_NT), lds, s, a);
+    hipLaunchKernelGGL((am_k_fe2<SPC, CPT>), dim3(grid), dim3(FE2_NT), lds_req, s, a);
     return hipGetLastError();
 }
 
