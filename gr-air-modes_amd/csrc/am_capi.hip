@@ -38,6 +38,7 @@ struct am_ctx {
     int use_pmf = 0;
     int tile = 0;
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
+    bool no_span = false;         // AIRMODES_NO_SPAN=1: tiled fused kernel instead of the per-wave span kernel
     char err[256] = "";
 
     // stream state (absolute sample indices)
@@ -229,6 +230,25 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     *M_out = 0;
     const unsigned T2 = c->force_generic ? 0u : am_fe2_tile(c->spc);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    unsigned span_segs = 0;
+    const size_t span_slots = (c->force_generic || c->no_span || avg) ? 0 : am_span_slots(c->spc, (long long)out_n, &span_segs);
+    if (span_slots) {
+        // barrier-free per-wave spans (16..64 Msps)
+        ENSURE(c, c->cand_seg, span_slots * sizeof(uint32_t));
+        ENSURE(c, c->seg_e, span_slots * sizeof(uint32_t));
+        ENSURE(c, c->seg_inavg, span_slots * sizeof(float));
+        ENSURE(c, c->seg_valid, span_slots);
+        ENSURE(c, c->blk_cnt, ((size_t)span_segs + 8) * sizeof(uint32_t));
+        ENSURE(c, c->blk_off, ((size_t)span_segs + 9) * sizeof(uint32_t));
+        unsigned ns = 0, st = 0;
+        HIPCHK(c, am_launch_span(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
+                                 (long long)out_n, bb, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
+                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
+                                 (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p,
+                                 (uint32_t *)c->blk_cnt.p, &ns, &st, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        return run_refine(c, bb, avg, ns, st, true, M_out);
+    }
     if (T2 == 0) {
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
@@ -406,6 +426,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
+            const char *ns = getenv("AIRMODES_NO_SPAN");
+            c->no_span = ns && ns[0] == '1';
         }
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);

@@ -47,6 +47,14 @@ hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, con
                              uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *e, uint32_t *tgt,
                              float *inavg, uint8_t *valid, hipStream_t s);
 
+/* barrier-free per-wave span kernel (am_span.hip): spc in {8,10,16,20,32}.
+ * am_span_slots: candidate slots needed for out_n outputs (0 = no specialisation for this spc). */
+size_t am_span_slots(int spc, long long out_n, unsigned *nseg_max);
+hipError_t am_launch_span(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
+                          long long out_n, float *bb, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
+                          float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg, uint8_t *seg_valid,
+                          uint32_t *blk_cnt, unsigned *nseg, unsigned *seg_stride, hipStream_t s);
+
 /* ---- preamble detection / refinement / greedy chain ----------------------------------- */
 #define AM_DET_THREADS 256
 #define AM_DET_PER_THREAD 8

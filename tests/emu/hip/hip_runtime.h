@@ -50,6 +50,9 @@ uint64_t shuffle(uint64_t v, int src_lane_rel, int width, int mode);   // mode 0
 } // namespace hipemu
 
 inline void __syncthreads() { hipemu::barrier(); }
+// wave-level compiler fence in the product = a real rendezvous of the wave's fibers here
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)hipemu::ballot(0))
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }

@@ -37,6 +37,23 @@ def test_stages(lib, rate, n, lam, seed, pmf):
     assert pc.check_stages(lib, rate, n, lam, seed, pmf=pmf) > 5
 
 
+def test_tiled_fused_kernel_still_matches(lib, monkeypatch):
+    monkeypatch.setenv("AIRMODES_NO_SPAN", "1")
+    for rate, n in ((16e6, 2000000), (20e6, 2000000), (64e6, 6000000)):
+        assert pc.check_stages(lib, rate, n, 6000.0, 51) > 3
+
+
+def test_span_geometry_variants(lib, monkeypatch):
+    iq, _ = synth.synth_capture(64e6, 4000000, 20000.0, seed=61)
+    want = oracle.demod(iq, 64e6)
+    for bps in ("1", "3", "64", "100000"):
+        monkeypatch.setenv("AIRMODES_SPAN_BLOCKS", bps)
+        ctx = _capi.Context(64e6, 7.0, True, lib=lib)
+        got = ctx.process_iq(iq, flush=True)
+        ctx.close()
+        assert np.array_equal(got, want), bps
+
+
 def test_generic_kernels_still_match(lib, monkeypatch):
     monkeypatch.setenv("AIRMODES_GENERIC", "1")
     for rate, n in ((2e6, 1000000), (20e6, 2000000), (64e6, 4000000)):
