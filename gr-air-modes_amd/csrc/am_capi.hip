@@ -38,7 +38,7 @@ struct am_ctx {
     int use_pmf = 0;
     int tile = 0;
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
-    bool no_span = false;         // AIRMODES_NO_SPAN=1: tiled fused kernel instead of the per-wave span kernel
+    bool no_span = true;          // AIRMODES_SPAN=1: experimental per-wave span kernel instead of the tiled fused kernel
     char err[256] = "";
 
     // stream state (absolute sample indices)
@@ -426,8 +426,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
-            const char *ns = getenv("AIRMODES_NO_SPAN");
-            c->no_span = ns && ns[0] == '1';
+            const char *ns = getenv("AIRMODES_SPAN");
+            c->no_span = !(ns && ns[0] == '1');
         }
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);

@@ -127,7 +127,7 @@ struct am_fe2_args {
 };
 
 template <int SPC, int CPT>
-__global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
+__global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
 {
     constexpr int R = SPC * CPT;                 // samples per thread
     constexpr int T = FE2_NT * R;                // samples per tile
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     __syncthreads();
 
     // logical LDS index of chip c (c = 0 is the extra halo chip, tile chips start at 49)
-    auto chip_base = [](int c) { return LHP - LH + c * SPC; };
+    auto chip_base = [](int c) __attribute__((always_inline)) { return LHP - LH + c * SPC; };
     const int c0 = FE2_LH_CHIPS + tid * CPT;               // first chip of this thread's run
     const int run_base = LHP + tid * R;                    // == chip_base(c0)
 
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(FE2_NT) am_k_fe2(am_fe2_args a)
     uint32_t *NL = WS + 16;                                // positions that need a late() flag
     uint32_t *NLP = NL + (NWORDS + 1);                     // exclusive prefix of popcounts
     uint32_t *LB = NLP + (NWORDS + 2);                     // late flags
-    auto energy = [&](int at) {
+    auto energy = [&](int at) __attribute__((always_inline)) {
         double e = 0.0;
         constexpr int chips[4] = {0, 2, 7, 9};
 #pragma unroll

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(AM_WAVE, 2) am_k_span(am_span_args a)
 
     // ---- helpers ------------------------------------------------------------------------------
     // request the IQ of block b (relative to out_abs0): branch-free clamped loads, zeroed later
-    auto iq_request = [&](int b, float4 (&v)[NLD]) {
+    auto iq_request = [&](int b, float4 (&v)[NLD]) __attribute__((always_inline)) {
         const long long n0 = a.out_abs0 + (long long)b * L;        // absolute first sample
         const long long rel0 = n0 - a.src_abs0;
         if (vec) {
@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(AM_WAVE, 2) am_k_span(am_span_args a)
         }
     };
     // |.|^2 (a1) of the requested block into ring rows [row0, row0+48)
-    auto stage_m = [&](int b, const float4 (&v)[NLD], int row0) {
+    auto stage_m = [&](int b, const float4 (&v)[NLD], int row0) __attribute__((always_inline)) {
         const long long n0 = a.out_abs0 + (long long)b * L;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(AM_WAVE, 2) am_k_span(am_span_args a)
     };
     // pulse matched filter (a3) for this lane's chip of the block staged in rows [row0, ..):
     // bbn = bb of the chip; also leaves bb in the ring (in place) and in the mirror rows
-    auto pmf_block = [&](int b, int row0, float (&bbn)[SPC]) {
+    auto pmf_block = [&](int b, int row0, float (&bbn)[SPC]) __attribute__((always_inline)) {
         float mc[SPC];
 #pragma unroll
         for (int i = 0; i < SPC; ++i) mc[i] = 0.0f;
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(AM_WAVE, 2) am_k_span(am_span_args a)
         AM_WAVE_SYNC();                                                 // bb rows visible to all lanes
     };
     // dense bb of block b: ring rows -> HBM, 16 bytes per lane, coalesced
-    auto bb_store = [&](int b, int row0) {
+    auto bb_store = [&](int b, int row0) __attribute__((always_inline)) {
         if (!a.bb) return;
         const long long o0 = (long long)b * L;
         constexpr int NQ = L / 4;
@@ -268,13 +268,13 @@ __global__ void __launch_bounds__(AM_WAVE, 2) am_k_span(am_span_args a)
         }
     };
     // sample s (>= 0, relative to the start of the current block, up to 48+17 chips) in the ring
-    auto ring_at = [&](int cur_row0, int s) -> float {
+    auto ring_at = [&](int cur_row0, int s) __attribute__((always_inline)) -> float {
         const int c = s / SPC, o = s - c * SPC;
         return RING[(cur_row0 + c) * CS + o];
     };
     // 4-pulse energy at sample s of the current block (preamble_impl.cc:91-98: chips 0,2,7,9,
     // chip-major, double accumulation)
-    auto energy = [&](int cur_row0, int s) {
+    auto energy = [&](int cur_row0, int s) __attribute__((always_inline)) {
         double e = 0.0;
         constexpr int chips[4] = {0, 2, 7, 9};
         const int c0 = s / SPC, o0 = s - c0 * SPC;
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(AM_WAVE, 2) am_k_span(am_span_args a)
         return e;
     };
     // wave-exclusive scan of a per-lane count; *total = wave sum
-    auto wave_excl = [&](uint32_t cnt, uint32_t *total) {
+    auto wave_excl = [&](uint32_t cnt, uint32_t *total) __attribute__((always_inline)) {
         uint32_t incl = cnt;
         for (int d = 1; d < AM_WAVE; d <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);

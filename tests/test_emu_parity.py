@@ -64,9 +64,8 @@ def test_sharded(emu_lib, rate, n, G):
 
 
 def test_tiled_fused_kernel_still_matches(emu_lib, monkeypatch):
-    """16..64 Msps normally run the per-wave span kernel; the tiled fused kernel (used for
-    2..10 Msps) must give the same answers there too."""
-    monkeypatch.setenv("AIRMODES_NO_SPAN", "1")
+    """The tiled fused kernel is the default everywhere it is specialised."""
+    monkeypatch.delenv("AIRMODES_SPAN", raising=False)
     for rate, n in ((16e6, 200000), (20e6, 300000), (64e6, 500000)):
         assert pc.check_stages(emu_lib, rate, n, 6000.0, 51) > 3
 
@@ -75,6 +74,7 @@ def test_span_geometry_variants(emu_lib, monkeypatch):
     """Span length must not matter (1 block per span ... everything in one span)."""
     iq, _ = synth.synth_capture(64e6, 400000, 20000.0, seed=61)
     want = oracle.demod(iq, 64e6)
+    monkeypatch.setenv("AIRMODES_SPAN", "1")
     for bps in ("1", "2", "5", "1000"):
         monkeypatch.setenv("AIRMODES_SPAN_BLOCKS", bps)
         ctx = _capi.Context(64e6, 7.0, True, lib=emu_lib)
