@@ -38,6 +38,7 @@ struct am_ctx {
     int use_pmf = 0;
     int tile = 0;
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
+    bool fe2_inkernel = false;    // AIRMODES_FE2_INKERNEL=1: refine inside the fused kernel (A/B testing)
     bool no_span = true;          // AIRMODES_SPAN=1: experimental per-wave span kernel instead of the tiled fused kernel
     char err[256] = "";
 
@@ -51,7 +52,7 @@ struct am_ctx {
 
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, seg_e, seg_inavg, seg_valid, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
-        visited, emit, jump, emit_idx,
+        visited, emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs;
 
     // results of the last scan
@@ -176,8 +177,8 @@ int run_frontend(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_ab
 // Scan of the per-segment candidate counts and read-back of the total; then either the
 // refinement kernel (generic path: candidates only) or the gather of the records the fused
 // kernel already produced.  Leaves the flat records (pos, e, tgt, inavg, valid) on the device.
-int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint32_t seg_stride, bool fused,
-               uint32_t *M_out)
+int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint32_t seg_stride, int mode,
+               uint32_t *M_out, uint32_t end_j = 0xFFFFFFFFu)
 {
     *M_out = 0;
     if (nseg == 0) return AM_OK;
@@ -192,7 +193,27 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
         ENSURE(c, c->valid, (size_t)M + 1);
-        if (fused)
+        if (mode == 2) {
+            // split refinement: positions -> energies once per reachable position -> per-candidate test
+            const uint32_t nb = (M + 2047u) / 2048u;
+            const uint64_t ebound = std::min<uint64_t>((uint64_t)M * (uint64_t)(c->spc + 1), (uint64_t)M + 0xFFFFFFFFull);
+            ENSURE(c, c->dcount, ((size_t)M + 1) * sizeof(uint32_t));
+            ENSURE(c, c->off_local, ((size_t)M + 1) * sizeof(uint32_t));
+            ENSURE(c, c->blk_tot2, ((size_t)nb + 1) * sizeof(uint32_t));
+            ENSURE(c, c->blk_base2, ((size_t)nb + 2) * sizeof(uint32_t));
+            ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
+            HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
+                                           c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream));
+            HIPCHK(c, am_launch_exscan_blocks((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
+                                              (uint32_t *)c->blk_tot2.p, M, c->stream));
+            HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_tot2.p, (uint32_t *)c->blk_base2.p, nb, c->stream));
+            HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
+                                       (uint32_t *)c->blk_base2.p, M, c->spc, (double *)c->energy.p, c->stream));
+            HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
+                                     (uint32_t *)c->off_local.p, (uint32_t *)c->blk_base2.p, (double *)c->energy.p, M,
+                                     c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
+                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream));
+        } else if (mode == 1)
             HIPCHK(c, am_launch_flatten((uint32_t *)c->cand_seg.p, (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p,
                                         (uint8_t *)c->seg_valid.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
                                         c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
@@ -219,7 +240,7 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
     ENSURE(c, c->blk_off, ((size_t)nblk + 1) * sizeof(uint32_t));
     HIPCHK(c, am_launch_detect(bb, avg, j0, j1, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p,
                                (uint32_t *)c->blk_cnt.p, nblk, c->stream));
-    return run_refine(c, bb, avg, nblk, AM_DET_PER_BLOCK, false, M_out);
+    return run_refine(c, bb, avg, nblk, AM_DET_PER_BLOCK, 0, M_out);
 }
 
 // IQ -> bb, avg and the refined candidate records for positions [j0, j1): the fused
@@ -247,7 +268,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                                  (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p,
                                  (uint32_t *)c->blk_cnt.p, &ns, &st, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        return run_refine(c, bb, avg, ns, st, true, M_out);
+        return run_refine(c, bb, avg, ns, st, 1, M_out);
     }
     if (T2 == 0) {
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
@@ -264,13 +285,22 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     ENSURE(c, c->blk_cnt, ((size_t)ntiles + 8) * sizeof(uint32_t));
     ENSURE(c, c->blk_off, ((size_t)ntiles + 9) * sizeof(uint32_t));
     unsigned nt = 0, tl = 0;
+    // split refinement (default): the fused kernel stops after detection and leaves avg[] around the
+    // candidates; AIRMODES_FE2_INKERNEL=1 refines inside the kernel instead
+    float *avg_sparse = nullptr;
+    if (!c->fe2_inkernel && !avg) {
+        ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
+        avg_sparse = (float *)c->avg.p;
+    }
     HIPCHK(c, am_launch_fe2(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
                             (long long)out_n, bb, avg, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                             (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
-                            (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p,
+                            (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p, avg_sparse,
                             (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    return run_refine(c, bb, avg, nt, tl, true, M_out);
+    const uint64_t endj = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
+    return run_refine(c, bb, avg_sparse ? avg_sparse : avg, nt, tl, avg_sparse ? 2 : 1, M_out,
+                      (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull));
 }
 
 // Greedy chain over the M flat records + extraction + slicing.  Only hits whose shifted start
@@ -426,6 +456,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
+            const char *ik = getenv("AIRMODES_FE2_INKERNEL");
+            c->fe2_inkernel = ik && ik[0] == '1';
             const char *ns = getenv("AIRMODES_SPAN");
             c->no_span = !(ns && ns[0] == '1');
         }
@@ -454,7 +486,8 @@ void am_destroy(am_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->seg_e, &c->seg_inavg,
-                     &c->seg_valid, &c->inavg, &c->blk_cnt, &c->blk_off,
+                     &c->seg_valid, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
+                     &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs};

@@ -114,6 +114,8 @@ struct am_fe2_args {
     long long out_n;                // outputs wanted
     float *bb;                      // dense pulse-matched power (read by burst extraction); may be null
     float *avg;                     // dense reference level; only written when non-null (block-level API)
+    float *avg_sparse;              // split mode: avg runs around candidates only (read by am_k_cand)
+    int split_refine;               // 1: stop after detection, refinement runs as separate kernels
     uint32_t j0, j1;                // positions (array coordinates) whose preamble test is wanted
     uint32_t *seg_pos;              // per tile: T candidate positions ...
     uint32_t *seg_e;                // ... shifted starts
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     float *ST = PT + NCH;
     uint32_t *BM = reinterpret_cast<uint32_t *>(ST + NCH);  // candidate bitmap [NWORDS]
     uint32_t *WS = BM + NWORDS;                             // wave sums for the block scan
+    uint32_t *RUNANY = WS + 16 + 3 * (NWORDS + 2);          // per thread: does its run hold a candidate
 
     const int tid = threadIdx.x;
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous range of
@@ -389,7 +392,6 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             const float nx = (i + 1 < R) ? bbv[(i + 1 < R) ? i + 1 : i] : nxt;
             const uint32_t j = jt0 + (uint32_t)(tid * R + i);
             c[i] = (x > thr) && !(nx > x) && j >= a.j0 && j < a.j1;     // :174, :175
-            avgv[i] = thr;                                               // only the threshold is needed below
         }
         constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
 #pragma unroll
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             float t[R];
             fe2_lds_load<R, SHIFT_AL>(X, run_base + offs[o], t);
 #pragma unroll
-            for (int i = 0; i < R; ++i) c[i] = c[i] && !(t[i] < avgv[i]);   // :177-179
+            for (int i = 0; i < R; ++i) c[i] = c[i] && !(t[i] < avgv[i] * a.thr_lin);   // :177-179
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) if (c[i]) cmask[i >> 5] |= 1u << (i & 31);
@@ -414,8 +416,24 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
                 }
             }
         }
+        RUNANY[tid] = 0u;
+#pragma unroll
+        for (int w = 0; w < (R + 31) / 32; ++w) if (cmask[w]) RUNANY[tid] = 1u;
     }
     __syncthreads();
+
+    // split mode: the refinement kernels need avg[e] for e in a candidate's run or the next one;
+    // write those runs only (plus the tile's first run, for candidates at the end of the previous tile)
+    if (a.split_refine && a.avg_sparse && !(a.ablate & 64u)) {
+        const bool need = tid == 0 || RUNANY[tid] != 0u || RUNANY[tid - 1] != 0u;
+        if (need) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                const long long o = (long long)jt0 + tid * R + i;
+                if (o < a.out_n) a.avg_sparse[o] = avgv[i];
+            }
+        }
+    }
 
     // ---- P6: bb out (coalesced), ordered candidate list ---------------------------------------------
     if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
@@ -456,7 +474,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         }
         if (tid == 0) a.blk_cnt[tile] = total;
     }
-    if (total == 0 || (a.ablate & 128u)) return;          // uniform: nothing to refine
+    if (total == 0 || a.split_refine || (a.ablate & 128u)) return;   // uniform: nothing to refine here
     __syncthreads();                                       // seg[] written by other waves is visible
 
     // ---- P7: refinement of this tile's candidates from LDS (a7, a8) -----------------------------------
@@ -624,7 +642,7 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     constexpr int RH = FE2_RH_CHIPS * SPC;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;
     constexpr int NWORDS = (T + 31) / 32;
-    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + 3 * (NWORDS + 2)) *
+    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + 3 * (NWORDS + 2) + FE2_NT) *
                        sizeof(float);
     am_fe2_args a = a_in;
     size_t lds_req = lds;
@@ -661,9 +679,12 @@ unsigned am_fe2_tile(int spc)
 hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
                          float sL, float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg,
-                         uint8_t *seg_valid, uint32_t *blk_cnt, unsigned *ntiles, unsigned *tile_len, hipStream_t s)
+                         uint8_t *seg_valid, float *avg_sparse, uint32_t *blk_cnt, unsigned *ntiles,
+                         unsigned *tile_len, hipStream_t s)
 {
     am_fe2_args a;
+    a.avg_sparse = avg_sparse;
+    a.split_refine = avg_sparse != nullptr;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
     a.bb = bb; a.avg = avg; a.j0 = j0; a.j1 = j1; a.seg_pos = seg_pos; a.seg_e = seg_e; a.seg_inavg = seg_inavg;
     a.seg_valid = seg_valid; a.blk_cnt = blk_cnt; a.ntiles = 0;

@@ -40,7 +40,22 @@ unsigned am_fe2_tile(int spc);
 hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
                          float sL, float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg,
-                         uint8_t *seg_valid, uint32_t *blk_cnt, unsigned *ntiles, unsigned *tile_len, hipStream_t s);
+                         uint8_t *seg_valid, float *avg_sparse, uint32_t *blk_cnt, unsigned *ntiles,
+                         unsigned *tile_len, hipStream_t s);
+/* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
+ * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
+hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
+                                uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
+                                hipStream_t s);
+hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
+                                   hipStream_t s);
+hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
+                            const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
+                            double *energy, hipStream_t s);
+hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
+                          const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
+                          int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
+                          uint8_t *valid, hipStream_t s);
 /* segmented records of the fused kernel -> flat, position-ordered arrays */
 hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, const float *seg_inavg,
                              const uint8_t *seg_valid, uint32_t seg_stride, const uint32_t *blk_off,

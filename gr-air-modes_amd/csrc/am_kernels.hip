@@ -424,6 +424,175 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
 }
 
 // ------------------------------------------------------------------------------------------
+// Split refinement (used after the fused front end).  A lane-per-candidate late-peak search makes
+// every wave as slow as its slowest lane (3 % of the candidates slide the full spc steps) and
+// recomputes the same energies for neighbouring candidates.  Instead the energies E(q) are
+// computed ONCE per reachable position: candidate c (positions sorted) contributes the
+// d[c] = min(spc+1, pos[c]-pos[c-1]) positions (pos[c]+spc-d[c], pos[c]+spc] that its
+// predecessors did not already cover; an exclusive scan of d[] lays them out contiguously, so
+// position pos[c]+s sits at index off[c]+d[c]-1-spc+s.  am_k_energy fills that array with one
+// lane per position (consecutive lanes = consecutive positions: coalesced loads); am_k_cand then
+// walks at most spc comparisons per candidate and does the quiet-zone test.
+// ------------------------------------------------------------------------------------------
+#define AM_SCAN_BLK 2048
+
+__global__ void __launch_bounds__(256)
+am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const uint32_t *__restrict__ blk_off,
+                uint32_t nseg, uint32_t M, int spc, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blk_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    const uint32_t slot = g - blk_off[lo];
+    const uint32_t p = seg_pos[(size_t)lo * seg_stride + slot];
+    uint32_t d = (uint32_t)spc + 1u;
+    if (g > 0) {
+        // previous candidate: same segment, or the last one of the nearest non-empty earlier segment
+        uint32_t pl = lo, ps = slot;
+        if (ps == 0) {
+            uint32_t l2 = 0, h2 = lo;       // last segment index < lo with blk_off[seg] < blk_off[lo] == g
+            while (h2 - l2 > 1) {
+                const uint32_t mid = (l2 + h2) >> 1;
+                if (blk_off[mid] < g) l2 = mid; else h2 = mid;
+            }
+            pl = l2;
+            ps = g - blk_off[pl];
+        }
+        const uint32_t pp = seg_pos[(size_t)pl * seg_stride + (ps - 1)];
+        const uint32_t gap = p - pp;
+        d = gap < d ? gap : d;
+    }
+    pos[g] = p;
+    dcount[g] = d;
+}
+
+// block-local exclusive scan (2048 elements per workgroup) + block totals
+__global__ void __launch_bounds__(256)
+am_k_exscan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out_local, uint32_t *__restrict__ blk_tot,
+                   uint32_t n)
+{
+    __shared__ uint32_t ws[256 / AM_WAVE];
+    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
+    const uint32_t base = blockIdx.x * AM_SCAN_BLK + threadIdx.x * 8;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+    for (int d = 1; d < AM_WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
+        if (lane >= d) incl += up;
+    }
+    if (lane == AM_WAVE - 1) ws[wv] = incl;
+    __syncthreads();
+    uint32_t off = incl - sum, total = 0;
+    for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) off += ws[k]; total += ws[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (base + k < n) out_local[base + k] = off; off += v[k]; }
+    if (threadIdx.x == 0) blk_tot[blockIdx.x] = total;
+}
+
+__device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_local,
+                                              const uint32_t *__restrict__ blk_base, uint32_t c)
+{
+    return off_local[c] + blk_base[c / AM_SCAN_BLK];
+}
+
+__global__ void __launch_bounds__(256)
+am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,
+            const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t M, int spc,
+            double *__restrict__ energy)
+{
+    const uint32_t nb = (M + AM_SCAN_BLK - 1) / AM_SCAN_BLK;
+    const uint32_t total = blk_base[nb];                     // number of positions that need an energy
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
+        // candidate that contributed compact index k: last c with off[c] <= k
+        uint32_t lo = 0, hi = M;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (am_off_at(off_local, blk_base, mid) <= k) lo = mid; else hi = mid;
+        }
+        const uint32_t q = pos[lo] + (uint32_t)spc + 1u - dcount[lo] + (k - am_off_at(off_local, blk_base, lo));
+        energy[k] = am_preamble_energy(bb + q, spc);         // preamble_impl.cc:91-98
+    }
+}
+
+__global__ void __launch_bounds__(256)
+am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
+          const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ off_local,
+          const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t M, int spc,
+          float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
+          float *__restrict__ inavg, uint8_t *__restrict__ valid)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= M) return;
+    const uint32_t j = pos[g];
+    // late-peak search (preamble_impl.cc:184-192) over the precomputed energies
+    const double *E = energy + (am_off_at(off_local, blk_base, g) + dcount[g] - 1u - (uint32_t)spc);
+    int how_late = 0;
+    while (how_late < spc && E[how_late + 1] > E[how_late]) how_late++;
+    const uint32_t e = j + (uint32_t)how_late;
+    // quiet zones (preamble_impl.cc:198-209)
+    const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
+    const float av = (e >= end_j) ? 0.0f : avg_sparse[e];   // beyond the end of the stream: 0
+    float ps = p0 + p1;
+    ps = ps + p2;
+    ps = ps + p3;
+    const float avgpeak = (float)((double)ps / 4.0);
+    const float sthr = av + (avgpeak - av) / thr_lin;
+    const bool ok = !am_any_above(bb + e + 3 * spc, 3 * spc + 1, sthr) &&      // offsets 3spc .. 6spc
+                    !am_any_above(bb + e + 10 * spc, 5 * spc + 1, sthr);       // offsets 10spc .. 15spc
+    eo[g] = e;
+    inavg[g] = av;
+    valid[g] = ok ? 1 : 0;
+    tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+}
+
+hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
+                                uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
+                                hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_gather_pos, dim3((M + 255) / 256), dim3(256), 0, s, seg_pos, seg_stride, blk_off, nseg,
+                       M, spc, pos, dcount);
+    return hipGetLastError();
+}
+hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
+                                   hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_exscan_blocks, dim3((n + AM_SCAN_BLK - 1) / AM_SCAN_BLK), dim3(256), 0, s, in,
+                       out_local, blk_tot, n);
+    return hipGetLastError();
+}
+hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
+                            const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
+                            double *energy, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    // grid-stride over a device-side count: no host round trip for the number of positions
+    uint64_t bound = (uint64_t)M * (uint64_t)(spc + 1);
+    unsigned grid = (unsigned)((bound + 255) / 256);
+    if (grid > 8192u) grid = 8192u;
+    hipLaunchKernelGGL(am_k_energy, dim3(grid), dim3(256), 0, s, bb, pos, dcount, off_local, blk_base, M, spc,
+                       energy);
+    return hipGetLastError();
+}
+hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
+                          const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
+                          int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
+                          uint8_t *valid, hipStream_t s)
+{
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_cand, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg_sparse, pos, dcount, off_local,
+                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Greedy chain.  The reference scan visits candidates in position order; after visiting c it
 // resumes at tgt[c], so the next visited candidate is succ(c) = first candidate with
 // pos >= tgt[c].  The visited set is the orbit of the root under succ: computed with
