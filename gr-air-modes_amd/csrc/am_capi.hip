@@ -67,6 +67,12 @@ struct am_ctx {
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
     bool shard_ready = false;
 
+    // pinned host memory the tail kernels write into directly
+    am_packet *pin_packets = nullptr;
+    am_tag *pin_tags = nullptr;
+    uint32_t *pin_scalars = nullptr;
+    uint32_t pin_cap = 0;
+
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_total_ms = 0.0f, last_dom_ms = 0.0f;
 };
@@ -307,7 +313,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
 // e lies in [own_lo, own_hi] and is <= emit_max are extracted (bb/avg must cover them).
 // cur0 = position at which the scan starts.  Fills h_packets / h_tags (+ h_bursts).
 int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M, uint32_t cur0,
-                        uint32_t emit_max, uint64_t base_abs, bool keep_bursts, uint32_t *final_cur,
+                        uint32_t emit_max, uint64_t base_abs, bool keep_bursts, uint32_t *final_cur, uint32_t max_hits,
                         uint32_t own_lo = 0, uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
 {
     c->h_packets.clear();
@@ -316,8 +322,13 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
     c->last_M = M;
     *final_cur = cur0;
     if (M == 0) return AM_OK;
+    // radix-16 pointer jumping: table k+1 = table k applied 16 times
+    const int RADIX = 16;
     int levels = 1;
-    while (((uint64_t)1 << levels) < (uint64_t)M + 1) levels++;
+    {
+        uint64_t reach = RADIX;
+        while (reach < (uint64_t)M + 1) { reach *= RADIX; levels++; }
+    }
     const size_t stride = (size_t)M + 1;
     ENSURE(c, c->visited, stride);
     ENSURE(c, c->emit, stride);
@@ -330,9 +341,10 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
     HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, cur0, jump,
                                    (uint8_t *)c->visited.p, c->stream));
     for (int k = 0; k < levels; k++)
-        HIPCHK(c, am_launch_chain_double(jump + (size_t)k * stride, jump + (size_t)(k + 1) * stride, M, c->stream));
+        HIPCHK(c, am_launch_chain_double(jump + (size_t)k * stride, jump + (size_t)(k + 1) * stride, M, RADIX,
+                                         c->stream));
     for (int k = levels; k >= 0; k--)
-        HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, c->stream));
+        HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, RADIX, c->stream));
     HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
                                    (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
                                    (uint8_t *)c->emit.p, (uint32_t *)c->scalars.p, c->stream));
@@ -341,37 +353,44 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
     HIPCHK(c, am_launch_flag_count((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_cnt.p, c->stream));
     HIPCHK(c, am_launch_scan_u32((uint32_t *)c->cblk_cnt.p, (uint32_t *)c->cblk_off.p, nb, c->stream));
-    uint32_t n_emit = 0, sc[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(&n_emit, (uint32_t *)c->cblk_off.p + nb, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipMemcpyAsync(sc, c->scalars.p, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    *final_cur = sc[0];
-    if (n_emit == 0) return AM_OK;
-    ENSURE(c, c->emit_idx, (size_t)n_emit * sizeof(uint32_t));
-    ENSURE(c, c->bursts, (size_t)n_emit * AM_BURST * sizeof(float));
-    ENSURE(c, c->tags, (size_t)n_emit * sizeof(am_tag));
-    ENSURE(c, c->packets, (size_t)n_emit * sizeof(am_packet));
+    // Hits are at least 240*spc apart, so their number is bounded by the span of the candidates;
+    // everything downstream is launched for that bound and reads the real count on the device.
+    // Packets and tags land directly in pinned host memory: one synchronisation for the whole tail.
+    const uint32_t n_max = max_hits < M ? max_hits : M;
+    const uint32_t *n_ptr = (const uint32_t *)c->cblk_off.p + nb;
+    ENSURE(c, c->emit_idx, (size_t)n_max * sizeof(uint32_t));
+    ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
+    if (c->pin_cap < n_max) {
+        if (c->pin_packets) (void)hipHostFree(c->pin_packets);
+        if (c->pin_tags) (void)hipHostFree(c->pin_tags);
+        c->pin_packets = nullptr; c->pin_tags = nullptr; c->pin_cap = 0;
+        const size_t want = (size_t)n_max + n_max / 4 + 64;
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_packets, want * sizeof(am_packet), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_tags, want * sizeof(am_tag), hipHostMallocDefault));
+        c->pin_cap = (uint32_t)want;
+    }
+    if (!c->pin_scalars) HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
                                      (uint32_t *)c->emit_idx.p, c->stream));
-    HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_emit,
-                                (uint32_t *)c->pos.p,
-                                (uint32_t *)c->e.p, base_abs, e_off, c->rate_i, (float *)c->bursts.p,
-                                (am_tag *)c->tags.p, c->stream));
-    HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, n_emit, (uint32_t *)c->crc_pow.p,
-                              (am_packet *)c->packets.p, c->stream));
-    c->h_packets.resize(n_emit);
-    c->h_tags.resize(n_emit);
-    HIPCHK(c, hipMemcpyAsync(c->h_packets.data(), c->packets.p, (size_t)n_emit * sizeof(am_packet),
-                             hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_tags.data(), c->tags.p, (size_t)n_emit * sizeof(am_tag),
-                             hipMemcpyDeviceToHost, c->stream));
-    if (keep_bursts) {
+    HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
+                                (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
+                                (float *)c->bursts.p, c->pin_tags, c->stream));
+    HIPCHK(c, am_launch_slice((float *)c->bursts.p, c->pin_tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
+                              c->pin_packets, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->pin_scalars[0], n_ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->pin_scalars[1], c->scalars.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t n_emit = c->pin_scalars[0];
+    *final_cur = c->pin_scalars[1];
+    if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
+    c->h_packets.assign(c->pin_packets, c->pin_packets + n_emit);
+    c->h_tags.assign(c->pin_tags, c->pin_tags + n_emit);
+    if (keep_bursts && n_emit) {
         c->h_bursts.resize((size_t)n_emit * AM_BURST);
         HIPCHK(c, hipMemcpyAsync(c->h_bursts.data(), c->bursts.p, (size_t)n_emit * AM_BURST * sizeof(float),
                                  hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return AM_OK;
 }
 
@@ -492,6 +511,9 @@ void am_destroy(am_ctx *c)
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs};
     for (DevBuf *b : all) release(*b);
+    if (c->pin_packets) (void)hipHostFree(c->pin_packets);
+    if (c->pin_tags) (void)hipHostFree(c->pin_tags);
+    if (c->pin_scalars) (void)hipHostFree(c->pin_scalars);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -601,7 +623,8 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         const uint32_t cur0 = c->chain_cur > out_abs0 ? (uint32_t)std::min<uint64_t>(c->chain_cur - out_abs0, 0xFFFFFFF0u) : 0u;
         const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - out_abs0);
         uint32_t fin = cur0;
-        rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, out_abs0, false, &fin);
+        const uint32_t max_hits = (uint32_t)((P1 - P0 + S) / ((uint64_t)AM_BURST * S) + 2);
+        rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, out_abs0, false, &fin, max_hits);
         if (rc != AM_OK) return rc;
         c->last_tags = c->h_packets.size();
         collect_accepted(c);
@@ -702,7 +725,8 @@ int am_preamble_work(am_ctx *c, const float *in, const float *inavg, uint64_t n,
         uint32_t M = 0, fin = 0;
         int rc = run_candidates(c, bb, avg, 0, (uint32_t)(em + 1), &M);
         if (rc != AM_OK) return rc;
-        rc = run_chain_and_slice(c, bb, avg, M, 0, (uint32_t)em, 0, true, &fin);
+        rc = run_chain_and_slice(c, bb, avg, M, 0, (uint32_t)em, 0, true, &fin,
+                                 (uint32_t)(n / ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2));
         if (rc != AM_OK) return rc;
     }
     const uint64_t nt = c->h_tags.size();
@@ -731,8 +755,11 @@ int am_slicer_work(am_ctx *c, const float *bursts, const am_tag *tags, uint64_t 
     ENSURE(c, c->packets, nb * sizeof(am_packet));
     HIPCHK(c, hipMemcpyAsync(c->bursts.p, bursts, nb * AM_BURST * sizeof(float), kind, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tags.p, tags, nb * sizeof(am_tag), kind, c->stream));
-    HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, (uint32_t)nb, (uint32_t *)c->crc_pow.p,
-                              (am_packet *)c->packets.p, c->stream));
+    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    const uint32_t nb32 = (uint32_t)nb;
+    HIPCHK(c, hipMemcpyAsync(c->scalars.p, &nb32, sizeof(nb32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, (const uint32_t *)c->scalars.p, nb32,
+                              (uint32_t *)c->crc_pow.p, (am_packet *)c->packets.p, c->stream));
     c->h_packets.resize(nb);
     HIPCHK(c, hipMemcpyAsync(c->h_packets.data(), c->packets.p, nb * sizeof(am_packet), hipMemcpyDeviceToHost,
                              c->stream));
@@ -903,7 +930,10 @@ int am_shard_resolve(am_ctx *c, const am_cand *all_recs, uint64_t n_all, uint32_
     const long long e_off = (long long)gbase - (long long)c->shard_base;
     uint32_t fin = 0;
     int rc = run_chain_and_slice(c, (const float *)c->bb.p, nullptr, M, 0u,
-                                 (uint32_t)(em - gbase), gbase, false, &fin, own_lo, own_hi, e_off);
+                                 (uint32_t)(em - gbase), gbase, false, &fin,
+                                 (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
+                                            ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2),
+                                 own_lo, own_hi, e_off);
     if (rc != AM_OK) return rc;
     c->last_tags = c->h_packets.size();
     collect_accepted(c);

@@ -105,8 +105,8 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
                             float *inavg, uint8_t *valid, hipStream_t s);
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
                                 uint32_t *jump0, uint8_t *visited, hipStream_t s);
-hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, hipStream_t s);
-hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, hipStream_t s);
+hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s);
+hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s);
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *scalars,
@@ -123,12 +123,13 @@ hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const f
                                  hipStream_t s);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
+/* n_ptr: device-side number of hits; n_max: upper bound used for the grid */
 hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
-                             uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
+                             const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
                              uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
                              am_tag *tags, hipStream_t s);
 /* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
-hipError_t am_launch_slice(const float *bursts, const am_tag *tags, uint32_t n,
+hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, hipStream_t s);
 
 #endif

@@ -626,19 +626,28 @@ am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ t
 }
 
 __global__ void __launch_bounds__(256)
-am_k_chain_double(const uint32_t *__restrict__ jk, uint32_t *__restrict__ jk1, uint32_t M)
+am_k_chain_double(const uint32_t *__restrict__ jk, uint32_t *__restrict__ jk1, uint32_t M, int hops)
 {
+    // jk1 = jk applied `hops` times (radix-16 pointer jumping: fewer, fatter launches)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g <= M) jk1[g] = jk[jk[g]];
+    if (g > M) return;
+    uint32_t t = g;
+    for (int h = 0; h < hops && t < M; ++h) t = jk[t];
+    jk1[g] = t;
 }
 
 __global__ void __launch_bounds__(256)
-am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M)
+am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M, int hops)
 {
+    // every node already known to be visited marks its next hops-1 successors under jk
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < M && visited[g]) {
-        const uint32_t t = jk[g];
-        if (t < M) visited[t] = 1;
+        uint32_t t = g;
+        for (int h = 1; h < hops; ++h) {
+            t = jk[t];
+            if (t >= M) break;
+            visited[t] = 1;
+        }
     }
 }
 
@@ -684,14 +693,14 @@ hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32
                        cur0, jump0, visited);
     return hipGetLastError();
 }
-hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, hipStream_t s)
+hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s)
 {
-    hipLaunchKernelGGL(am_k_chain_double, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, jk, jk1, M);
+    hipLaunchKernelGGL(am_k_chain_double, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, jk, jk1, M, hops);
     return hipGetLastError();
 }
-hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, hipStream_t s)
+hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s)
 {
-    hipLaunchKernelGGL(am_k_chain_mark, dim3(am_grid(M, 256)), dim3(256), 0, s, jk, visited, M);
+    hipLaunchKernelGGL(am_k_chain_mark, dim3(am_grid(M, 256)), dim3(256), 0, s, jk, visited, M, hops);
     return hipGetLastError();
 }
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
@@ -834,13 +843,13 @@ hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const f
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
-             const uint32_t *__restrict__ emit_idx, uint32_t n_emit, const uint32_t *__restrict__ pos,
+             const uint32_t *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ pos,
              const uint32_t *__restrict__ eo, uint64_t base_abs, long long e_off, uint64_t rate,
              float *__restrict__ bursts, am_tag *__restrict__ tags)
 {
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
-    if (i >= n_emit) return;
+    if (i >= *n_ptr) return;                              // device-side hit count (no host round trip)
     const uint32_t g = emit_idx[i];
     const uint32_t e = eo[g];
     const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
@@ -861,12 +870,12 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int 
 }
 
 hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
-                             uint32_t n_emit, const uint32_t *pos, const uint32_t *e,
+                             const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
                              uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
                              am_tag *tags, hipStream_t s)
 {
-    if (n_emit == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_emit, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_emit,
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_ptr,
                        pos, e, base_abs, e_off, rate, bursts, tags);
     return hipGetLastError();
 }
@@ -902,12 +911,12 @@ __device__ __forceinline__ uint32_t am_bitrev8(uint32_t v)
 }
 
 __global__ void __launch_bounds__(256)
-am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, uint32_t n,
+am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, const uint32_t *__restrict__ n_ptr,
            const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets)
 {
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
-    if (i >= n) return;                                   // wave-uniform
+    if (i >= *n_ptr) return;                              // wave-uniform; device-side burst count
     const float *b = bursts + (size_t)i * AM_BURST;
     float s = b[0] + b[2];                                // slicer_impl.cc:128-131
     s = s + b[7];
@@ -964,10 +973,10 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, ui
     }
 }
 
-hipError_t am_launch_slice(const float *bursts, const am_tag *tags, uint32_t n, const uint32_t *crc_pow,
-                           am_packet *packets, hipStream_t s)
+hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
+                           const uint32_t *crc_pow, am_packet *packets, hipStream_t s)
 {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_slice, dim3(am_grid(n, 4)), dim3(256), 0, s, bursts, tags, n, crc_pow, packets);
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bursts, tags, n_ptr, crc_pow, packets);
     return hipGetLastError();
 }
