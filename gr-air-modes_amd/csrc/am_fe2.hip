@@ -27,7 +27,7 @@
 #pragma clang fp contract(off)
 #endif
 
-#define FE2_NT 384
+#define FE2_NT 768
 #define FE2_RH_CHIPS 17                      /* refinement looks ahead 16 chips + 1 sample */
 #define FE2_LH_CHIPS (AM_CHIPS_AVG + 1)      /* 48-chip block + one chip                 */
 #define FE2_HALO_THREADS (AM_CHIPS_AVG + FE2_RH_CHIPS)
@@ -664,7 +664,7 @@ unsigned am_fe2_tile(int spc)
 {
     switch (spc) {
     case 1: return FE2_NT * 8;
-    case 2: return FE2_NT * 16;
+    case 2: return FE2_NT * 8;
     case 4: return FE2_NT * 16;
     case 5: return FE2_NT * 20;
     case 8: return FE2_NT * 16;
@@ -697,7 +697,7 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
     // (SPC, chips per thread): run = SPC*CPT samples per thread, chosen so that the per-chip
     // side arrays and the sample array together stay <= 80 KB of LDS (two workgroups per CU)
     case 1: return fe2_launch<1, 8>(a, s, ntiles, tile_len);
-    case 2: return fe2_launch<2, 8>(a, s, ntiles, tile_len);
+    case 2: return fe2_launch<2, 4>(a, s, ntiles, tile_len);
     case 4: return fe2_launch<4, 4>(a, s, ntiles, tile_len);
     case 5: return fe2_launch<5, 4>(a, s, ntiles, tile_len);
     case 8: return fe2_launch<8, 2>(a, s, ntiles, tile_len);
