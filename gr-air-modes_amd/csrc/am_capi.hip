@@ -347,7 +347,8 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
         HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, RADIX, c->stream));
     HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
                                    (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
-                                   (uint8_t *)c->emit.p, (uint32_t *)c->scalars.p, c->stream));
+                                   (uint8_t *)c->emit.p, (uint32_t *)c->scalars.p,
+                                   emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream));
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));

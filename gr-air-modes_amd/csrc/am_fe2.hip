@@ -396,6 +396,11 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
+            // wave-uniform early out: in quiet stretches no lane has a survivor left
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < R; ++i) any = any || c[i];
+            if (__ballot(any) == 0ull) break;
             float t[R];
             fe2_lds_load<R, SHIFT_AL>(X, run_base + offs[o], t);
 #pragma unroll

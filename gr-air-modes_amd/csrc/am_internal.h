@@ -110,7 +110,7 @@ hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *scalars,
-                                hipStream_t s);
+                                int want_resume, hipStream_t s);
 hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
                                   uint32_t *out_idx, hipStream_t s);

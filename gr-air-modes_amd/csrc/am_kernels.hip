@@ -243,32 +243,26 @@ hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint
 __global__ void __launch_bounds__(AM_SCAN_THREADS)
 am_k_scan_u32(const uint32_t *__restrict__ cnt, uint32_t *__restrict__ off, uint32_t n)
 {
-    __shared__ uint32_t buf[2][AM_SCAN_THREADS];
-    __shared__ uint32_t carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < n; c0 += AM_SCAN_THREADS) {
-        const uint32_t i = c0 + tid;
-        const uint32_t v = (i < n) ? cnt[i] : 0u;
-        int cur = 0;
-        buf[0][tid] = v;
-        __syncthreads();
-        for (int d = 1; d < AM_SCAN_THREADS; d <<= 1) {
-            uint32_t x = buf[cur][tid];
-            if (tid >= d) x += buf[cur][tid - d];
-            buf[cur ^ 1][tid] = x;
-            cur ^= 1;
-            __syncthreads();
-        }
-        const uint32_t incl = buf[cur][tid];
-        const uint32_t base = carry;
-        if (i < n) off[i] = base + incl - v;
-        __syncthreads();
-        if (tid == AM_SCAN_THREADS - 1) carry = base + incl;
-        __syncthreads();
+    // one workgroup: thread t owns the contiguous slice [t*per, (t+1)*per); slice sums are scanned
+    // with wave shuffles + one LDS hop; then every thread writes its slice's exclusive offsets
+    __shared__ uint32_t ws[AM_SCAN_THREADS / AM_WAVE];
+    const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
+    const uint32_t per = (n + AM_SCAN_THREADS - 1) / AM_SCAN_THREADS;
+    const uint32_t lo = (uint32_t)tid * per;
+    const uint32_t hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += cnt[i];
+    uint32_t incl = sum;
+    for (int d = 1; d < AM_WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
+        if (lane >= d) incl += up;
     }
-    if (tid == 0) off[n] = carry;
+    if (lane == AM_WAVE - 1) ws[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum, total = 0;
+    for (int k = 0; k < AM_SCAN_THREADS / AM_WAVE; ++k) { if (k < wv) base += ws[k]; total += ws[k]; }
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = cnt[i]; off[i] = base; base += v; }
+    if (tid == 0) off[n] = total;
 }
 
 hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hipStream_t s)
@@ -655,7 +649,7 @@ __global__ void __launch_bounds__(256)
 am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ valid,
                 const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
                 const uint32_t *__restrict__ tgt, uint32_t M, uint32_t emit_max, uint32_t own_lo,
-                uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *scalars)
+                uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *scalars, int want_resume)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = g < M;
@@ -667,8 +661,10 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
         const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
         emit[g] = em ? 1 : 0;
     }
-    // where the scan resumes after everything visited here: the largest target.  Same-address
-    // atomics serialise (~11 ns each), so reduce per workgroup first: one atomic per 256 nodes.
+    // where the scan resumes after everything visited here: the largest target (only needed when
+    // the stream continues).  Same-address atomics serialise (~11 ns each), so reduce per
+    // workgroup first: one atomic per 256 nodes.
+    if (!want_resume) return;
     __shared__ uint32_t wmax[256 / AM_WAVE];
     uint32_t t = vis ? tgt[g] : 0u;
     for (int o = 32; o >= 1; o >>= 1) {
@@ -706,11 +702,11 @@ hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *scalars,
-                                hipStream_t s)
+                                int want_resume, hipStream_t s)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, 256)), dim3(256), 0, s, visited, valid, pos, e, tgt, M,
-                       emit_max, own_lo, own_hi, emit, scalars);
+                       emit_max, own_lo, own_hi, emit, scalars, want_resume);
     return hipGetLastError();
 }
 
