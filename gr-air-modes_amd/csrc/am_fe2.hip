@@ -35,9 +35,6 @@
 // LDS padding: 4 spare words per 32 keep 16-byte alignment for ds_read_b128 while spreading
 // lanes that walk 32-float runs over all banks.
 __device__ __forceinline__ int fe2_pidx(int i) { return i + ((i >> 5) << 2); }
-// per-chip LDS arrays: one spare word per 48-chip block, so that the lanes that walk one block each
-// (stride 48 chips) fall on different banks
-__host__ __device__ constexpr int fe2_cq(int q) { return q + (q + AM_CHIPS_AVG - 1) / AM_CHIPS_AVG; }
 __host__ __device__ constexpr int fe2_padn(int n) { return n + ((n >> 5) << 2) + 8; }
 
 template <int N, bool ALIGNED>
@@ -152,11 +149,10 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     HIP_DYNAMIC_SHARED(float, smem);
     float *X = smem;                                        // [LHP + T + RH] padded
     float *TOT = X + fe2_padn(LHP + T + RH);                // chip totals, left->right   [NCH]
-    constexpr int NCHP = fe2_cq(NCH) + 1;                   // padded length of the per-chip arrays
-    float *RTOT = TOT + NCHP;                               // chip totals, right->left
-    float *PT = RTOT + NCHP;
-    float *ST = PT + NCHP;
-    uint32_t *BM = reinterpret_cast<uint32_t *>(ST + NCHP); // candidate bitmap [NWORDS]
+    float *RTOT = TOT + NCH;                                // chip totals, right->left   [NCH]
+    float *PT = RTOT + NCH;
+    float *ST = PT + NCH;
+    uint32_t *BM = reinterpret_cast<uint32_t *>(ST + NCH);  // candidate bitmap [NWORDS]
     uint32_t *WS = BM + NWORDS;                             // wave sums for the block scan
     uint32_t *RUNANY = WS + 16 + 3 * (NWORDS + 2);          // per thread: does its run hold a candidate
 
@@ -212,15 +208,8 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
                         m0 = rr + ii;
                     }
                     const int li = LHP - LH + 2 * p;
-                    if constexpr (((LHP - LH) & 1) == 0) {
-                        // li is even: the pair is contiguous and 8-byte aligned in the padded layout
-                        float2 mm;
-                        mm.x = m0; mm.y = m1;
-                        *reinterpret_cast<float2 *>(&X[fe2_pidx(li)]) = mm;
-                    } else {
-                        X[fe2_pidx(li)] = m0;
-                        if (2 * p + 1 < W) X[fe2_pidx(li + 1)] = m1;
-                    }
+                    X[fe2_pidx(li)] = m0;
+                    if (2 * p + 1 < W) X[fe2_pidx(li + 1)] = m1;
                 }
             }
         } else {
@@ -249,7 +238,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             }
         }
         for (int w = tid; w < NWORDS; w += FE2_NT) BM[w] = 0u;
-        if (tid == 0) PT[fe2_cq(FE2_LH_CHIPS + FE2_NT * CPT)] = 0.0f;  // first chip after the tile opens a block
+        if (tid == 0) PT[FE2_LH_CHIPS + FE2_NT * CPT] = 0.0f;  // first chip after the tile opens a block
     }
     __syncthreads();
 
@@ -309,8 +298,8 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         for (int i = 0; i < SPC; ++i) f = f + bbv[k * SPC + i];
 #pragma unroll
         for (int i = SPC - 1; i >= 0; --i) b = b + bbv[k * SPC + i];
-        TOT[fe2_cq(c0 + k)] = f;
-        RTOT[fe2_cq(c0 + k)] = b;
+        TOT[c0 + k] = f;
+        RTOT[c0 + k] = b;
     }
     if (has_halo) {
         float f = 0.0f, b = 0.0f;
@@ -318,8 +307,8 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         for (int i = 0; i < SPC; ++i) f = f + hb[i];
 #pragma unroll
         for (int i = SPC - 1; i >= 0; --i) b = b + hb[i];
-        TOT[fe2_cq(hq)] = f;
-        RTOT[fe2_cq(hq)] = b;
+        TOT[hq] = f;
+        RTOT[hq] = b;
     }
     __syncthreads();                                       // everyone has read its |.|^2
     fe2_lds_store<R, RUN_AL>(X, run_base, bbv);
@@ -332,18 +321,18 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         const int qb = 1 + AM_CHIPS_AVG * (idx >> 1);
         float t[AM_CHIPS_AVG];
 #pragma unroll
-        for (int j = 0; j < AM_CHIPS_AVG; ++j) t[j] = TOT[fe2_cq(qb + j)];
+        for (int j = 0; j < AM_CHIPS_AVG; ++j) t[j] = TOT[qb + j];
         float acc = 0.0f;
         if (idx & 1) {
 #pragma unroll
             for (int j = AM_CHIPS_AVG - 1; j >= 0; --j) { const float v = t[j]; t[j] = acc; acc = acc + v; }
 #pragma unroll
-            for (int j = 0; j < AM_CHIPS_AVG; ++j) ST[fe2_cq(qb + j)] = t[j];
+            for (int j = 0; j < AM_CHIPS_AVG; ++j) ST[qb + j] = t[j];
         } else {
 #pragma unroll
             for (int j = 0; j < AM_CHIPS_AVG; ++j) { const float v = t[j]; t[j] = acc; acc = acc + v; }
 #pragma unroll
-            for (int j = 0; j < AM_CHIPS_AVG; ++j) PT[fe2_cq(qb + j)] = t[j];
+            for (int j = 0; j < AM_CHIPS_AVG; ++j) PT[qb + j] = t[j];
         }
     }
     __syncthreads();
@@ -368,9 +357,9 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
 #pragma unroll
             for (int i = SPC - 1; i >= 0; --i) { acc = acc + pv[i]; scv[i] = acc; }
         }
-        const float pt = PT[fe2_cq(q)];
-        const float st_a = ST[fe2_cq(q - AM_CHIPS_AVG)];
-        const float suf_last = RTOT[fe2_cq(q - AM_CHIPS_AVG + 1)] + ST[fe2_cq(q - AM_CHIPS_AVG + 1)];
+        const float pt = PT[q];
+        const float st_a = ST[q - AM_CHIPS_AVG];
+        const float suf_last = RTOT[q - AM_CHIPS_AVG + 1] + ST[q - AM_CHIPS_AVG + 1];
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < SPC; ++i) {
@@ -602,17 +591,17 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             float pc = 0.0f;
 #pragma unroll
             for (int i = 0; i < SPC; ++i) pc = (i <= io) ? (pc + t[i]) : pc;
-            const float PRE = PT[fe2_cq(q)] + pc;
+            const float PRE = PT[q] + pc;
             float ssum;
             if (io == SPC - 1) {
-                ssum = (jb == AM_CHIPS_AVG - 1) ? PRE : ((RTOT[fe2_cq(q - AM_CHIPS_AVG + 1)] + ST[fe2_cq(q - AM_CHIPS_AVG + 1)]) + PRE);
+                ssum = (jb == AM_CHIPS_AVG - 1) ? PRE : ((RTOT[q - AM_CHIPS_AVG + 1] + ST[q - AM_CHIPS_AVG + 1]) + PRE);
             } else {
                 float u[SPC];
                 fe2_lds_load<SPC, false>(X, chip_base(q - AM_CHIPS_AVG), u);
                 float sc = 0.0f;
 #pragma unroll
                 for (int i = SPC - 1; i >= 0; --i) sc = (i > io) ? (sc + u[i]) : sc;
-                ssum = (sc + ST[fe2_cq(q - AM_CHIPS_AVG)]) + PRE;
+                ssum = (sc + ST[q - AM_CHIPS_AVG]) + PRE;
             }
             av = ssum * a.sL;
             if ((long long)le >= end_li) av = 0.0f;                // beyond the end of the stream
@@ -658,7 +647,7 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     constexpr int RH = FE2_RH_CHIPS * SPC;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;
     constexpr int NWORDS = (T + 31) / 32;
-    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * (fe2_cq(NCH) + 1) + NWORDS + 16 + 16 + 3 * (NWORDS + 2) + FE2_NT) *
+    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + 3 * (NWORDS + 2) + FE2_NT) *
                        sizeof(float);
     am_fe2_args a = a_in;
     size_t lds_req = lds;
