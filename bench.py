@@ -115,6 +115,18 @@ def main():
         value = total_samples / dt
         fe_avg_ms = float(np.mean(fe_ms)) if fe_ms else 0.0
         achieved = (8.0 * (n + (0 if world == 1 else 0))) / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
+        fused = spc in (1, 2, 4, 5, 8, 10, 16, 20, 32)
+        kernel_name = ("am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc) if fused \
+            else "am_k_frontend"
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, "profiles", "current_traffic.json")
+        if world == 1 and os.path.exists(tj):
+            with open(tj) as f:
+                t = json.load(f)
+            if t.get("workload") == args.workload and args.seconds is None:
+                traffic = t["traffic_bytes"]
+                traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
         res = {
             "metric": "complex samples/sec demodulated (IQ -> Mode-S packet list)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -127,9 +139,10 @@ def main():
                                       "" if world == 1 else ", one stream time-sharded over %d GPUs" % world),
                        "rate_sps": rate, "samples_per_gpu_per_step": n,
                        "parallelism": "single GPU" if world == 1 else "time-chunk shards x%d, RCCL halo + candidate all-gather" % world},
-            "roofline": {"bound": "hbm", "kernel": "am_k_frontend", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_ms": fe_avg_ms, "algorithmic_bytes_per_launch": 8 * n},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "kernel_ms": fe_avg_ms,
+                         "algorithmic_bytes_per_launch": 8 * n},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle
