@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--workload", default="64msps", choices=["64msps", "2msps", "20msps"])
     ap.add_argument("--seconds", type=float, default=None, help="signal seconds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,7 +68,7 @@ def main():
     iq, truth = synth.synth_capture(rate, n, lam, seed + rank)
     ctx = _capi.Context(rate, 7.0, True, device=local)
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
         torch.cuda.synchronize()
 

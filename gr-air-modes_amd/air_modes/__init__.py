@@ -14,7 +14,7 @@ a block does, and raises if the library or a HIP device is missing (no CPU fallb
 from .msg_queue import message, msg_queue
 from .blocks import preamble, slicer
 from .rx_path import rx_path
-from ._capi import AirModesError, Context, Library, PACKET_DTYPE, TAG_DTYPE, CAND_DTYPE
+from ._capi import AirModesError, Context, Library, PACKET_DTYPE, TAG_DTYPE, EXIT_DTYPE, shard_entries
 
 __all__ = ["message", "msg_queue", "preamble", "slicer", "rx_path", "AirModesError", "Context",
-           "Library", "PACKET_DTYPE", "TAG_DTYPE", "CAND_DTYPE"]
+           "Library", "PACKET_DTYPE", "TAG_DTYPE", "EXIT_DTYPE", "shard_entries"]

@@ -24,7 +24,8 @@ PACKET_DTYPE = np.dtype([
     ("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8")])
 TAG_DTYPE = np.dtype([("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8"),
                       ("inavg", "<f4"), ("how_late", "<u4")])
-CAND_DTYPE = np.dtype([("pos", "<u8"), ("shift_valid", "<u4"), ("inavg", "<f4")])
+EXIT_DTYPE = np.dtype([("pos", "<u8"), ("exit", "<u8")])
+CAND_DTYPE = EXIT_DTYPE   # (name kept for older imports)
 assert PACKET_DTYPE.itemsize == 56 and TAG_DTYPE.itemsize == 32 and CAND_DTYPE.itemsize == 16
 
 
@@ -93,7 +94,8 @@ class Library(object):
         L.am_format_message.argtypes = [vp, ci, C.c_char_p, C.c_size_t]
         L.am_shard_halo.argtypes = [vp, pu64, pu64]
         L.am_shard_scan.argtypes = [vp, vp, u64, u64, u64, u32, vp, u64, pu64]
-        L.am_shard_resolve.argtypes = [vp, vp, u64, u32, vp, u64, pu64]
+        L.am_shard_entry.argtypes = [vp, vp, vp, u32, vp]
+        L.am_shard_resolve.argtypes = [vp, u64, vp, u64, pu64]
         L.am_last_error.restype = C.c_char_p
         L.am_last_error.argtypes = [vp]
         L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
@@ -251,35 +253,47 @@ class Context(object):
         self._chk(self.lib.L.am_shard_halo(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
-    def shard_scan(self, iq_with_halo, abs_start, abs_end, total_n, device_ptr=None, n_with_halo=None):
-        """Candidate records of chunk [abs_start, abs_end); iq_with_halo covers
-        [abs_start - left, abs_end + right) clipped to [0, total_n)."""
+    def shard_scan(self, iq_with_halo, abs_start, abs_end, total_n, device_ptr=None):
+        """Scan chunk [abs_start, abs_end) of a stream of total_n samples; iq_with_halo covers
+        [abs_start - left, abs_end + right) clipped to the stream.  Returns the chunk's exit table."""
         flags = 0
         if device_ptr is not None:
             ptr, flags = int(device_ptr), AM_F_DEVICE_IN
         else:
             f = _iq_f32(iq_with_halo)
             ptr = f.ctypes.data if f.size else None
-        cap = max(1024, (abs_end - abs_start) // 8)
+        cap = 1024
         while True:
-            recs = np.zeros(cap, CAND_DTYPE)
+            tab = np.zeros(cap, EXIT_DTYPE)
             got = C.c_uint64(0)
-            rc = self.lib.L.am_shard_scan(self._h, ptr, abs_start, abs_end, total_n, flags, recs.ctypes.data, cap,
+            rc = self.lib.L.am_shard_scan(self._h, ptr, abs_start, abs_end, total_n, flags, tab.ctypes.data, cap,
                                           C.byref(got))
             if rc == AM_ECAPACITY:
                 cap = int(got.value)
                 continue
             self._chk(rc)
-            return recs[:got.value]
+            return tab[:got.value]
 
-    def shard_resolve(self, all_recs, capacity=None):
-        r = np.ascontiguousarray(all_recs, CAND_DTYPE)
-        cap = int(capacity) if capacity is not None else max(64, r.size)
+    def shard_resolve(self, cur_in, capacity=None):
+        cap = int(capacity) if capacity is not None else 4096
         out = np.zeros(cap, PACKET_DTYPE)
         got = C.c_uint64(0)
-        rc = self.lib.L.am_shard_resolve(self._h, r.ctypes.data if r.size else None, r.size, 0, out.ctypes.data, cap,
-                                         C.byref(got))
+        rc = self.lib.L.am_shard_resolve(self._h, int(cur_in), out.ctypes.data, cap, C.byref(got))
         if rc == AM_ECAPACITY:
             return self._fetch(int(got.value))
         self._chk(rc)
         return out[:got.value]
+
+
+def shard_entries(lib, tables, starts):
+    """am_shard_entry: scan entry position of every chunk from the chunks' exit tables."""
+    n = len(tables)
+    tabs = [np.ascontiguousarray(t, EXIT_DTYPE) for t in tables]
+    ptrs = (C.c_void_p * n)(*[t.ctypes.data if t.size else None for t in tabs])
+    counts = np.array([t.size for t in tabs], np.uint64)
+    st = np.array(starts, np.uint64)
+    entry = np.zeros(n, np.uint64)
+    rc = lib.L.am_shard_entry(ptrs, counts.ctypes.data, st.ctypes.data, n, entry.ctypes.data)
+    if rc != AM_OK:
+        raise AirModesError(rc, "am_shard_entry")
+    return entry

@@ -2,21 +2,23 @@
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on the GPU box,
 "gloo" in the CPU tests).  A stream of world*n samples is cut into `world` contiguous time
-chunks.  Per step:
+chunks.  The reference's preamble scan is sequential, but the only state that crosses a chunk
+boundary is the position at which the scan resumes, and that can reach at most 241*spc
+samples into the next chunk.  Per step:
 
   1. halo exchange   every rank publishes [its last `left` samples | its first `right` samples]
                      in ONE all_gather of fixed-size slabs (KB-scale: latency bound, far below
                      the 153 GB/s per xGMI link) and keeps its two neighbours' slabs;
-  2. local scan      am_shard_scan: front end + detection + refinement of the chunk's own
-                     positions -> candidate records (16 bytes each);
-  3. record exchange all_gather of the record counts, then of the padded record arrays;
-  4. resolve         am_shard_resolve on the concatenated list: the greedy chain of the
-                     reference's sequential scan (lib/preamble_impl.cc:172,209,237) is resolved
-                     identically on every rank; each rank extracts + slices the hits whose
-                     first-stage position lies in its chunk.
+  2. local scan      am_shard_scan: front end, detection, refinement and the jump tables of the
+                     chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan
+                     could enter the chunk at (those in its first 241*spc samples), where the
+                     scan would leave the chunk;
+  3. table exchange  one all_gather of the fixed-size exit tables (16 bytes per entry, KBs);
+                     every rank composes them (am_shard_entry) -> scan entry of its own chunk;
+  4. resolve         am_shard_resolve(entry): mark the chain from that entry, extract + slice.
 
 Packets of all ranks, concatenated in rank order, equal the single-GPU (and the reference's)
-packet list for the whole stream.
+packet list for the whole stream; the per-rank work does not grow with the number of ranks.
 """
 import ctypes as C
 
@@ -37,6 +39,8 @@ class ShardedReceiver(object):
         if self.world > 1 and self.n < max(self.left, self.right):
             raise ValueError("chunk shorter than the halo (%d samples)" % max(self.left, self.right))
         self.a0, self.a1 = self.rank * self.n, (self.rank + 1) * self.n
+        spc = max(int(ctx.get_rate() / 2e6), 1)
+        self.tab_cap = 241 * spc + 4                      # a lead-in cannot hold more candidates than positions
         self._buf = None
 
     def _alloc(self, like):
@@ -46,10 +50,10 @@ class ShardedReceiver(object):
         self._buf = t.zeros((hl + n + hr) * 2, dtype=t.float32, device=dev)
         self._slab = t.empty((hl + hr) * 2, dtype=t.float32, device=dev)
         self._slabs = [t.empty_like(self._slab) for _ in range(self.world)]
-        self._cap = max(4096, n // 8)
-        self._recs = t.zeros(self._cap * 2, dtype=t.int64, device=dev)        # am_cand = 16 bytes
-        self._cnt = t.zeros(1, dtype=t.int64, device=dev)
-        self._cnts = [t.zeros(1, dtype=t.int64, device=dev) for _ in range(self.world)]
+        # exit table message: [count, pos0, exit0, pos1, exit1, ...] as int64
+        self._msg = t.zeros(1 + 2 * self.tab_cap, dtype=t.int64, device=dev)
+        self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
+        self._host_tab = np.zeros(self.tab_cap, _capi.EXIT_DTYPE)
 
     def step(self, own):
         """own: this rank's chunk, interleaved float32 I,Q (2*n values), torch tensor on the
@@ -74,44 +78,23 @@ class ShardedReceiver(object):
             t.cuda.synchronize()
         lo = max(0, self.a0 - hl)
         off = (hl - (self.a0 - lo)) * 2                      # floats to skip at the stream start
-        flags_in = _capi.AM_F_DEVICE_IN if on_gpu else 0
         L = self.ctx.lib.L
-        while True:
-            got = C.c_uint64(0)
-            rc = L.am_shard_scan(self.ctx._h, buf.data_ptr() + off * 4, self.a0, self.a1, self.total,
-                                 flags_in | (_capi.AM_F_DEVICE_OUT if on_gpu else 0),
-                                 self._recs.data_ptr(), self._cap, C.byref(got))
-            if rc == _capi.AM_ECAPACITY:
-                self._cap = int(got.value) + 1024
-                self._recs = t.zeros(self._cap * 2, dtype=t.int64, device=own.device)
-                continue
-            self.ctx._chk(rc)
-            break
+        got = C.c_uint64(0)
+        rc = L.am_shard_scan(self.ctx._h, buf.data_ptr() + off * 4, self.a0, self.a1, self.total,
+                             _capi.AM_F_DEVICE_IN if on_gpu else 0, self._host_tab.ctypes.data, self.tab_cap,
+                             C.byref(got))
+        self.ctx._chk(rc)
         m = int(got.value)
         if world > 1:
-            self._cnt[0] = m
-            dist.all_gather(self._cnts, self._cnt, group=self.group)
-            ms = [int(c.item()) for c in self._cnts]
-            mmax = max(max(ms), 1)
-            if mmax > self._cap:
-                grown = t.zeros(mmax * 2, dtype=t.int64, device=own.device)
-                grown[:self._cap * 2] = self._recs
-                self._recs, self._cap = grown, mmax
-            parts = [t.empty(mmax * 2, dtype=t.int64, device=own.device) for _ in range(world)]
-            dist.all_gather(parts, self._recs[:mmax * 2].contiguous(), group=self.group)
-            allr = t.cat([parts[r][:ms[r] * 2] for r in range(world)]).contiguous()
-            mall = sum(ms)
+            msg = np.zeros(1 + 2 * self.tab_cap, np.int64)
+            msg[0] = m
+            msg[1:1 + 2 * m] = self._host_tab[:m].view(np.int64)
+            self._msg.copy_(t.from_numpy(msg))
+            dist.all_gather(self._msgs, self._msg, group=self.group)
+            allm = t.stack(self._msgs).cpu().numpy()
+            tables = [allm[r, 1:1 + 2 * int(allm[r, 0])].copy().view(_capi.EXIT_DTYPE) for r in range(world)]
+            entry = _capi.shard_entries(self.ctx.lib, tables, [r * n for r in range(world)])
+            cur_in = int(entry[rank])
         else:
-            allr, mall = self._recs, m
-        if on_gpu:
-            t.cuda.synchronize()
-        cap = max(64, n // 2000 + 64)
-        while True:
-            out = np.zeros(cap, _capi.PACKET_DTYPE)
-            g2 = C.c_uint64(0)
-            rc = L.am_shard_resolve(self.ctx._h, allr.data_ptr() if mall else None, mall, flags_in,
-                                    out.ctypes.data, cap, C.byref(g2))
-            if rc == _capi.AM_ECAPACITY:
-                return self.ctx._fetch(int(g2.value))
-            self.ctx._chk(rc)
-            return out[:g2.value]
+            cur_in = 0
+        return self.ctx.shard_resolve(cur_in, capacity=max(64, n // 2000 + 64))

@@ -53,15 +53,19 @@ struct am_ctx {
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, seg_e, seg_inavg, seg_valid, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         visited, emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
-        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs;
+        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab;
 
     // results of the last scan
     std::vector<am_packet> h_packets;   // every sliced burst, reserved[0] = accepted
     std::vector<am_tag> h_tags;
     std::vector<float> h_bursts;
     std::vector<am_packet> pending;     // accepted packets not yet handed to the caller
+    std::vector<am_shard_exit> h_exit;  // exit table of the resident chunk
     uint64_t last_tags = 0;
     uint32_t last_M = 0;
+    uint32_t chain_M = 0;               // records the jump tables were built for
+    int chain_levels = 0;
+    size_t chain_stride = 0;
 
     // time-sharded mode: the chunk whose bb/avg are resident
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
@@ -309,42 +313,57 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                       (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull));
 }
 
-// Greedy chain over the M flat records + extraction + slicing.  Only hits whose shifted start
-// e lies in [own_lo, own_hi] and is <= emit_max are extracted (bb/avg must cover them).
-// cur0 = position at which the scan starts.  Fills h_packets / h_tags (+ h_bursts).
-int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M, uint32_t cur0,
-                        uint32_t emit_max, uint64_t base_abs, bool keep_bursts, uint32_t *final_cur, uint32_t max_hits,
-                        uint32_t own_lo = 0, uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
+// Greedy chain, part 1: successor pointers and radix-16 jump tables over the M flat records.
+const int AM_CHAIN_RADIX = 16;
+int chain_build(am_ctx *c, uint32_t M)
 {
+    c->chain_M = M;
+    c->chain_levels = 0;
+    c->chain_stride = (size_t)M + 1;
+    if (M == 0) return AM_OK;
+    int levels = 1;
+    {
+        uint64_t reach = AM_CHAIN_RADIX;
+        while (reach < (uint64_t)M + 1) { reach *= AM_CHAIN_RADIX; levels++; }
+    }
+    c->chain_levels = levels;
+    const size_t stride = c->chain_stride;
+    ENSURE(c, c->visited, stride);
+    ENSURE(c, c->emit, stride);
+    ENSURE(c, c->jump, (size_t)(levels + 1) * stride * sizeof(uint32_t));
+    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    uint32_t *jump = (uint32_t *)c->jump.p;
+    HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, 0, jump, nullptr, c->stream));
+    for (int k = 0; k < levels; k++)
+        HIPCHK(c, am_launch_chain_double(jump + (size_t)k * stride, jump + (size_t)(k + 1) * stride, M,
+                                         AM_CHAIN_RADIX, c->stream));
+    return AM_OK;
+}
+
+// Greedy chain, part 2: mark the candidates the scan visits when it starts at cur0, then extract
+// and slice the hits (e <= emit_max, first-stage position in [own_lo, own_hi)).
+// Fills h_packets / h_tags (+ h_bursts).
+int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, uint64_t base_abs,
+                 bool keep_bursts, uint32_t *final_cur, uint32_t max_hits, uint32_t own_lo = 0,
+                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
+{
+    const uint32_t M = c->chain_M;
     c->h_packets.clear();
     c->h_tags.clear();
     c->h_bursts.clear();
     c->last_M = M;
     *final_cur = cur0;
     if (M == 0) return AM_OK;
-    // radix-16 pointer jumping: table k+1 = table k applied 16 times
-    const int RADIX = 16;
-    int levels = 1;
-    {
-        uint64_t reach = RADIX;
-        while (reach < (uint64_t)M + 1) { reach *= RADIX; levels++; }
-    }
-    const size_t stride = (size_t)M + 1;
-    ENSURE(c, c->visited, stride);
-    ENSURE(c, c->emit, stride);
-    ENSURE(c, c->jump, (size_t)(levels + 1) * stride * sizeof(uint32_t));
-    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    const int levels = c->chain_levels;
+    const size_t stride = c->chain_stride;
     uint32_t *jump = (uint32_t *)c->jump.p;
     HIPCHK(c, hipMemsetAsync(c->visited.p, 0, stride, c->stream));
     uint32_t init[2] = {cur0, 0};
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, cur0, jump,
-                                   (uint8_t *)c->visited.p, c->stream));
-    for (int k = 0; k < levels; k++)
-        HIPCHK(c, am_launch_chain_double(jump + (size_t)k * stride, jump + (size_t)(k + 1) * stride, M, RADIX,
-                                         c->stream));
+    HIPCHK(c, am_launch_chain_root((uint32_t *)c->pos.p, M, cur0, (uint8_t *)c->visited.p, c->stream));
     for (int k = levels; k >= 0; k--)
-        HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, RADIX, c->stream));
+        HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, AM_CHAIN_RADIX,
+                                       c->stream));
     HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
                                    (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
                                    (uint8_t *)c->emit.p, (uint32_t *)c->scalars.p,
@@ -393,6 +412,19 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *avg, uint32_t M
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return AM_OK;
+}
+
+int run_chain_and_slice(am_ctx *c, const float *bb, const float *, uint32_t M, uint32_t cur0, uint32_t emit_max,
+                        uint64_t base_abs, bool keep_bursts, uint32_t *final_cur, uint32_t max_hits)
+{
+    c->h_packets.clear();
+    c->h_tags.clear();
+    c->h_bursts.clear();
+    c->last_M = M;
+    *final_cur = cur0;
+    int rc = chain_build(c, M);
+    if (rc != AM_OK || M == 0) return rc;
+    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits);
 }
 
 void collect_accepted(am_ctx *c)
@@ -510,7 +542,7 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs};
+                     &c->recs, &c->exit_tab};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -814,10 +846,10 @@ int am_shard_halo(const am_ctx *c, uint64_t *left, uint64_t *right)
 }
 
 int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
-                  uint32_t flags, am_cand *recs, uint64_t cap, uint64_t *n_recs)
+                  uint32_t flags, am_shard_exit *table, uint64_t cap, uint64_t *n_table)
 {
     if (!c) return AM_EINVAL;
-    if (n_recs) *n_recs = 0;
+    if (n_table) *n_table = 0;
     if (abs_end < abs_start || abs_end > total_n) return fail(c, AM_EINVAL, "bad chunk bounds");
     HIPCHK(c, hipSetDevice(c->device));
     c->shard_ready = false;
@@ -866,75 +898,75 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     c->shard_start = abs_start;
     c->shard_end = abs_end;
     c->shard_total = total_n;
-    c->shard_ready = true;
-    if (n_recs) *n_recs = M;
-    if (M > cap) return fail(c, AM_ECAPACITY, "candidate array too small");
-    if (M) {
-        if (!recs) return fail(c, AM_EINVAL, "null recs");
-        am_cand *drecs = recs;
-        if (!(flags & AM_F_DEVICE_OUT)) {
-            ENSURE(c, c->recs, (size_t)M * sizeof(am_cand));
-            drecs = (am_cand *)c->recs.p;
-        }
-        HIPCHK(c, am_launch_cand_export((uint32_t *)c->pos.p, (uint32_t *)c->e.p, (const float *)c->inavg.p,
-                                        (uint8_t *)c->valid.p, M, out_abs0, drecs, c->stream));
-        if (!(flags & AM_F_DEVICE_OUT))
-            HIPCHK(c, hipMemcpyAsync(recs, drecs, (size_t)M * sizeof(am_cand), hipMemcpyDeviceToHost, c->stream));
+    int rc = chain_build(c, M);
+    if (rc != AM_OK) return rc;
+    // exit table for the candidates the scan can enter at: those in the first 241*spc samples of
+    // the chunk (the farthest a predecessor's skip can reach) and the first one after them
+    const uint64_t lead = (uint64_t)(AM_BURST + 1) * S + 1;
+    const uint64_t lead_end = abs_start + lead;                 // absolute, exclusive
+    const uint32_t n_dev = (uint32_t)std::min<uint64_t>(M, lead + 1);
+    uint64_t nt = 0;
+    if (n_dev) {
+        ENSURE(c, c->exit_tab, (size_t)n_dev * sizeof(am_shard_exit));
+        HIPCHK(c, am_launch_chain_exit((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, (uint32_t *)c->jump.p,
+                                       c->chain_stride, c->chain_levels, AM_CHAIN_RADIX, M, n_dev, out_abs0,
+                                       (am_shard_exit *)c->exit_tab.p, c->stream));
+        c->h_exit.resize(n_dev);
+        HIPCHK(c, hipMemcpyAsync(c->h_exit.data(), c->exit_tab.p, (size_t)n_dev * sizeof(am_shard_exit),
+                                 hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
     (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
+    for (uint32_t i = 0; i < n_dev; i++) {
+        nt = i + 1;
+        if (c->h_exit[i].pos >= lead_end) break;                // first candidate past the lead-in: last entry
+    }
+    c->shard_ready = true;
+    if (n_table) *n_table = nt;
+    if (nt > cap) return fail(c, AM_ECAPACITY, "exit table too small");
+    if (nt) {
+        if (!table) return fail(c, AM_EINVAL, "null table");
+        memcpy(table, c->h_exit.data(), (size_t)nt * sizeof(am_shard_exit));
+    }
     return AM_OK;
 }
 
-int am_shard_resolve(am_ctx *c, const am_cand *all_recs, uint64_t n_all, uint32_t flags, am_packet *out,
-                     uint64_t cap, uint64_t *n_out)
+int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, const uint64_t *starts,
+                   uint32_t nranks, uint64_t *entry)
+{
+    if (!entry || (nranks && (!tables || !counts || !starts))) return AM_EINVAL;
+    uint64_t cur = 0;                                           // the scan starts at sample 0
+    for (uint32_t r = 0; r < nranks; r++) {
+        entry[r] = cur;
+        const am_shard_exit *t = tables[r];
+        const uint64_t n = counts[r];
+        // first candidate of chunk r at or after cur; the table covers every position cur can take
+        uint64_t i = 0;
+        while (i < n && t[i].pos < cur) i++;
+        if (i < n) cur = t[i].exit > cur ? t[i].exit : cur;     // no candidate left: the scan passes through
+    }
+    (void)starts;
+    return AM_OK;
+}
+
+int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out)
 {
     if (!c) return AM_EINVAL;
     if (n_out) *n_out = 0;
     if (!c->shard_ready) return fail(c, AM_EINVAL, "am_shard_scan has not been called");
-    if (n_all > 0x7FFFFFF0u) return fail(c, AM_EINVAL, "too many candidates");
     HIPCHK(c, hipSetDevice(c->device));
     c->pending.clear();
     c->last_tags = 0;
-    if (n_all == 0) return AM_OK;
-    if (!all_recs) return fail(c, AM_EINVAL, "null recs");
-    const uint32_t M = (uint32_t)n_all;
-    const am_cand *drecs = all_recs;
-    if (!(flags & AM_F_DEVICE_IN)) {
-        ENSURE(c, c->recs, (size_t)M * sizeof(am_cand));
-        HIPCHK(c, hipMemcpyAsync(c->recs.p, all_recs, (size_t)M * sizeof(am_cand), hipMemcpyHostToDevice,
-                                 c->stream));
-        drecs = (const am_cand *)c->recs.p;
-    }
-    // Re-base the global list on its first candidate so that positions fit in 32 bits, resolve
-    // the greedy chain over ALL candidates (identically on every rank), and extract / slice
-    // only the hits whose first-stage position lies in this rank's chunk.
-    am_cand first;
-    HIPCHK(c, hipMemcpyAsync(&first, drecs, sizeof(first), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const uint64_t gbase = first.pos;
-    if (c->shard_total - gbase > 0xFFFF0000ull) return fail(c, AM_EINVAL, "stream span exceeds 2^32 samples");
     uint64_t em = 0;
-    if (!flush_limits(c->shard_total, c->spc, &em) || em < gbase) return AM_OK;
-    if (c->shard_end <= gbase) return AM_OK;                  // nothing of this chunk in the list
-    ENSURE(c, c->pos, ((size_t)M + 1) * sizeof(uint32_t));
-    ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
-    ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
-    ENSURE(c, c->valid, (size_t)M + 1);
-    ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
-    HIPCHK(c, am_launch_cand_import(drecs, M, gbase, c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->e.p,
-                                    (uint32_t *)c->tgt.p, (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream));
-    const uint32_t own_lo = c->shard_start > gbase ? (uint32_t)(c->shard_start - gbase) : 0u;
-    const uint32_t own_hi = (uint32_t)(c->shard_end - gbase);
-    const long long e_off = (long long)gbase - (long long)c->shard_base;
+    if (c->chain_M == 0 || !flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base) return AM_OK;
+    const uint32_t cur0 = cur_in > c->shard_base ? (uint32_t)std::min<uint64_t>(cur_in - c->shard_base, 0xFFFFFFF0u) : 0u;
+    const uint32_t emax = (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
     uint32_t fin = 0;
-    int rc = run_chain_and_slice(c, (const float *)c->bb.p, nullptr, M, 0u,
-                                 (uint32_t)(em - gbase), gbase, false, &fin,
-                                 (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
-                                            ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2),
-                                 own_lo, own_hi, e_off);
+    int rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin,
+                          (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
+                                     ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2));
     if (rc != AM_OK) return rc;
     c->last_tags = c->h_packets.size();
     collect_accepted(c);

@@ -114,13 +114,10 @@ hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, co
 hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
                                   uint32_t *out_idx, hipStream_t s);
-/* records from an exchanged candidate list (time-sharded mode) */
-hipError_t am_launch_cand_import(const am_cand *recs, uint32_t M, uint64_t base_abs, int spc,
-                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
-                                 hipStream_t s);
-hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const float *inavg,
-                                 const uint8_t *valid, uint32_t M, uint64_t base_abs, am_cand *recs,
-                                 hipStream_t s);
+hipError_t am_launch_chain_root(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited, hipStream_t s);
+hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
+                                int levels, int radix, uint32_t M, uint32_t n, uint64_t base_abs,
+                                am_shard_exit *table, hipStream_t s);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
 /* n_ptr: device-side number of hits; n_max: upper bound used for the grid */

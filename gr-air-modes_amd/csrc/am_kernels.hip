@@ -613,10 +613,46 @@ am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ t
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < M) jump0[g] = am_lower_bound(pos, g + 1, M, tgt[g]);
     if (g == M) jump0[M] = M;
-    if (g == 0) {
+    if (g == 0 && visited) {
         const uint32_t root = am_lower_bound(pos, 0, M, cur0);
         if (root < M) visited[root] = 1;
     }
+}
+
+// mark the first candidate the scan reaches when it (re)starts at position cur0
+__global__ void am_k_chain_root(const uint32_t *__restrict__ pos, uint32_t M, uint32_t cur0,
+                                uint8_t *__restrict__ visited)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t root = am_lower_bound(pos, 0, M, cur0);
+        if (root < M) visited[root] = 1;
+    }
+}
+
+// Exit table of a time chunk (am_shard_scan): for each of the first n candidates, the scan
+// position after the chunk's LAST visited candidate if the scan enters at that candidate.
+// Walk the radix-R jump tables top-down, taking up to R-1 jumps per level while they stay
+// inside the list.
+__global__ void __launch_bounds__(256)
+am_k_chain_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt,
+                const uint32_t *__restrict__ jump, size_t stride, int levels, int radix, uint32_t M,
+                uint32_t n, uint64_t base_abs, am_shard_exit *__restrict__ table)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c = i;
+    for (int k = levels; k >= 0; --k) {
+        const uint32_t *jk = jump + (size_t)k * stride;
+        for (int h = 1; h < radix; ++h) {
+            const uint32_t nx = jk[c];
+            if (nx >= M) break;
+            c = nx;
+        }
+    }
+    am_shard_exit t;
+    t.pos = base_abs + pos[i];
+    t.exit = base_abs + tgt[c];
+    table[i] = t;
 }
 
 __global__ void __launch_bounds__(256)
@@ -687,6 +723,20 @@ hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32
 {
     hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M,
                        cur0, jump0, visited);
+    return hipGetLastError();
+}
+hipError_t am_launch_chain_root(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_chain_root, dim3(1), dim3(64), 0, s, pos, M, cur0, visited);
+    return hipGetLastError();
+}
+hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
+                                int levels, int radix, uint32_t M, uint32_t n, uint64_t base_abs,
+                                am_shard_exit *table, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_chain_exit, dim3(am_grid(n, 256)), dim3(256), 0, s, pos, tgt, jump, stride, levels,
+                       radix, M, n, base_abs, table);
     return hipGetLastError();
 }
 hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s)
@@ -775,60 +825,6 @@ hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_flag_scatter, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, flags,
                        M, blk_off, out_idx);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Candidate records <-> exchange format (time-sharded operation)
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-am_k_cand_import(const am_cand *__restrict__ recs, uint32_t M, uint64_t base_abs, int spc,
-                 uint32_t *__restrict__ pos, uint32_t *__restrict__ e, uint32_t *__restrict__ tgt,
-                 float *__restrict__ inavg, uint8_t *__restrict__ valid)
-{
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    const am_cand r = recs[g];
-    const uint32_t p = (uint32_t)(r.pos - base_abs);
-    const uint32_t ee = p + (r.shift_valid & 0x7FFFFFFFu);
-    const bool ok = (r.shift_valid >> 31) != 0;
-    pos[g] = p;
-    e[g] = ee;
-    inavg[g] = r.inavg;
-    valid[g] = ok ? 1 : 0;
-    tgt[g] = ok ? (ee + (uint32_t)(AM_BURST * spc)) : (ee + 1u);
-}
-
-__global__ void __launch_bounds__(256)
-am_k_cand_export(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
-                 const float *__restrict__ inavg, const uint8_t *__restrict__ valid, uint32_t M,
-                 uint64_t base_abs, am_cand *__restrict__ recs)
-{
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    am_cand r;
-    r.pos = base_abs + pos[g];
-    r.shift_valid = (e[g] - pos[g]) | (valid[g] ? 0x80000000u : 0u);
-    r.inavg = inavg[g];
-    recs[g] = r;
-}
-
-hipError_t am_launch_cand_import(const am_cand *recs, uint32_t M, uint64_t base_abs, int spc,
-                                 uint32_t *pos, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
-                                 hipStream_t s)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_cand_import, dim3(am_grid(M, 256)), dim3(256), 0, s, recs, M, base_abs, spc, pos, e,
-                       tgt, inavg, valid);
-    return hipGetLastError();
-}
-hipError_t am_launch_cand_export(const uint32_t *pos, const uint32_t *e, const float *inavg,
-                                 const uint8_t *valid, uint32_t M, uint64_t base_abs, am_cand *recs,
-                                 hipStream_t s)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_cand_export, dim3(am_grid(M, 256)), dim3(256), 0, s, pos, e, inavg, valid, M,
-                       base_abs, recs);
     return hipGetLastError();
 }
 

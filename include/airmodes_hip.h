@@ -146,31 +146,42 @@ uint32_t am_crc24(const uint8_t *data, int nbytes);
 int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
 
 /* ---- time-sharded operation (one context per GPU, one contiguous time chunk each) -------
- * The greedy preamble scan is sequential only through a sparse candidate list, so a stream
- * cut into G chunks is processed as: every rank runs am_shard_scan on its chunk (with the
- * neighbours' boundary samples attached), the fixed-size candidate records are exchanged
- * (all-gather), and every rank runs am_shard_resolve on the concatenated list, emitting the
- * packets whose preamble starts inside its own chunk.
+ * The reference's preamble scan is sequential, but the only state that crosses a chunk
+ * boundary is ONE number: the position at which the scan resumes ("cur": after a hit at e the
+ * scan skips to e + 240*spc, lib/preamble_impl.cc:237; after a rejected candidate to e + 1,
+ * :209).  That position can reach at most 241*spc samples into the next chunk, so a chunk's
+ * result depends on its predecessor only through which of its first few candidates (those in
+ * its first 241*spc samples, the "lead-in") the scan enters at.  Protocol per step:
+ *   1. every rank attaches its neighbours' boundary samples (am_shard_halo) and runs
+ *      am_shard_scan on its chunk: front end, detection, refinement, jump tables of its own
+ *      greedy chain -- and an EXIT TABLE: for each lead-in candidate (plus the first candidate
+ *      after the lead-in, if any) the position at which the scan would leave the chunk if it
+ *      entered at that candidate;
+ *   2. the small tables are exchanged (all-gather, a few KB), every rank composes them
+ *      (am_shard_entry) to learn the position at which the scan enters ITS chunk;
+ *   3. am_shard_resolve marks the chain from that entry and extracts + slices the chunk's hits.
+ * The concatenation of all chunks' packets equals the single-stream result.
  *
- * am_shard_halo: number of complex samples a chunk needs from its left / right neighbour.
  * am_shard_scan: iq holds samples [abs_start - left, abs_end + right) of the global stream
- *   (left/right as returned by am_shard_halo, clipped at the stream ends; total_n = length
- *   of the global stream).  Produces this chunk's candidate records into recs (host or
- *   device per flags; AM_F_DEVICE_IN applies to iq, AM_F_DEVICE_OUT to recs).
- * am_shard_resolve: all_recs = the G chunks' records concatenated in chunk order. */
-typedef struct am_cand {
-    uint64_t pos;          /* absolute stream index where the first-stage test fired       */
-    uint32_t shift_valid;  /* bits 0..30: late shifts (preamble starts at pos + shift);
-                              bit 31: passed the quiet-zone validation                     */
-    float    inavg;        /* reference level at the shifted start                         */
-} am_cand;
+ *   (left/right from am_shard_halo, clipped to [0, total_n)); AM_F_DEVICE_IN if on the GPU.
+ *   table/cap: caller's host array; *n_table entries written (AM_ECAPACITY if cap is too small,
+ *   *n_table = needed).
+ * am_shard_entry: tables[r] / counts[r] for r = 0..nranks-1 in chunk order, starts[r] = abs_start of
+ *   chunk r; writes entry[r] = scan position when it reaches chunk r (entry[0] = 0). Host only.
+ * am_shard_resolve: cur_in = entry of this rank's chunk. */
+typedef struct am_shard_exit {
+    uint64_t pos;          /* absolute position of the candidate                            */
+    uint64_t exit;         /* scan position after the chunk's last visited candidate, if the
+                              scan enters the chunk at this candidate                       */
+} am_shard_exit;
 
 int am_shard_halo(const am_ctx *ctx, uint64_t *left, uint64_t *right);
 int am_shard_scan(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end,
-                  uint64_t total_n, uint32_t flags, am_cand *recs, uint64_t cap,
-                  uint64_t *n_recs);
-int am_shard_resolve(am_ctx *ctx, const am_cand *all_recs, uint64_t n_all, uint32_t flags,
-                     am_packet *out, uint64_t cap, uint64_t *n_out);
+                  uint64_t total_n, uint32_t flags, am_shard_exit *table, uint64_t cap,
+                  uint64_t *n_table);
+int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, const uint64_t *starts,
+                   uint32_t nranks, uint64_t *entry);
+int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out);
 
 /* last error text of the context (or of am_create when ctx == NULL) */
 const char *am_last_error(const am_ctx *ctx);

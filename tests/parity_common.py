@@ -94,19 +94,19 @@ def check_chunked(lib, rate, iq, edges, thr=7.0, pmf=True, want=None):
 
 
 def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None):
-    """Time-sharded operation (G chunks, candidate exchange) == whole-stream result."""
+    """Time-sharded operation (G chunks, exit-table exchange) == whole-stream result."""
     n = len(iq)
     if want is None:
         want = oracle.demod(iq, rate, thr, pmf)
     ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
     hl, hr = ctxs[0].shard_halo()
     bounds = [(g * n) // G for g in range(G + 1)]
-    recs = []
+    tables = []
     for g in range(G):
         a, b = bounds[g], bounds[g + 1]
-        recs.append(ctxs[g].shard_scan(iq[max(0, a - hl):min(n, b + hr)], a, b, n))
-    allr = np.concatenate(recs)
-    got = np.concatenate([ctxs[g].shard_resolve(allr) for g in range(G)])
+        tables.append(ctxs[g].shard_scan(iq[max(0, a - hl):min(n, b + hr)], a, b, n))
+    entry = _capi.shard_entries(lib, tables, bounds[:-1])
+    got = np.concatenate([ctxs[g].shard_resolve(int(entry[g])) for g in range(G)])
     for c in ctxs:
         c.close()
     assert np.array_equal(got, want), "sharded result differs (%d vs %d packets)" % (len(got), len(want))

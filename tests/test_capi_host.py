@@ -56,7 +56,7 @@ def test_packet_layout_matches_header():
     assert d.itemsize == 56
     assert [d.fields[k][1] for k in ("data", "nbytes", "df", "numlowconf", "crc", "ref", "sample", "secs", "frac")] == \
         [0, 14, 15, 16, 20, 24, 32, 40, 48]
-    assert _capi.TAG_DTYPE.itemsize == 32 and _capi.CAND_DTYPE.itemsize == 16
+    assert _capi.TAG_DTYPE.itemsize == 32 and _capi.EXIT_DTYPE.itemsize == 16
 
 
 def test_msg_queue_semantics():
