@@ -28,7 +28,10 @@ from . import _capi
 
 
 class ShardedReceiver(object):
-    def __init__(self, ctx, rank, world, n_per_rank, group=None):
+    """`chunk` is this rank's 2*n float32 I,Q samples (a view into the halo'd device buffer:
+    write the samples there once, no per-step copy); step() runs one pass."""
+
+    def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -41,12 +44,12 @@ class ShardedReceiver(object):
         self.a0, self.a1 = self.rank * self.n, (self.rank + 1) * self.n
         spc = max(int(ctx.get_rate() / 2e6), 1)
         self.tab_cap = 241 * spc + 4                      # a lead-in cannot hold more candidates than positions
-        self._buf = None
+        self._alloc(device if device is not None else "cpu")
+        self.chunk = self._buf[self.left * 2:(self.left + self.n) * 2]
 
-    def _alloc(self, like):
+    def _alloc(self, dev):
         t = self.torch
         hl, hr, n = self.left, self.right, self.n
-        dev = like.device
         self._buf = t.zeros((hl + n + hr) * 2, dtype=t.float32, device=dev)
         self._slab = t.empty((hl + hr) * 2, dtype=t.float32, device=dev)
         self._slabs = [t.empty_like(self._slab) for _ in range(self.world)]
@@ -55,17 +58,13 @@ class ShardedReceiver(object):
         self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
         self._host_tab = np.zeros(self.tab_cap, _capi.EXIT_DTYPE)
 
-    def step(self, own):
-        """own: this rank's chunk, interleaved float32 I,Q (2*n values), torch tensor on the
-        GPU (or on the CPU for the gloo tests).  Returns this rank's accepted packets."""
+    def step(self):
+        """One pass over the samples currently in `chunk`.  Returns this rank's accepted packets."""
         t, dist = self.torch, self.dist
         hl, hr, n, world, rank = self.left, self.right, self.n, self.world, self.rank
-        assert own.numel() == 2 * n and own.dtype == t.float32
-        if self._buf is None:
-            self._alloc(own)
         buf = self._buf
-        on_gpu = own.is_cuda
-        buf[hl * 2:(hl + n) * 2] = own
+        own = self.chunk
+        on_gpu = buf.is_cuda
         if world > 1:
             self._slab[:hl * 2] = own[(n - hl) * 2:]
             self._slab[hl * 2:] = own[:hr * 2]

@@ -31,8 +31,9 @@ def _worker(rank, world, port, ret):
         lib = _capi.Library(conftest.EMU_LIB)
         ctx = _capi.Context(RATE, 7.0, True, lib=lib)
         rx = ShardedReceiver(ctx, rank, world, N_PER_RANK)
-        pk = rx.step(own)
-        pk2 = rx.step(own)                     # a second step reuses every buffer
+        rx.chunk.copy_(own)
+        pk = rx.step()
+        pk2 = rx.step()                        # a second step reuses every buffer
         assert np.array_equal(pk, pk2)
         ret[rank] = pk.tobytes()
     finally:
