@@ -298,7 +298,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     // split refinement (default): the fused kernel stops after detection and leaves avg[] around the
     // candidates; AIRMODES_FE2_INKERNEL=1 refines inside the kernel instead
     float *avg_sparse = nullptr;
-    if (!c->fe2_inkernel && !avg) {
+    if (!avg) {
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
         avg_sparse = (float *)c->avg.p;
     }

@@ -11,8 +11,8 @@
 //   P5  reference level avg[n] in registers + first-stage preamble test (a6), branch-free from
 //       wide LDS loads of the runs 2, 7 and 9 chips ahead -> candidate bitmap
 //   P6  bb out (coalesced, from X), ordered candidate list (bitmap + block scan)
-//   P7  refinement (a7, a8) of this tile's candidates straight from LDS: late-peak search,
-//       quiet zones, reference level at the shifted start -> candidate records
+//       and avg[] for the runs that hold or follow a candidate (all the refinement kernels
+//       am_k_energy / am_k_cand in am_kernels.hip need)
 //
 // LDS holds ONE float per sample (X), so a 12 K-sample tile fits twice per CU; the left halo is
 // one 48-chip block + one chip (13 % at 64 Msps) and is served from L2 because consecutive
@@ -70,19 +70,19 @@ __device__ __forceinline__ void fe2_lds_store(float *X, int base, const float (&
 
 // bb of one chip from |.|^2 of the previous chip (mp) and of this chip (mc):
 //   bb[i] = fl( (suf_prev[i+1] + pre[i]) * s1 ), last sample: pre only     
+// (in place: mp is turned into its own suffix sums, mc from |iq|^2 into bb -- register diet)
 template <int SPC>
-__device__ __forceinline__ void fe2_pmf_chip(const float (&mp)[SPC], const float *mc, float s1, float *out)
+__device__ __forceinline__ void fe2_pmf_chip(float (&mp)[SPC], float *mc, float s1)
 {
-    float suf[SPC];
     float acc = 0.0f;
 #pragma unroll
-    for (int i = SPC - 1; i >= 0; --i) { acc = acc + mp[i]; suf[i] = acc; }
+    for (int i = SPC - 1; i >= 0; --i) { acc = acc + mp[i]; mp[i] = acc; }
     acc = 0.0f;
 #pragma unroll
     for (int i = 0; i < SPC; ++i) {
         acc = acc + mc[i];
-        const float s = (i == SPC - 1) ? acc : (suf[i + 1] + acc);
-        out[i] = s * s1;
+        const float s = (i == SPC - 1) ? acc : (mp[(i + 1 < SPC) ? i + 1 : i] + acc);
+        mc[i] = s * s1;
     }
 }
 
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     float *ST = PT + NCH;
     uint32_t *BM = reinterpret_cast<uint32_t *>(ST + NCH);  // candidate bitmap [NWORDS]
     uint32_t *WS = BM + NWORDS;                             // wave sums for the block scan
-    uint32_t *RUNANY = WS + 16 + 3 * (NWORDS + 2);          // per thread: does its run hold a candidate
+    uint32_t *RUNANY = WS + 16;                             // per thread: does its run hold a candidate
 
     const int tid = threadIdx.x;
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous range of
@@ -255,32 +255,32 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     const long long end_li = a.src_abs1 - x0 + (LHP - LH);
 
     // ---- P2: pulse matched filter (a3), registers; P3: chip totals -----------------------------
-    fe2_lds_load<R, RUN_AL>(X, run_base, bbv);             // |.|^2 of the run
+    // halo chip first (its temporaries die before the run's registers come alive)
+    const bool do_pmf = a.use_pmf && SPC > 1 && !(a.ablate & 1u);
     float hb[SPC] = {};
-    if (has_halo) fe2_lds_load<SPC, false>(X, chip_base(hq), hb);
-    if (a.use_pmf && SPC > 1 && !(a.ablate & 1u)) {
+    if (has_halo) {
+        fe2_lds_load<SPC, false>(X, chip_base(hq), hb);
+        if (do_pmf) {
+            float hp[SPC];
+            fe2_lds_load<SPC, false>(X, chip_base(hq) - SPC, hp);
+            fe2_pmf_chip<SPC>(hp, &hb[0], a.s1);
+        }
+    }
+    fe2_lds_load<R, RUN_AL>(X, run_base, bbv);             // |.|^2 of the run
+    if (do_pmf) {
         float mp[SPC];
         fe2_lds_load<SPC, CHIP_AL && RUN_AL>(X, run_base - SPC, mp);
-        float out[R];
+        // last chip first: chip k still needs the raw |iq|^2 of chip k-1
 #pragma unroll
-        for (int k = 0; k < CPT; ++k) {
+        for (int k = CPT - 1; k >= 0; --k) {
             if (k == 0) {
-                fe2_pmf_chip<SPC>(mp, &bbv[0], a.s1, &out[0]);
+                fe2_pmf_chip<SPC>(mp, &bbv[0], a.s1);
             } else {
                 float prev[SPC];
 #pragma unroll
                 for (int i = 0; i < SPC; ++i) prev[i] = bbv[(k - 1) * SPC + i];
-                fe2_pmf_chip<SPC>(prev, &bbv[k * SPC], a.s1, &out[k * SPC]);
+                fe2_pmf_chip<SPC>(prev, &bbv[k * SPC], a.s1);
             }
-        }
-#pragma unroll
-        for (int i = 0; i < R; ++i) bbv[i] = out[i];
-        if (has_halo) {
-            float hp[SPC], ho[SPC];
-            fe2_lds_load<SPC, false>(X, chip_base(hq) - SPC, hp);
-            fe2_pmf_chip<SPC>(hp, &hb[0], a.s1, &ho[0]);
-#pragma unroll
-            for (int i = 0; i < SPC; ++i) hb[i] = ho[i];
         }
     }
     // samples beyond the end of the stream read as zero (preamble view pads with zeros)
@@ -351,11 +351,10 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         // in-chip suffix sums of the chip 48 chips back
         float scv[SPC];
         {
-            float pv[SPC];
-            fe2_lds_load<SPC, CHIP_AL && RUN_AL>(X, chip_base(q - AM_CHIPS_AVG), pv);
+            fe2_lds_load<SPC, CHIP_AL && RUN_AL>(X, chip_base(q - AM_CHIPS_AVG), scv);
             float acc = 0.0f;
 #pragma unroll
-            for (int i = SPC - 1; i >= 0; --i) { acc = acc + pv[i]; scv[i] = acc; }
+            for (int i = SPC - 1; i >= 0; --i) { acc = acc + scv[i]; scv[i] = acc; }
         }
         const float pt = PT[q];
         const float st_a = ST[q - AM_CHIPS_AVG];
@@ -381,9 +380,10 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     }
     // a6, branch-free: the pulses 2, 7 and 9 chips ahead are the same run shifted, fetched with
     // wide LDS loads; the result is one bit per sample
-    uint32_t cmask[(R + 31) / 32] = {};
+    static_assert(R <= 32, "one candidate word per thread");
+    uint32_t cmask[1] = {0u};
     if (!(a.ablate & 64u)) {
-        bool c[R];
+        uint32_t cm = 0u;
         const float nxt = X[fe2_pidx(run_base + R)];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -391,23 +391,22 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             const float thr = avgv[i] * a.thr_lin;                       // preamble_impl.cc:173
             const float nx = (i + 1 < R) ? bbv[(i + 1 < R) ? i + 1 : i] : nxt;
             const uint32_t j = jt0 + (uint32_t)(tid * R + i);
-            c[i] = (x > thr) && !(nx > x) && j >= a.j0 && j < a.j1;     // :174, :175
+            const bool c = (x > thr) && !(nx > x) && j >= a.j0 && j < a.j1;   // :174, :175
+            cm |= (c ? 1u : 0u) << i;
         }
         constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             // wave-uniform early out: in quiet stretches no lane has a survivor left
-            bool any = false;
-#pragma unroll
-            for (int i = 0; i < R; ++i) any = any || c[i];
-            if (__ballot(any) == 0ull) break;
+            if (__ballot(cm != 0u) == 0ull) break;
             float t[R];
             fe2_lds_load<R, SHIFT_AL>(X, run_base + offs[o], t);
+            uint32_t below = 0u;
 #pragma unroll
-            for (int i = 0; i < R; ++i) c[i] = c[i] && !(t[i] < avgv[i] * a.thr_lin);   // :177-179
+            for (int i = 0; i < R; ++i) below |= ((t[i] < avgv[i] * a.thr_lin) ? 1u : 0u) << i;   // :177-179
+            cm &= ~below;
         }
-#pragma unroll
-        for (int i = 0; i < R; ++i) if (c[i]) cmask[i >> 5] |= 1u << (i & 31);
+        cmask[0] = cm;
         if constexpr (R == 32) {
             BM[tid] = cmask[0];
         } else {
@@ -479,165 +478,6 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         }
         if (tid == 0) a.blk_cnt[tile] = total;
     }
-    if (total == 0 || a.split_refine || (a.ablate & 128u)) return;   // uniform: nothing to refine here
-    __syncthreads();                                       // seg[] written by other waves is visible
-
-    // ---- P7: refinement of this tile's candidates from LDS (a7, a8) -----------------------------------
-    // The reference slides a candidate right while the 4-pulse energy still grows
-    // (preamble_impl.cc:184-192): late(q) := E(q+1) > E(q).  A lane-per-candidate loop would make
-    // every wave run as long as its slowest lane (a few candidates slide the full spc steps), and
-    // neighbouring candidates would recompute the same energies.  Instead:
-    //   P7a  late(q) is evaluated ONCE for every position q that some candidate can reach
-    //        (q in [p, p+spc-1]), one lane per position, all lanes busy -> bitmap LB
-    //   P7b  per candidate: shifts = number of consecutive late bits from p (capped at spc), then
-    //        the reference level at the shifted start and the quiet-zone test.
-    uint32_t *NL = WS + 16;                                // positions that need a late() flag
-    uint32_t *NLP = NL + (NWORDS + 1);                     // exclusive prefix of popcounts
-    uint32_t *LB = NLP + (NWORDS + 2);                     // late flags
-    auto energy = [&](int at) __attribute__((always_inline)) {
-        double e = 0.0;
-        constexpr int chips[4] = {0, 2, 7, 9};
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            float t[SPC];
-            fe2_lds_load<SPC, false>(X, at + chips[cc] * SPC, t);
-#pragma unroll
-            for (int i = 0; i < SPC; ++i) e += (double)t[i];
-        }
-        return e;
-    };
-    {
-        // needed positions = candidate bitmap dilated by spc-1 towards higher positions
-        uint32_t cnt = 0;
-        uint32_t nlw[WPT + 1];
-        constexpr int WPT2 = (NWORDS + 1 + FE2_NT - 1) / FE2_NT;
-        static_assert(WPT2 <= WPT + 1, "word ownership");
-#pragma unroll
-        for (int k = 0; k < WPT2; ++k) {
-            const int w = tid * WPT2 + k;
-            uint32_t d32 = 0;
-            if (w <= NWORDS) {
-                const unsigned long long hi = (w < NWORDS) ? BM[w] : 0u;
-                const unsigned long long lo = (w > 0) ? BM[w - 1] : 0u;
-                unsigned long long v = (hi << 32) | lo;
-                // OR of shifts 0 .. SPC-1
-                int covered = 1;
-#pragma unroll
-                for (int step = 1; step * 2 <= SPC; step *= 2) { v |= v << step; covered = step * 2; }
-                if (covered < SPC) v |= v << (SPC - covered);
-                d32 = (uint32_t)(v >> 32);
-                NL[w] = d32;
-                LB[w] = 0u;
-            }
-            nlw[k] = d32;
-            cnt += (uint32_t)__popcll((unsigned long long)d32);
-        }
-        const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
-        uint32_t incl = cnt;
-        for (int d = 1; d < AM_WAVE; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
-            if (lane >= d) incl += up;
-        }
-        __syncthreads();                                   // WS reuse: everyone has read the candidate totals
-        if (lane == AM_WAVE - 1) WS[wv] = incl;
-        __syncthreads();
-        uint32_t off = incl - cnt;
-        for (int k = 0; k < wv; ++k) off += WS[k];
-#pragma unroll
-        for (int k = 0; k < WPT2; ++k) {
-            const int w = tid * WPT2 + k;
-            if (w <= NWORDS) NLP[w] = off;
-            off += (uint32_t)__popcll((unsigned long long)nlw[k]);
-        }
-        if (tid == FE2_NT - 1) NLP[NWORDS + 1] = off;      // total number of needed positions
-    }
-    __syncthreads();
-    {
-        const uint32_t nneed = NLP[NWORDS + 1];
-        for (uint32_t k = tid; k < nneed; k += FE2_NT) {
-            // compact index k -> word (last w with NLP[w] <= k) -> bit (the (k - NLP[w])-th set bit)
-            int lo = 0, hi = NWORDS + 1;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (NLP[mid] <= k) lo = mid; else hi = mid;
-            }
-            uint32_t wbits = NL[lo];
-            for (uint32_t r = k - NLP[lo]; r > 0; --r) wbits &= wbits - 1u;
-            const int q = lo * 32 + (__ffsll((long long)wbits) - 1);   // local position
-            double e0 = 0.0, e1 = 0.0;
-            if (!(a.ablate & 512u)) { e0 = energy(LHP + q); e1 = energy(LHP + q + 1); }
-            if (e1 > e0) atomicOr(&LB[q >> 5], 1u << (q & 31));
-        }
-    }
-    __syncthreads();
-
-    if (a.ablate & 256u) return;
-    for (uint32_t ci = tid; ci < total; ci += FE2_NT) {
-        const uint32_t j = seg[ci];
-        const int pl = (int)(j - jt0);                     // local position of the candidate
-        const int w0 = pl >> 5;
-        const unsigned long long win = (((unsigned long long)LB[w0 + 1] << 32) | LB[w0]) >> (pl & 31);
-        int how_late = __ffsll((long long)~win) - 1;       // consecutive late flags from the candidate
-        if (how_late > SPC) how_late = SPC;
-        const int le = LHP + pl + how_late;
-        // reference level at the shifted start: avg[e] in the canonical two-level order
-        float av;
-        {
-            const int rel = le - (LHP - LH);
-            const int q = rel / SPC, io = rel - q * SPC;           // chip and offset inside it
-            const int jb = (q - 1) % AM_CHIPS_AVG;
-            float t[SPC];
-            fe2_lds_load<SPC, false>(X, chip_base(q), t);
-            float pc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < SPC; ++i) pc = (i <= io) ? (pc + t[i]) : pc;
-            const float PRE = PT[q] + pc;
-            float ssum;
-            if (io == SPC - 1) {
-                ssum = (jb == AM_CHIPS_AVG - 1) ? PRE : ((RTOT[q - AM_CHIPS_AVG + 1] + ST[q - AM_CHIPS_AVG + 1]) + PRE);
-            } else {
-                float u[SPC];
-                fe2_lds_load<SPC, false>(X, chip_base(q - AM_CHIPS_AVG), u);
-                float sc = 0.0f;
-#pragma unroll
-                for (int i = SPC - 1; i >= 0; --i) sc = (i > io) ? (sc + u[i]) : sc;
-                ssum = (sc + ST[q - AM_CHIPS_AVG]) + PRE;
-            }
-            av = ssum * a.sL;
-            if ((long long)le >= end_li) av = 0.0f;                // beyond the end of the stream
-        }
-        // quiet zones (preamble_impl.cc:198-209)
-        const float p0 = X[fe2_pidx(le)], p1 = X[fe2_pidx(le + 2 * SPC)];
-        const float p2 = X[fe2_pidx(le + 7 * SPC)], p3 = X[fe2_pidx(le + 9 * SPC)];
-        float ps = p0 + p1;
-        ps = ps + p2;
-        ps = ps + p3;
-        const float avgpeak = (float)((double)ps / 4.0);
-        const float sthr = av + (avgpeak - av) / a.thr_lin;
-        bool bad = false;
-        {
-            constexpr int N1 = 3 * SPC + 1, N2 = 5 * SPC + 1;      // offsets 3spc..6spc, 10spc..15spc
-            constexpr int CH = 16;
-            for (int o = 0; o < N1 && !bad; o += CH) {
-                float t[CH];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) t[k] = X[fe2_pidx(le + 3 * SPC + ((o + k < N1) ? o + k : N1 - 1))];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) bad = bad || (t[k] > sthr);
-            }
-            for (int o = 0; o < N2 && !bad; o += CH) {
-                float t[CH];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) t[k] = X[fe2_pidx(le + 10 * SPC + ((o + k < N2) ? o + k : N2 - 1))];
-#pragma unroll
-                for (int k = 0; k < CH; ++k) bad = bad || (t[k] > sthr);
-            }
-        }
-        const size_t so = (size_t)tile * T + ci;
-        a.seg_e[so] = j + (uint32_t)how_late;
-        a.seg_inavg[so] = av;
-        a.seg_valid[so] = bad ? 0 : 1;
-    }
 }
 
 template <int SPC, int CPT>
@@ -647,7 +487,7 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     constexpr int RH = FE2_RH_CHIPS * SPC;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;
     constexpr int NWORDS = (T + 31) / 32;
-    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + 3 * (NWORDS + 2) + FE2_NT) *
+    const size_t lds = ((size_t)fe2_padn(LHP + T + RH) + (size_t)4 * NCH + NWORDS + 16 + 16 + FE2_NT) *
                        sizeof(float);
     am_fe2_args a = a_in;
     size_t lds_req = lds;

@@ -70,13 +70,6 @@ def test_tiled_fused_kernel_still_matches(emu_lib, monkeypatch):
         assert pc.check_stages(emu_lib, rate, n, 6000.0, 51) > 3
 
 
-def test_inkernel_refinement_still_matches(emu_lib, monkeypatch):
-    """A/B path: refinement inside the fused kernel instead of the split energy/candidate kernels."""
-    monkeypatch.setenv("AIRMODES_FE2_INKERNEL", "1")
-    for rate, n in ((16e6, 200000), (20e6, 300000), (64e6, 500000), (2e6, 150000)):
-        assert pc.check_stages(emu_lib, rate, n, 6000.0, 52) > 3
-
-
 def test_span_geometry_variants(emu_lib, monkeypatch):
     """Span length must not matter (1 block per span ... everything in one span)."""
     iq, _ = synth.synth_capture(64e6, 400000, 20000.0, seed=61)

@@ -43,13 +43,6 @@ def test_tiled_fused_kernel_still_matches(lib, monkeypatch):
         assert pc.check_stages(lib, rate, n, 6000.0, 51) > 3
 
 
-def test_inkernel_refinement_still_matches(lib, monkeypatch):
-    """A/B path: refinement inside the fused kernel instead of the split energy/candidate kernels."""
-    monkeypatch.setenv("AIRMODES_FE2_INKERNEL", "1")
-    for rate, n in ((16e6, 2000000), (20e6, 2000000), (64e6, 6000000), (2e6, 150000)):
-        assert pc.check_stages(lib, rate, n, 6000.0, 52) > 3
-
-
 def test_span_geometry_variants(lib, monkeypatch):
     iq, _ = synth.synth_capture(64e6, 4000000, 20000.0, seed=61)
     want = oracle.demod(iq, 64e6)
