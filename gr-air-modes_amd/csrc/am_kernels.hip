@@ -275,17 +275,21 @@ hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hi
 // Refinement (a7, a8): per candidate, the 4-pulse energy (double precision, chip-major order
 // as in the reference) at the late shifts it actually visits, then the quiet-zone scan.
 // ------------------------------------------------------------------------------------------
-// 16 loads are put in flight before they are consumed; the additions keep the reference's
+// four floats at a 4-byte aligned address in one 16-byte global load (gfx950 allows unaligned
+// vector memory access; the packed type tells the compiler not to assume 16-byte alignment)
+struct __attribute__((packed, aligned(4))) am_f4u { float v[4]; };
+
+// 16 values are put in flight before they are consumed; the additions keep the reference's
 // strict left-to-right double-precision order (preamble_impl.cc:91-98).
 __device__ __forceinline__ double am_energy_chip(const float *__restrict__ p, int spc, double e)
 {
     int i = 0;
     for (; i + 16 <= spc; i += 16) {
-        float t[16];
+        am_f4u t[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t[k] = p[i + k];
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const am_f4u *>(p + i + 4 * k);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) e += (double)t[k];
+        for (int k = 0; k < 16; ++k) e += (double)t[k >> 2].v[k & 3];
     }
     for (; i + 4 <= spc; i += 4) {
         float t[4];
@@ -313,12 +317,12 @@ __device__ __forceinline__ bool am_any_above(const float *__restrict__ z, int n,
 {
     int o = 0;
     for (; o + 16 <= n; o += 16) {
-        float t[16];
+        am_f4u t[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t[k] = z[o + k];
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const am_f4u *>(z + o + 4 * k);
         bool hit = false;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) hit = hit || (t[k] > thr);
+        for (int k = 0; k < 16; ++k) hit = hit || (t[k >> 2].v[k & 3] > thr);
         if (hit) return true;
     }
     for (; o < n; ++o) if (z[o] > thr) return true;
