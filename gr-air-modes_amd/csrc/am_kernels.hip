@@ -504,17 +504,35 @@ am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, cons
             const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t M, int spc,
             double *__restrict__ energy)
 {
+    __shared__ uint32_t cb[2];
     const uint32_t nb = (M + AM_SCAN_BLK - 1) / AM_SCAN_BLK;
     const uint32_t total = blk_base[nb];                     // number of positions that need an energy
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
-        // candidate that contributed compact index k: last c with off[c] <= k
-        uint32_t lo = 0, hi = M;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (am_off_at(off_local, blk_base, mid) <= k) lo = mid; else hi = mid;
+    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < total; k0 += gridDim.x * blockDim.x) {
+        // The 256 consecutive compact indices of this workgroup belong to a short run of candidates:
+        // two lanes bracket it with a full binary search, the others search inside the bracket.
+        if (threadIdx.x < 2) {
+            uint32_t key = threadIdx.x == 0 ? k0 : k0 + blockDim.x - 1;
+            if (key >= total) key = total - 1;
+            uint32_t lo = 0, hi = M;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (am_off_at(off_local, blk_base, mid) <= key) lo = mid; else hi = mid;
+            }
+            cb[threadIdx.x] = lo;
         }
-        const uint32_t q = pos[lo] + (uint32_t)spc + 1u - dcount[lo] + (k - am_off_at(off_local, blk_base, lo));
-        energy[k] = am_preamble_energy(bb + q, spc);         // preamble_impl.cc:91-98
+        __syncthreads();
+        const uint32_t k = k0 + threadIdx.x;
+        if (k < total) {
+            // candidate that contributed compact index k: last c with off[c] <= k
+            uint32_t lo = cb[0], hi = cb[1] + 1;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (am_off_at(off_local, blk_base, mid) <= k) lo = mid; else hi = mid;
+            }
+            const uint32_t q = pos[lo] + (uint32_t)spc + 1u - dcount[lo] + (k - am_off_at(off_local, blk_base, lo));
+            energy[k] = am_preamble_energy(bb + q, spc);     // preamble_impl.cc:91-98
+        }
+        __syncthreads();
     }
 }
 
