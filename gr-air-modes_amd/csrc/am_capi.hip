@@ -357,21 +357,19 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     const int levels = c->chain_levels;
     const size_t stride = c->chain_stride;
     uint32_t *jump = (uint32_t *)c->jump.p;
-    HIPCHK(c, hipMemsetAsync(c->visited.p, 0, stride, c->stream));
-    uint32_t init[2] = {cur0, 0};
-    HIPCHK(c, hipMemcpyAsync(c->scalars.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, am_launch_chain_root((uint32_t *)c->pos.p, M, cur0, (uint8_t *)c->visited.p, c->stream));
+    (void)stride;
+    HIPCHK(c, am_launch_chain_init((uint32_t *)c->pos.p, M, cur0, (uint8_t *)c->visited.p,
+                                   (uint32_t *)c->scalars.p, c->stream));
     for (int k = levels; k >= 0; k--)
         HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, AM_CHAIN_RADIX,
                                        c->stream));
-    HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
-                                   (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
-                                   (uint8_t *)c->emit.p, (uint32_t *)c->scalars.p,
-                                   emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream));
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
-    HIPCHK(c, am_launch_flag_count((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_cnt.p, c->stream));
+    HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
+                                   (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
+                                   (uint8_t *)c->emit.p, (uint32_t *)c->cblk_cnt.p, (uint32_t *)c->scalars.p,
+                                   emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream));
     HIPCHK(c, am_launch_scan_u32((uint32_t *)c->cblk_cnt.p, (uint32_t *)c->cblk_off.p, nb, c->stream));
     // Hits are at least 240*spc apart, so their number is bounded by the span of the candidates;
     // everything downstream is launched for that bound and reads the real count on the device.
@@ -395,10 +393,10 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                 (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
                                 (float *)c->bursts.p, c->pin_tags, c->stream));
+    c->pin_scalars[0] = 0;
+    c->pin_scalars[1] = cur0;
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, c->pin_tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
-                              c->pin_packets, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->pin_scalars[0], n_ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&c->pin_scalars[1], c->scalars.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                              c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const uint32_t n_emit = c->pin_scalars[0];
     *final_cur = c->pin_scalars[1];
@@ -792,7 +790,7 @@ int am_slicer_work(am_ctx *c, const float *bursts, const am_tag *tags, uint64_t 
     const uint32_t nb32 = (uint32_t)nb;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, &nb32, sizeof(nb32), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, (const uint32_t *)c->scalars.p, nb32,
-                              (uint32_t *)c->crc_pow.p, (am_packet *)c->packets.p, c->stream));
+                              (uint32_t *)c->crc_pow.p, (am_packet *)c->packets.p, nullptr, nullptr, c->stream));
     c->h_packets.resize(nb);
     HIPCHK(c, hipMemcpyAsync(c->h_packets.data(), c->packets.p, nb * sizeof(am_packet), hipMemcpyDeviceToHost,
                              c->stream));

@@ -109,12 +109,13 @@ hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M,
 hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s);
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
-                                uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *scalars,
-                                int want_resume, hipStream_t s);
+                                uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
+                                uint32_t *scalars, int want_resume, hipStream_t s);
 hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
                                   uint32_t *out_idx, hipStream_t s);
-hipError_t am_launch_chain_root(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited, hipStream_t s);
+hipError_t am_launch_chain_init(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited,
+                                uint32_t *scalars, hipStream_t s);
 hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
                                 int levels, int radix, uint32_t M, uint32_t n, uint64_t base_abs,
                                 am_shard_exit *table, hipStream_t s);
@@ -127,6 +128,7 @@ hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const
                              am_tag *tags, hipStream_t s);
 /* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
-                           const uint32_t *crc_pow, am_packet *packets, hipStream_t s);
+                           const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,
+                           uint32_t *host_out, hipStream_t s);
 
 #endif

@@ -641,14 +641,18 @@ am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ t
     }
 }
 
-// mark the first candidate the scan reaches when it (re)starts at position cur0
-__global__ void am_k_chain_root(const uint32_t *__restrict__ pos, uint32_t M, uint32_t cur0,
-                                uint8_t *__restrict__ visited)
+// visited[] = {the first candidate the scan reaches when it (re)starts at cur0}; scalars[0] = cur0.
+// One launch instead of memset + copy + a one-thread kernel: every workgroup finds the root itself.
+__global__ void __launch_bounds__(256)
+am_k_chain_init(const uint32_t *__restrict__ pos, uint32_t M, uint32_t cur0, uint8_t *__restrict__ visited,
+                uint32_t *__restrict__ scalars)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t root = am_lower_bound(pos, 0, M, cur0);
-        if (root < M) visited[root] = 1;
-    }
+    __shared__ uint32_t root_s;
+    if (threadIdx.x == 0) root_s = am_lower_bound(pos, 0, M, cur0);
+    __syncthreads();
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g <= M) visited[g] = (g == root_s && g < M) ? 1 : 0;
+    if (g == 0) { scalars[0] = cur0; scalars[1] = 0u; }
 }
 
 // Exit table of a time chunk (am_shard_scan): for each of the first n candidates, the scan
@@ -703,38 +707,45 @@ am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M, i
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(AM_DET_THREADS)
 am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ valid,
                 const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
                 const uint32_t *__restrict__ tgt, uint32_t M, uint32_t emit_max, uint32_t own_lo,
-                uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *scalars, int want_resume)
+                uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *__restrict__ blk_cnt, uint32_t *scalars,
+                int want_resume)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = g < M;
-    const bool vis = in && visited[g] != 0;
-    // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is
-    // not emitted (and nothing after it can be).  [own_lo, own_hi) restricts the output to
-    // the hits this GPU's time chunk owns (everything in single-GPU operation).
-    if (in) {
+    // emit flags + their per-2048 block counts (for the ordered compaction) in one pass.
+    // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is not
+    // emitted (and nothing after it can be).  [own_lo, own_hi) restricts the output to the hits
+    // this GPU's time chunk owns (everything in single-GPU operation).
+    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
+    __shared__ uint32_t wmax[AM_DET_THREADS / AM_WAVE];
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const int w = threadIdx.x / AM_WAVE;
+    const uint32_t base = blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
+    uint32_t cnt = 0, t = 0;
+    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
+        const uint32_t g = base + it * AM_WAVE + lane;
+        const bool in = g < M;
+        const bool vis = in && visited[g] != 0;
         const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
-        emit[g] = em ? 1 : 0;
+        if (in) emit[g] = em ? 1 : 0;
+        cnt += (uint32_t)__popcll(__ballot(em));
+        if (want_resume && vis) { const uint32_t tg = tgt[g]; t = tg > t ? tg : t; }
     }
     // where the scan resumes after everything visited here: the largest target (only needed when
-    // the stream continues).  Same-address atomics serialise (~11 ns each), so reduce per
-    // workgroup first: one atomic per 256 nodes.
-    if (!want_resume) return;
-    __shared__ uint32_t wmax[256 / AM_WAVE];
-    uint32_t t = vis ? tgt[g] : 0u;
+    // the stream continues).  Same-address atomics serialise (~11 ns each): one per workgroup.
     for (int o = 32; o >= 1; o >>= 1) {
         const uint32_t other = (uint32_t)__shfl_xor((int)t, o, AM_WAVE);
         t = other > t ? other : t;
     }
-    if ((threadIdx.x & (AM_WAVE - 1)) == 0) wmax[threadIdx.x / AM_WAVE] = t;
+    if (lane == 0) { wc[w] = cnt; wmax[w] = t; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t m = 0;
-        for (int k = 0; k < 256 / AM_WAVE; ++k) m = wmax[k] > m ? wmax[k] : m;
-        if (m) atomicMax(&scalars[0], m);
+        uint32_t tot = 0, m = 0;
+        for (int k = 0; k < AM_DET_THREADS / AM_WAVE; ++k) { tot += wc[k]; m = wmax[k] > m ? wmax[k] : m; }
+        blk_cnt[blockIdx.x] = tot;
+        if (want_resume && m) atomicMax(&scalars[0], m);
     }
 }
 
@@ -747,9 +758,11 @@ hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32
                        cur0, jump0, visited);
     return hipGetLastError();
 }
-hipError_t am_launch_chain_root(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited, hipStream_t s)
+hipError_t am_launch_chain_init(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited,
+                                uint32_t *scalars, hipStream_t s)
 {
-    hipLaunchKernelGGL(am_k_chain_root, dim3(1), dim3(64), 0, s, pos, M, cur0, visited);
+    hipLaunchKernelGGL(am_k_chain_init, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, M, cur0, visited,
+                       scalars);
     return hipGetLastError();
 }
 hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
@@ -773,12 +786,12 @@ hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M
 }
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
-                                uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *scalars,
-                                int want_resume, hipStream_t s)
+                                uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
+                                uint32_t *scalars, int want_resume, hipStream_t s)
 {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, 256)), dim3(256), 0, s, visited, valid, pos, e, tgt, M,
-                       emit_max, own_lo, own_hi, emit, scalars, want_resume);
+    hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, visited,
+                       valid, pos, e, tgt, M, emit_max, own_lo, own_hi, emit, blk_cnt, scalars, want_resume);
     return hipGetLastError();
 }
 
@@ -926,10 +939,13 @@ __device__ __forceinline__ uint32_t am_bitrev8(uint32_t v)
 
 __global__ void __launch_bounds__(256)
 am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, const uint32_t *__restrict__ n_ptr,
-           const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets)
+           const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets,
+           const uint32_t *__restrict__ scalars, uint32_t *__restrict__ host_out)
 {
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
+    // hit count and scan resume position go straight to pinned host memory (no extra copies)
+    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) { host_out[0] = *n_ptr; host_out[1] = scalars[0]; }
     if (i >= *n_ptr) return;                              // wave-uniform; device-side burst count
     const float *b = bursts + (size_t)i * AM_BURST;
     float s = b[0] + b[2];                                // slicer_impl.cc:128-131
@@ -988,9 +1004,11 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
 }
 
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
-                           const uint32_t *crc_pow, am_packet *packets, hipStream_t s)
+                           const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,
+                           uint32_t *host_out, hipStream_t s)
 {
     if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bursts, tags, n_ptr, crc_pow, packets);
+    hipLaunchKernelGGL(am_k_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bursts, tags, n_ptr, crc_pow, packets,
+                       scalars, host_out);
     return hipGetLastError();
 }
