@@ -289,9 +289,6 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
     const size_t nslots = (size_t)ntiles * T2;
     ENSURE(c, c->cand_seg, nslots * sizeof(uint32_t));
-    ENSURE(c, c->seg_e, nslots * sizeof(uint32_t));
-    ENSURE(c, c->seg_inavg, nslots * sizeof(float));
-    ENSURE(c, c->seg_valid, nslots);
     ENSURE(c, c->blk_cnt, ((size_t)ntiles + 8) * sizeof(uint32_t));
     ENSURE(c, c->blk_off, ((size_t)ntiles + 9) * sizeof(uint32_t));
     unsigned nt = 0, tl = 0;
@@ -305,8 +302,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     HIPCHK(c, am_launch_fe2(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
                             (long long)out_n, bb, avg, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                             (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
-                            (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p, avg_sparse,
-                            (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
+                            nullptr, nullptr, nullptr, avg_sparse, (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const uint64_t endj = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
     return run_refine(c, bb, avg_sparse ? avg_sparse : avg, nt, tl, avg_sparse ? 2 : 1, M_out,
