@@ -21,14 +21,22 @@
 // lib/preamble_impl.cc:172-179.
 #include "am_internal.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <vector>
 
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
 
-#define FE2_NT 768
-#define FE2_RH_CHIPS 17                      /* refinement looks ahead 16 chips + 1 sample */
+#ifndef FE2_NT
+#define FE2_NT 768                          /* threads per workgroup (tuning builds may override) */
+#endif
+#ifndef FE2_WPS
+#define FE2_WPS 3                          /* launch bound: waves per SIMD */
+#endif
+#define FE2_RH_CHIPS 9                       /* the first-stage test looks 9 chips (+ 1 sample) ahead */
 #define FE2_LH_CHIPS (AM_CHIPS_AVG + 1)      /* 48-chip block + one chip                 */
 #define FE2_HALO_THREADS (AM_CHIPS_AVG + FE2_RH_CHIPS)
 
@@ -36,35 +44,40 @@
 // lanes that walk 32-float runs over all banks.
 __device__ __forceinline__ int fe2_pidx(int i) { return i + ((i >> 5) << 2); }
 __host__ __device__ constexpr int fe2_padn(int n) { return n + ((n >> 5) << 2) + 8; }
+__host__ __device__ constexpr int fe2_lhp(int lh) { return (lh + 1 + 31) & ~31; }
 
-template <int N, bool ALIGNED>
+// INGROUP: the caller guarantees that the N words lie inside one 32-word padding group, so the
+// padded index is one computation plus constant offsets (the per-word form costs ~3 VALU each).
+template <int N, bool ALIGNED, bool INGROUP = false>
 __device__ __forceinline__ void fe2_lds_load(const float *X, int base, float (&v)[N])
 {
+    const float *P = X + (INGROUP ? fe2_pidx(base) : 0);
     if constexpr (ALIGNED && (N % 4 == 0)) {
 #pragma unroll
         for (int k = 0; k < N / 4; ++k) {
-            const float4 t = *reinterpret_cast<const float4 *>(&X[fe2_pidx(base + 4 * k)]);
+            const float4 t = *reinterpret_cast<const float4 *>(INGROUP ? &P[4 * k] : &X[fe2_pidx(base + 4 * k)]);
             v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < N; ++k) v[k] = X[fe2_pidx(base + k)];
+        for (int k = 0; k < N; ++k) v[k] = INGROUP ? P[k] : X[fe2_pidx(base + k)];
     }
 }
 
-template <int N, bool ALIGNED>
+template <int N, bool ALIGNED, bool INGROUP = false>
 __device__ __forceinline__ void fe2_lds_store(float *X, int base, const float (&v)[N])
 {
+    float *P = X + (INGROUP ? fe2_pidx(base) : 0);
     if constexpr (ALIGNED && (N % 4 == 0)) {
 #pragma unroll
         for (int k = 0; k < N / 4; ++k) {
             float4 t;
             t.x = v[4 * k]; t.y = v[4 * k + 1]; t.z = v[4 * k + 2]; t.w = v[4 * k + 3];
-            *reinterpret_cast<float4 *>(&X[fe2_pidx(base + 4 * k)]) = t;
+            *reinterpret_cast<float4 *>(INGROUP ? &P[4 * k] : &X[fe2_pidx(base + 4 * k)]) = t;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < N; ++k) X[fe2_pidx(base + k)] = v[k];
+        for (int k = 0; k < N; ++k) (INGROUP ? P[k] : X[fe2_pidx(base + k)]) = v[k];
     }
 }
 
@@ -88,11 +101,21 @@ __device__ __forceinline__ void fe2_pmf_chip(float (&mp)[SPC], float *mc, float 
 
 // tile -> global, 16 bytes per lane (the output arrays are 16-byte aligned and tiles start at
 // multiples of 4 samples); the ragged end of the stream falls back to scalar stores
-template <int T>
+template <int T, bool EDGE>
 __device__ __forceinline__ void fe2_store_tile(const float *X, int lhp, float *dst, long long o0, long long out_n,
                                                int tid)
 {
     static_assert(T % 4 == 0, "tile length");
+    if constexpr (!EDGE) {
+        float4 *d4 = reinterpret_cast<float4 *>(dst + o0);       // uniform base, 32-bit lane offsets
+        static_assert((T / 4) % FE2_NT == 0, "whole rounds");
+        const float *P = X + fe2_pidx(lhp + 4 * tid);           // lhp and 4*768 are multiples of 32
+        constexpr int KSTEP = 4 * FE2_NT + (((4 * FE2_NT) >> 5) << 2);
+#pragma unroll
+        for (int k = 0; k < T / 4 / FE2_NT; ++k)
+            d4[(unsigned)(tid + k * FE2_NT)] = *reinterpret_cast<const float4 *>(&P[k * KSTEP]);
+        return;
+    }
 #pragma unroll 4
     for (int i4 = tid; i4 < T / 4; i4 += FE2_NT) {
         const long long o = o0 + 4 * i4;
@@ -106,6 +129,13 @@ __device__ __forceinline__ void fe2_store_tile(const float *X, int lhp, float *d
         }
     }
 }
+
+// phase stamps (profiling builds of the host set a.clk): lane 0 of wave 0 and of wave 5
+#define FE2_STAMP(k)                                                                            \
+    do {                                                                                       \
+        if (a.clk && (tid == 0 || tid == 5 * AM_WAVE))                                          \
+            a.clk[(size_t)tile * 32 + (tid ? 16 : 0) + (k)] = (long long)clock64();             \
+    } while (0)
 
 struct am_fe2_args {
     const float *iq;
@@ -126,27 +156,36 @@ struct am_fe2_args {
     int use_pmf;
     float s1, sL, thr_lin;
     unsigned ablate;                // profiling only (AIRMODES_FE2_ABLATE): skip phases, results invalid
+    long long *clk;                 // profiling only (AIRMODES_FE2_CLOCK): per tile, 2 waves x 16 phase stamps
 };
 
-template <int SPC, int CPT>
-__global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
+// One tile.  EDGE = false is the interior fast path: the tile, its halos and every position it
+// tests lie inside the stream and inside the wanted output range, so no per-sample bounds
+// predicate, clamp or 64-bit address survives (they were ~60 % of the VALU instructions, and
+// this kernel is VALU-issue bound once its loads are batched).  EDGE = true keeps all of them
+// and serves the first / last tiles of a stream and unaligned inputs.
+template <int SPC, int CPT, bool EDGE>
+__device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned tile, float *smem)
 {
     constexpr int R = SPC * CPT;                 // samples per thread
     constexpr int T = FE2_NT * R;                // samples per tile
     constexpr int LH = FE2_LH_CHIPS * SPC;
-    constexpr int LHP = (LH + 31) & ~31;         // tile starts 32-aligned in LDS
+    constexpr int LHP = fe2_lhp(LH);             // tile starts 32-aligned in LDS, >= 1 spare slot before the halo
     constexpr int RH = FE2_RH_CHIPS * SPC;
+    constexpr int W = LH + T + RH;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;   // chips resident
     constexpr int NBLK = 1 + (FE2_NT * CPT) / AM_CHIPS_AVG;           // 48-chip blocks incl. halo block
     constexpr bool RUN_AL = (R % 4 == 0);
     constexpr bool CHIP_AL = (SPC % 4 == 0);
     constexpr bool SHIFT_AL = RUN_AL && ((2 * SPC) % 4 == 0) && ((7 * SPC) % 4 == 0) && ((9 * SPC) % 4 == 0);
+    // padded-index shortcuts (LHP is a multiple of 32; chips sit at LHP - 49*SPC + c*SPC)
+    constexpr bool RUN_IG = (32 % R == 0);       // a run lies inside one padding group
+    constexpr bool CHIP_IG = (32 % SPC == 0);    // so does a chip
     constexpr int NWORDS = (T + 31) / 32;
     constexpr int WPT = (NWORDS + FE2_NT - 1) / FE2_NT;               // bitmap words per thread
     static_assert((FE2_NT * CPT) % AM_CHIPS_AVG == 0, "tile must be whole 48-chip blocks");
-    static_assert(FE2_HALO_THREADS <= FE2_NT, "halo chips are handled one per thread");
+    static_assert(FE2_HALO_THREADS <= AM_WAVE, "halo chips are handled by one wave, one per lane");
 
-    HIP_DYNAMIC_SHARED(float, smem);
     float *X = smem;                                        // [LHP + T + RH] padded
     float *TOT = X + fe2_padn(LHP + T + RH);                // chip totals, left->right   [NCH]
     float *RTOT = TOT + NCH;                                // chip totals, right->left   [NCH]
@@ -157,28 +196,51 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     uint32_t *RUNANY = WS + 16;                             // per thread: does its run hold a candidate
 
     const int tid = threadIdx.x;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous range of
-    // tiles so that neighbouring tiles (which share the halo) share an L2.
-    const unsigned nb = a.ntiles;
-    const unsigned per = (nb + 7u) / 8u;
-    const unsigned tile = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
-    if (tile >= nb) return;                                 // whole workgroup (uniform)
-    if (a.ablate & 1024u) { if (tid == 0) a.blk_cnt[tile] = 0; return; }
     const long long tile0 = a.out_abs0 + (long long)tile * T;
     const long long x0 = tile0 - LH;                        // absolute index of logical LDS index LHP-LH
+    const long long rel0 = x0 - a.src_abs0;                 // the same as an offset into a.iq
 
+    FE2_STAMP(0);
     // ---- P1: IQ -> |.|^2 -> X ---------------------------------------------------------------
     // All of a thread's loads are issued back to back before the first use (one HBM round trip
-    // per tile instead of one per load).  To keep them in one basic block the loads are
-    // unconditional from a clamped (always valid) address and out-of-stream lanes are zeroed
-    // afterwards: a branch around a load would force an s_waitcnt at its join.
-    {
-        constexpr int W = LH + T + RH;
+    // per tile instead of one per load).
+    if constexpr (!EDGE) {
+        // 16 bytes per lane from a uniform base: pair p holds samples 2p-sh, 2p-sh+1 of the window
+        // (sh = 1 when the window starts on an odd sample: it is then loaded from one sample early)
+        constexpr int NPI = (W + 2) / 2;
+        constexpr int NP = (NPI + FE2_NT - 1) / FE2_NT;
+        const int sh = (int)(rel0 & 1);
+        const float4 *base = reinterpret_cast<const float4 *>(a.iq) + ((rel0 - sh) >> 1);
+        float4 v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            unsigned p = (unsigned)(tid + k * FE2_NT);
+            if ((k + 1) * FE2_NT > NPI) p = p < (unsigned)NPI ? p : (unsigned)(NPI - 1);   // last round only
+            v[k] = base[p];
+        }
+        // LDS slot of pair 0; pair p + 768 k lands 1536 k samples = 48 k padding groups further
+        const int li0 = LHP - LH - sh + 2 * tid;
+        const int q0 = fe2_pidx(li0), q1 = fe2_pidx(li0 + 1);
+        constexpr int KSTEP = 2 * FE2_NT + (((2 * FE2_NT) >> 5) << 2);
+        static_assert((2 * FE2_NT) % 32 == 0, "pair rounds keep the padding phase");
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const float r0 = v[k].x * v[k].x, i0 = v[k].y * v[k].y;
+            const float r1 = v[k].z * v[k].z, i1 = v[k].w * v[k].w;
+            if ((k + 1) * FE2_NT <= NPI || tid + k * FE2_NT < NPI) {
+                X[q0 + k * KSTEP] = r0 + i0;                             // a1: fl(fl(I*I) + fl(Q*Q))
+                X[q1 + k * KSTEP] = r1 + i1;
+            }
+        }
+        for (int w = tid; w < NWORDS; w += FE2_NT) BM[w] = 0u;
+    } else {
+        // Loads are unconditional from a clamped (always valid) address so that they stay in one
+        // basic block, and out-of-stream lanes are zeroed afterwards: a branch around a load would
+        // force an s_waitcnt at its join.
         constexpr int NPAIR = (W + 1) / 2;
         constexpr int NP = (NPAIR + FE2_NT - 1) / FE2_NT;
         const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
         const long long len = a.src_abs1 - a.src_abs0;
-        const long long rel0 = x0 - a.src_abs0;
         const bool vec = (rel0 & 1) == 0 && (reinterpret_cast<uintptr_t>(a.iq) & 15u) == 0 && len >= 2;
         if (a.ablate & 16u) {
             for (int i = tid; i < fe2_padn(LHP + T + RH); i += FE2_NT) X[i] = 1.0f;
@@ -238,9 +300,10 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             }
         }
         for (int w = tid; w < NWORDS; w += FE2_NT) BM[w] = 0u;
-        if (tid == 0) PT[FE2_LH_CHIPS + FE2_NT * CPT] = 0.0f;  // first chip after the tile opens a block
     }
+    FE2_STAMP(1);
     __syncthreads();
+    FE2_STAMP(2);
 
     // logical LDS index of chip c (c = 0 is the extra halo chip, tile chips start at 49)
     auto chip_base = [](int c) __attribute__((always_inline)) { return LHP - LH + c * SPC; };
@@ -248,7 +311,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     const int run_base = LHP + tid * R;                    // == chip_base(c0)
 
     float bbv[R];                                          // this thread's run of bb
-    // halo chip handled additionally by threads 0..64: 48 left-halo chips, 17 right-halo chips
+    // halo chip handled additionally by the lanes of wave 0: 48 left-halo chips, 9 right-halo chips
     const int hq = (tid < AM_CHIPS_AVG) ? (1 + tid) : (FE2_LH_CHIPS + FE2_NT * CPT + (tid - AM_CHIPS_AVG));
     const bool has_halo = tid < FE2_HALO_THREADS;
     // absolute index of the last valid sample + 1, as a logical LDS index (bb beyond it reads 0)
@@ -259,17 +322,17 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
     const bool do_pmf = a.use_pmf && SPC > 1 && !(a.ablate & 1u);
     float hb[SPC] = {};
     if (has_halo) {
-        fe2_lds_load<SPC, false>(X, chip_base(hq), hb);
+        fe2_lds_load<SPC, false, CHIP_IG>(X, chip_base(hq), hb);
         if (do_pmf) {
             float hp[SPC];
-            fe2_lds_load<SPC, false>(X, chip_base(hq) - SPC, hp);
+            fe2_lds_load<SPC, false, CHIP_IG>(X, chip_base(hq) - SPC, hp);
             fe2_pmf_chip<SPC>(hp, &hb[0], a.s1);
         }
     }
-    fe2_lds_load<R, RUN_AL>(X, run_base, bbv);             // |.|^2 of the run
+    fe2_lds_load<R, RUN_AL, RUN_IG>(X, run_base, bbv);             // |.|^2 of the run
     if (do_pmf) {
         float mp[SPC];
-        fe2_lds_load<SPC, CHIP_AL && RUN_AL>(X, run_base - SPC, mp);
+        fe2_lds_load<SPC, CHIP_AL && RUN_AL, CHIP_IG>(X, run_base - SPC, mp);
         // last chip first: chip k still needs the raw |iq|^2 of chip k-1
 #pragma unroll
         for (int k = CPT - 1; k >= 0; --k) {
@@ -283,12 +346,14 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             }
         }
     }
-    // samples beyond the end of the stream read as zero (preamble view pads with zeros)
+    if constexpr (EDGE) {
+        // samples beyond the end of the stream read as zero (preamble view pads with zeros)
 #pragma unroll
-    for (int i = 0; i < R; ++i) if (run_base + i >= end_li) bbv[i] = 0.0f;
-    if (has_halo) {
+        for (int i = 0; i < R; ++i) if (run_base + i >= end_li) bbv[i] = 0.0f;
+        if (has_halo) {
 #pragma unroll
-        for (int i = 0; i < SPC; ++i) if (chip_base(hq) + i >= end_li) hb[i] = 0.0f;
+            for (int i = 0; i < SPC; ++i) if (chip_base(hq) + i >= end_li) hb[i] = 0.0f;
+        }
     }
     // chip totals in both directions (canonical level-1 sums)
 #pragma unroll
@@ -310,9 +375,11 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         TOT[hq] = f;
         RTOT[hq] = b;
     }
+    FE2_STAMP(3);
     __syncthreads();                                       // everyone has read its |.|^2
-    fe2_lds_store<R, RUN_AL>(X, run_base, bbv);
-    if (has_halo) fe2_lds_store<SPC, false>(X, chip_base(hq), hb);
+    FE2_STAMP(4);
+    fe2_lds_store<R, RUN_AL, RUN_IG>(X, run_base, bbv);
+    if (has_halo) fe2_lds_store<SPC, false, CHIP_IG>(X, chip_base(hq), hb);
 
     // ---- P4: exclusive prefix / suffix of chip totals inside each 48-chip block ----------------
     // (the 48 totals are fetched in one batch; the additions keep the canonical sequential order)
@@ -335,7 +402,9 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
             for (int j = 0; j < AM_CHIPS_AVG; ++j) PT[qb + j] = t[j];
         }
     }
+    FE2_STAMP(5);
     __syncthreads();
+    FE2_STAMP(6);
 
     // ---- P5: reference level (a4) + first-stage preamble test (a6) ------------------------------
     float avgv[R];
@@ -351,7 +420,7 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         // in-chip suffix sums of the chip 48 chips back
         float scv[SPC];
         {
-            fe2_lds_load<SPC, CHIP_AL && RUN_AL>(X, chip_base(q - AM_CHIPS_AVG), scv);
+            fe2_lds_load<SPC, CHIP_AL && RUN_AL, CHIP_IG>(X, chip_base(q - AM_CHIPS_AVG), scv);
             float acc = 0.0f;
 #pragma unroll
             for (int i = SPC - 1; i >= 0; --i) { acc = acc + scv[i]; scv[i] = acc; }
@@ -375,56 +444,68 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const long long o = (long long)jt0 + tid * R + i;
-            if (o < a.out_n) a.avg[o] = avgv[i];
+            if (!EDGE || o < a.out_n) a.avg[o] = avgv[i];
         }
     }
-    // a6, branch-free: the pulses 2, 7 and 9 chips ahead are the same run shifted, fetched with
-    // wide LDS loads; the result is one bit per sample
+    FE2_STAMP(7);
+    // a6, branch-free.  Each test is a per-sample bool (a lane mask in scalar registers, combined
+    // on the scalar unit); the pulses 2, 7 and 9 chips ahead are the same run shifted, fetched with
+    // wide LDS loads.  The result is folded into one bit per sample at the end.
     static_assert(R <= 32, "one candidate word per thread");
-    uint32_t cmask[1] = {0u};
+    uint32_t cm = 0u;
     if (!(a.ablate & 64u)) {
-        uint32_t cm = 0u;
+        constexpr int CH = (R % 16 == 0) ? 16 : R;           // samples per pass (scalar register budget)
+        static_assert(R % CH == 0, "passes tile the run");
         const float nxt = X[fe2_pidx(run_base + R)];
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const float x = bbv[i];
-            const float thr = avgv[i] * a.thr_lin;                       // preamble_impl.cc:173
-            const float nx = (i + 1 < R) ? bbv[(i + 1 < R) ? i + 1 : i] : nxt;
-            const uint32_t j = jt0 + (uint32_t)(tid * R + i);
-            const bool c = (x > thr) && !(nx > x) && j >= a.j0 && j < a.j1;   // :174, :175
-            cm |= (c ? 1u : 0u) << i;
-        }
-        constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
+        for (int h = 0; h < R; h += CH) {
+            bool c[CH];
+            float thr[CH];
+            bool any = false;
 #pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            // wave-uniform early out: in quiet stretches no lane has a survivor left
-            if (__ballot(cm != 0u) == 0ull) break;
-            float t[R];
-            fe2_lds_load<R, SHIFT_AL>(X, run_base + offs[o], t);
-            uint32_t below = 0u;
+            for (int i = 0; i < CH; ++i) {
+                const float x = bbv[h + i];
+                thr[i] = avgv[h + i] * a.thr_lin;                        // preamble_impl.cc:173
+                const float nx = (h + i + 1 < R) ? bbv[(h + i + 1 < R) ? h + i + 1 : h + i] : nxt;
+                c[i] = (x > thr[i]) & !(nx > x);                         // :174, :175
+                if constexpr (EDGE) {
+                    const uint32_t j = jt0 + (uint32_t)(tid * R + h + i);
+                    c[i] = c[i] & (j >= a.j0) & (j < a.j1);
+                }
+                any = any | c[i];
+            }
+            constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
 #pragma unroll
-            for (int i = 0; i < R; ++i) below |= ((t[i] < avgv[i] * a.thr_lin) ? 1u : 0u) << i;   // :177-179
-            cm &= ~below;
-        }
-        cmask[0] = cm;
-        if constexpr (R == 32) {
-            BM[tid] = cmask[0];
-        } else {
+            for (int o = 0; o < 3; ++o) {
+                // wave-uniform early out: in quiet stretches no lane has a survivor left
+                if (__ballot(any) == 0ull) break;
+                float t[CH];
+                fe2_lds_load<CH, SHIFT_AL && (CH % 4 == 0), (SPC % CH == 0) && (32 % CH == 0)>(X, run_base + offs[o] + h, t);
+                any = false;
 #pragma unroll
-            for (int w = 0; w < (R + 31) / 32; ++w) {
-                if (cmask[w]) {
-                    const int bit0 = tid * R + 32 * w;          // first sample this word describes
-                    const unsigned long long wide = (unsigned long long)cmask[w] << (bit0 & 31);
-                    atomicOr(&BM[bit0 >> 5], (uint32_t)wide);
-                    if ((uint32_t)(wide >> 32)) atomicOr(&BM[(bit0 >> 5) + 1], (uint32_t)(wide >> 32));
+                for (int i = 0; i < CH; ++i) {
+                    c[i] = c[i] & !(t[i] < thr[i]);                      // :177-179
+                    any = any | c[i];
                 }
             }
-        }
-        RUNANY[tid] = 0u;
 #pragma unroll
-        for (int w = 0; w < (R + 31) / 32; ++w) if (cmask[w]) RUNANY[tid] = 1u;
+            for (int i = 0; i < CH; ++i) cm |= c[i] ? (1u << (h + i)) : 0u;
+        }
+        if constexpr (R == 32) {
+            BM[tid] = cm;
+        } else {
+            if (cm) {
+                const int bit0 = tid * R;                       // first sample this word describes
+                const unsigned long long wide = (unsigned long long)cm << (bit0 & 31);
+                atomicOr(&BM[bit0 >> 5], (uint32_t)wide);
+                if ((uint32_t)(wide >> 32)) atomicOr(&BM[(bit0 >> 5) + 1], (uint32_t)(wide >> 32));
+            }
+        }
+        RUNANY[tid] = cm ? 1u : 0u;
     }
+    FE2_STAMP(8);
     __syncthreads();
+    FE2_STAMP(9);
 
     // split mode: the refinement kernels need avg[e] for e in a candidate's run or the next one;
     // write those runs only (plus the tile's first run, for candidates at the end of the previous tile)
@@ -434,13 +515,15 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
 #pragma unroll
             for (int i = 0; i < R; ++i) {
                 const long long o = (long long)jt0 + tid * R + i;
-                if (o < a.out_n) a.avg_sparse[o] = avgv[i];
+                if (!EDGE || o < a.out_n) a.avg_sparse[o] = avgv[i];
             }
         }
     }
 
+    FE2_STAMP(10);
     // ---- P6: bb out (coalesced), ordered candidate list ---------------------------------------------
-    if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
+    if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T, EDGE>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
+    FE2_STAMP(11);
     uint32_t total = 0;
     uint32_t *seg = a.seg_pos + (size_t)tile * T;
     {
@@ -478,12 +561,37 @@ __global__ void __launch_bounds__(FE2_NT, 3) am_k_fe2(am_fe2_args a)
         }
         if (tid == 0) a.blk_cnt[tile] = total;
     }
+    FE2_STAMP(12);
+}
+
+template <int SPC, int CPT>
+__global__ void __launch_bounds__(FE2_NT, FE2_WPS) am_k_fe2(am_fe2_args a)
+{
+    constexpr int R = SPC * CPT, T = FE2_NT * R, LH = FE2_LH_CHIPS * SPC, RH = FE2_RH_CHIPS * SPC;
+    constexpr int W = LH + T + RH;
+    HIP_DYNAMIC_SHARED(float, smem);
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous range of
+    // tiles so that neighbouring tiles (which share the halo) share an L2.  The order is reversed so
+    // that the (slower) edge tiles at the end of the stream are dispatched first, not last.
+    const unsigned nb = a.ntiles;
+    const unsigned per = (nb + 7u) / 8u;
+    const unsigned fwd = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
+    if (fwd >= nb) return;                                  // whole workgroup (uniform)
+    const unsigned tile = nb - 1u - fwd;
+    if (a.ablate & 1024u) { if (threadIdx.x == 0) a.blk_cnt[tile] = 0; return; }
+    const long long jt0 = (long long)tile * T;              // array coordinate of the tile start
+    const long long rel0 = a.out_abs0 + jt0 - LH - a.src_abs0;
+    const bool interior = rel0 >= 1 && rel0 + W + 2 <= a.src_abs1 - a.src_abs0 &&
+                          (reinterpret_cast<uintptr_t>(a.iq) & 15u) == 0 && jt0 >= (long long)a.j0 &&
+                          jt0 + T <= (long long)a.j1 && jt0 + T <= a.out_n && !(a.ablate & (16u | 2048u));
+    if (interior) fe2_tile<SPC, CPT, false>(a, tile, smem);
+    else fe2_tile<SPC, CPT, true>(a, tile, smem);
 }
 
 template <int SPC, int CPT>
 static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *ntiles, unsigned *tile_len)
 {
-    constexpr int R = SPC * CPT, T = FE2_NT * R, LH = FE2_LH_CHIPS * SPC, LHP = (LH + 31) & ~31;
+    constexpr int R = SPC * CPT, T = FE2_NT * R, LH = FE2_LH_CHIPS * SPC, LHP = fe2_lhp(LH);
     constexpr int RH = FE2_RH_CHIPS * SPC;
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;
     constexpr int NWORDS = (T + 31) / 32;
@@ -500,8 +608,29 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
     if (rc != hipSuccess) return rc;
     const unsigned grid = ((a.ntiles + 7u) / 8u) * 8u;     // whole XCD rounds (extra groups exit)
+    // profiling only: per-phase clock stamps, printed as average cycles between stamps (blocking)
+    static const bool want_clk = getenv("AIRMODES_FE2_CLOCK") != nullptr;
+    a.clk = nullptr;
+    if (want_clk && hipMalloc(reinterpret_cast<void **>(&a.clk), (size_t)a.ntiles * 32 * sizeof(long long)) != hipSuccess)
+        a.clk = nullptr;
     hipLaunchKernelGGL((am_k_fe2<SPC, CPT>), dim3(grid), dim3(FE2_NT), lds_req, s, a);
-    return hipGetLastError();
+    hipError_t lrc = hipGetLastError();
+    if (a.clk) {
+        std::vector<long long> h((size_t)a.ntiles * 32);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), a.clk, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+        (void)hipFree(a.clk);
+        for (int w = 0; w < 2; ++w) {
+            double acc[13] = {};
+            unsigned cnt = 0;
+            for (unsigned t = 1; t + 2 < a.ntiles; ++t, ++cnt)       // interior tiles
+                for (int k = 1; k <= 12; ++k) acc[k] += (double)(h[t * 32 + w * 16 + k] - h[t * 32 + w * 16 + k - 1]);
+            fprintf(stderr, "fe2 clock wave %d:", w ? 5 : 0);
+            for (int k = 1; k <= 12; ++k) fprintf(stderr, " %d:%.0f", k, cnt ? acc[k] / cnt : 0.0);
+            fprintf(stderr, "\n");
+        }
+    }
+    return lrc;
 }
 
 // Geometry only (buffer sizing): tile length for a supported spc, 0 if there is no specialisation.

@@ -32,6 +32,7 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __shared__ static
 #define __constant__
 #define __launch_bounds__(...)
+static inline long long clock64() { return 0; }
 #define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(hipemu::dyn_smem());
 
 typedef int hipError_t;
