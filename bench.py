@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=None, help="signal seconds per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (contexts/streams driven by host threads)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 3-batches-in-flight figure (profiling runs)")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
     args = ap.parse_args()
 
@@ -127,7 +128,7 @@ def main():
     dt = time.perf_counter() - t0
     npk = len(pk)
     pipelined = None
-    if world == 1 and not args.force_sharded and inflight == 1 and args.steps >= 3:
+    if world == 1 and not args.force_sharded and inflight == 1 and args.steps >= 3 and not args.no_pipelined:
         # additional figure: the same steps with 3 batches in flight (3 contexts / HIP streams driven by
         # 3 host threads): the launch-latency-bound tail of one batch overlaps the streaming kernel of the
         # next.  Reported separately so that `value`, `roofline` and the rocprof summaries stay one-to-one.

@@ -1,0 +1,70 @@
+"""File-source subset of the reference's command-line receiver (apps/modes_rx:32-110,
+python/radio.py:90-118,221-234):
+
+    python -m air_modes.modes_rx -s capture.cf32 -r 2e6 [-T 7.0] [--no-pmf] [-l lat,lon] [-n] [--raw]
+
+Reads a gr_complex file (interleaved little-endian float32 I,Q -- what
+blocks.file_source(gr.sizeof_gr_complex, path) reads), pushes it through air_modes.rx_path on
+the GPU chunk by chunk, and prints one line per decoded report in the reference's format
+(python/msprint.py), or the slicer's raw messages with --raw.
+
+Differences from modes_radio, all of them outside the demodulator: no live sources (UHD / osmocom /
+UDP), no ZeroMQ relay (the parser is called directly) and no resampling of sub-4-Msps input to
+4 Msps (radio.py:49-53) -- the rate given is the processing rate.
+"""
+import argparse
+import sys
+
+import numpy as np
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog="modes_rx", description=__doc__.split("\n\n")[0])
+    ap.add_argument("-s", "--source", required=True, help="gr_complex (cf32) file")        # radio.py:94
+    ap.add_argument("-r", "--rate", type=float, default=4e6, help="sample rate [default=%(default)s]")   # :112
+    ap.add_argument("-T", "--threshold", type=float, default=7.0,
+                    help="pulse detection threshold above noise in dB [default=%(default)s]")            # :114
+    ap.add_argument("-p", "--pmf", action="store_true", default=True, help="use pulse matched filtering")  # :116
+    ap.add_argument("--no-pmf", dest="pmf", action="store_false")
+    ap.add_argument("-l", "--location", default=None, help="receiver position as lat,lon (enables range/bearing "
+                    "and surface positions)")                                                            # modes_rx:40
+    ap.add_argument("-n", "--no-print", action="store_true", help="do not print decoded reports")       # modes_rx:45
+    ap.add_argument("--raw", action="store_true", help="print the slicer's raw messages instead of parsed reports")
+    ap.add_argument("--chunk", type=int, default=1 << 22, help="complex samples per GPU call")
+    return ap
+
+
+def main(argv=None, out=None):
+    args = build_parser().parse_args(argv)
+    out = out or sys.stdout
+    from . import cpr_decoder, make_parser, msg_queue, output_print, pubsub, rx_path
+
+    queue = msg_queue()
+    rx = rx_path(args.rate, args.threshold, queue, use_pmf=args.pmf)
+    publisher = pubsub()
+    feed = make_parser(publisher)
+    my_position = [float(n) for n in args.location.split(",")] if args.location else None
+    if not args.no_print and not args.raw:
+        output_print(cpr_decoder(my_position), publisher, callback=lambda line: print(line, file=out))
+    print("Using file source %s" % args.source, file=sys.stderr)
+    print("Rate is %i" % int(args.rate), file=sys.stderr)
+    with open(args.source, "rb") as f:
+        while True:
+            raw = np.fromfile(f, dtype=np.float32, count=2 * args.chunk)
+            last = raw.size < 2 * args.chunk
+            rx.work(raw[: raw.size // 2 * 2], flush=last)
+            while not queue.empty_p():
+                text = queue.delete_head().to_string()
+                if args.raw:
+                    if not args.no_print:
+                        print(text, file=out)
+                else:
+                    feed(text)
+            if last:
+                break
+    print("%d samples, %d packets" % (rx.samples, rx.packets), file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
