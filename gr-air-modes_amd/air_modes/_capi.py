@@ -99,6 +99,8 @@ class Library(object):
         L.am_last_error.restype = C.c_char_p
         L.am_last_error.argtypes = [vp]
         L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
+        L.am_last_num_candidates.restype = C.c_longlong
+        L.am_last_num_candidates.argtypes = [vp]
         self.L = L
         if L.am_abi_version() != 1:
             raise OSError("ABI version mismatch in %s" % path)
@@ -181,6 +183,9 @@ class Context(object):
 
     def last_num_tags(self):
         return int(self.lib.L.am_last_num_tags(self._h))
+
+    def last_num_candidates(self):
+        return int(self.lib.L.am_last_num_candidates(self._h))
 
     def last_timing(self):
         a, b = C.c_float(0), C.c_float(0)

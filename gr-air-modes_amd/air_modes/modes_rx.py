@@ -59,7 +59,13 @@ def main(argv=None, out=None):
                     if not args.no_print:
                         print(text, file=out)
                 else:
-                    feed(text)
+                    try:
+                        feed(text)
+                    except (IndexError, KeyError, ValueError) as err:
+                        # table lookups the reference does unguarded (e.g. emitter category 7 in category
+                        # set B, python/parse.py:274-280): there the exception ends the subscriber thread,
+                        # here the report is skipped and the receiver keeps going
+                        print("skipped %s: %r" % (text.split()[0], err), file=sys.stderr)
             if last:
                 break
     print("%d samples, %d packets" % (rx.samples, rx.packets), file=sys.stderr)

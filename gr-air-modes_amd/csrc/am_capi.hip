@@ -37,6 +37,8 @@ struct am_ctx {
     float thr_lin = 0.0f;
     int use_pmf = 0;
     int tile = 0;
+    bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
+    bool chain_tables = false;    // AIRMODES_CHAIN_TABLES=1: radix-16 jump tables instead of the blocked chain
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     bool fe2_inkernel = false;    // AIRMODES_FE2_INKERNEL=1: refine inside the fused kernel (A/B testing)
     bool no_span = true;          // AIRMODES_SPAN=1: experimental per-wave span kernel instead of the tiled fused kernel
@@ -53,7 +55,7 @@ struct am_ctx {
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, seg_e, seg_inavg, seg_valid, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         visited, emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
-        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab;
+        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch;
 
     // results of the last scan
     std::vector<am_packet> h_packets;   // every sliced burst, reserved[0] = accepted
@@ -341,7 +343,7 @@ int chain_build(am_ctx *c, uint32_t M)
 // Fills h_packets / h_tags (+ h_bursts).
 int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, uint64_t base_abs,
                  bool keep_bursts, uint32_t *final_cur, uint32_t max_hits, uint32_t own_lo = 0,
-                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
+                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0, bool marked = false)
 {
     const uint32_t M = c->chain_M;
     c->h_packets.clear();
@@ -354,11 +356,13 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     const size_t stride = c->chain_stride;
     uint32_t *jump = (uint32_t *)c->jump.p;
     (void)stride;
-    HIPCHK(c, am_launch_chain_init((uint32_t *)c->pos.p, M, cur0, (uint8_t *)c->visited.p,
-                                   (uint32_t *)c->scalars.p, c->stream));
-    for (int k = levels; k >= 0; k--)
-        HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, AM_CHAIN_RADIX,
-                                       c->stream));
+    if (!marked) {
+        HIPCHK(c, am_launch_chain_init((uint32_t *)c->pos.p, M, cur0, (uint8_t *)c->visited.p,
+                                       (uint32_t *)c->scalars.p, c->stream));
+        for (int k = levels; k >= 0; k--)
+            HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, AM_CHAIN_RADIX,
+                                           c->stream));
+    }
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
@@ -393,7 +397,9 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     c->pin_scalars[1] = cur0;
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, c->pin_tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
                               c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tail_synced = true;
     const uint32_t n_emit = c->pin_scalars[0];
     *final_cur = c->pin_scalars[1];
     if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
@@ -416,9 +422,26 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *, uint32_t M, u
     c->h_bursts.clear();
     c->last_M = M;
     *final_cur = cur0;
-    int rc = chain_build(c, M);
-    if (rc != AM_OK || M == 0) return rc;
-    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits);
+    if (c->chain_tables || M == 0 || am_chain_blocked_scratch(M) / sizeof(uint32_t) > 0xFFFFFFFFull) {
+        int rc = chain_build(c, M);
+        if (rc != AM_OK || M == 0) return rc;
+        return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits);
+    }
+    // blocked chain: successor array only (no jump tables), visited[] from three LDS-resident launches
+    c->chain_M = M;
+    c->chain_levels = 0;
+    c->chain_stride = (size_t)M + 1;
+    ENSURE(c, c->visited, c->chain_stride);
+    ENSURE(c, c->emit, c->chain_stride);
+    ENSURE(c, c->jump, c->chain_stride * sizeof(uint32_t));
+    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    ENSURE(c, c->cscratch, am_chain_blocked_scratch(M));
+    HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, 0, (uint32_t *)c->jump.p, nullptr,
+                                   c->stream));
+    HIPCHK(c, am_launch_chain_blocked((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, c->spc,
+                                      (uint32_t *)c->cscratch.p, (uint8_t *)c->visited.p, (uint32_t *)c->scalars.p,
+                                      c->stream));
+    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits, 0, 0xFFFFFFFFu, 0, true);
 }
 
 void collect_accepted(am_ctx *c)
@@ -506,6 +529,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->fe2_inkernel = ik && ik[0] == '1';
             const char *ns = getenv("AIRMODES_SPAN");
             c->no_span = !(ns && ns[0] == '1');
+            const char *ct = getenv("AIRMODES_CHAIN_TABLES");
+            c->chain_tables = ct && ct[0] == '1';
         }
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
@@ -536,7 +561,7 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->exit_tab};
+                     &c->recs, &c->exit_tab, &c->cscratch};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -592,6 +617,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->tail_synced = false;
 
     // 1. one contiguous device view of [src_abs0, S1): carried tail + new samples
     const float *src = nullptr;
@@ -671,13 +697,18 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
             HIPCHK(c, hipMemcpyAsync(c->carry2.p, src + (C0 - src_abs0) * 2, keep * 2 * sizeof(float),
                                      hipMemcpyDeviceToDevice, c->stream));
             std::swap(c->carry, c->carry2);
+            c->tail_synced = false;
         }
         c->carry_abs0 = C0;
         c->carry_n = keep;
         c->total_in = S1;
     }
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->tail_synced) {
+        // something was enqueued after the scan's own synchronisation (or no scan ran): the input
+        // buffer must not be reused by the caller before the device is done with it
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
     (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
     return hand_out(c, out, cap, n_out);
@@ -975,6 +1006,11 @@ int am_last_timing(const am_ctx *c, float *total_ms, float *dom_ms)
     if (total_ms) *total_ms = c->last_total_ms;
     if (dom_ms) *dom_ms = c->last_dom_ms;
     return AM_OK;
+}
+
+long long am_last_num_candidates(const am_ctx *c)
+{
+    return c ? (long long)c->last_M : (long long)AM_EINVAL;
 }
 
 } // extern "C"

@@ -105,6 +105,9 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
                             float *inavg, uint8_t *valid, hipStream_t s);
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
                                 uint32_t *jump0, uint8_t *visited, hipStream_t s);
+size_t am_chain_blocked_scratch(uint32_t M);
+hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0, int spc,
+                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s);
 hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s);
 hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s);
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,

@@ -499,38 +499,85 @@ __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_l
     return off_local[c] + blk_base[c / AM_SCAN_BLK];
 }
 
+// E(q) for every compact index.  One workgroup owns AM_ECB consecutive candidates, whose compact
+// indices form one contiguous range [off(c0), off(c0 + AM_ECB)): their offsets, positions and counts
+// sit in LDS, so a lane finds the candidate of its index with an LDS binary search (no dependent
+// global loads).  Consecutive compact indices are consecutive positions except where two candidates
+// lie more than spc + 1 apart, so the 256 positions of a pass read one short stretch of bb
+// (256 + 10*spc samples, each sample up to 4*spc times): it is staged in LDS once and every lane
+// runs its own sequential double sum (pulse 0, 2, 7, 9; ascending within a pulse:
+// preamble_impl.cc:91-98) from there.
+#define AM_ECB 64                   /* candidates per workgroup (about one 256-lane pass of positions) */
+#define AM_ESTAGE 2048              /* floats of bb a pass may stage (8 KB) */
+
 __global__ void __launch_bounds__(256)
 am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,
             const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t M, int spc,
             double *__restrict__ energy)
 {
-    __shared__ uint32_t cb[2];
-    const uint32_t nb = (M + AM_SCAN_BLK - 1) / AM_SCAN_BLK;
-    const uint32_t total = blk_base[nb];                     // number of positions that need an energy
-    for (uint32_t k0 = blockIdx.x * blockDim.x; k0 < total; k0 += gridDim.x * blockDim.x) {
-        // The 256 consecutive compact indices of this workgroup belong to a short run of candidates:
-        // two lanes bracket it with a full binary search, the others search inside the bracket.
-        if (threadIdx.x < 2) {
-            uint32_t key = threadIdx.x == 0 ? k0 : k0 + blockDim.x - 1;
-            if (key >= total) key = total - 1;
-            uint32_t lo = 0, hi = M;
+    __shared__ uint32_t coff[AM_ECB + 1];   // compact offset of each candidate of this group (+ end)
+    __shared__ uint32_t cq[AM_ECB];         // position of the candidate's first compact index
+    __shared__ uint32_t qr[2];
+    __shared__ float W[AM_ESTAGE];
+    const uint32_t c0 = blockIdx.x * AM_ECB;
+    if (c0 >= M) return;
+    const uint32_t nc = (M - c0 < AM_ECB) ? M - c0 : AM_ECB;
+    {
+        const uint32_t i = threadIdx.x;
+        if (i < nc) {
+            const uint32_t c = c0 + i;
+            const uint32_t o = am_off_at(off_local, blk_base, c);
+            const uint32_t d = dcount[c];
+            coff[i] = o;
+            cq[i] = pos[c] + (uint32_t)spc + 1u - d;
+            if (i == nc - 1) coff[nc] = o + d;
+        }
+    }
+    __syncthreads();
+    const uint32_t kbeg = coff[0], kend = coff[nc];
+    for (uint32_t k0 = kbeg; k0 < kend; k0 += blockDim.x) {
+        const uint32_t k = k0 + threadIdx.x;
+        const uint32_t klast = (k0 + blockDim.x - 1 < kend) ? k0 + blockDim.x - 1 : kend - 1;
+        uint32_t q = 0;
+        if (k < kend) {
+            uint32_t lo = 0, hi = nc;                        // last candidate with coff <= k
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (am_off_at(off_local, blk_base, mid) <= key) lo = mid; else hi = mid;
+                if (coff[mid] <= k) lo = mid; else hi = mid;
             }
-            cb[threadIdx.x] = lo;
+            q = cq[lo] + (k - coff[lo]);
+            if (k == k0) qr[0] = q;                          // k -> q is strictly increasing
+            if (k == klast) qr[1] = q;
         }
         __syncthreads();
-        const uint32_t k = k0 + threadIdx.x;
-        if (k < total) {
-            // candidate that contributed compact index k: last c with off[c] <= k
-            uint32_t lo = cb[0], hi = cb[1] + 1;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (am_off_at(off_local, blk_base, mid) <= k) lo = mid; else hi = mid;
+        const uint32_t w0 = qr[0] & ~3u;                     // 16-byte aligned start of the window
+        const uint32_t wn = qr[1] + 10u * (uint32_t)spc - w0;   // samples q .. q + 10*spc - 1 of every lane
+        if (wn <= AM_ESTAGE) {
+            for (uint32_t i = 4u * threadIdx.x; i < wn; i += 4u * blockDim.x) {
+                const float4 t = *reinterpret_cast<const float4 *>(bb + w0 + i);   // (arrays are padded)
+                *reinterpret_cast<float4 *>(&W[i]) = t;
             }
-            const uint32_t q = pos[lo] + (uint32_t)spc + 1u - dcount[lo] + (k - am_off_at(off_local, blk_base, lo));
-            energy[k] = am_preamble_energy(bb + q, spc);     // preamble_impl.cc:91-98
+            __syncthreads();
+            if (k < kend) {
+                const float *p = W + (q - w0);
+                double e = 0.0;
+                const int offs[4] = {0, 2 * spc, 7 * spc, 9 * spc};
+                for (int pu = 0; pu < 4; ++pu) {
+                    const float *pp = p + offs[pu];
+                    int i = 0;
+                    for (; i + 8 <= spc; i += 8) {
+                        float t[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) t[u] = pp[i + u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) e += (double)t[u];
+                    }
+                    for (; i < spc; ++i) e += (double)pp[i];
+                }
+                energy[k] = e;
+            }
+        } else if (k < kend) {
+            energy[k] = am_preamble_energy(bb + q, spc);     // sparse candidates: straight from memory
         }
         __syncthreads();
     }
@@ -589,10 +636,7 @@ hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t
                             double *energy, hipStream_t s)
 {
     if (M == 0) return hipSuccess;
-    // grid-stride over a device-side count: no host round trip for the number of positions
-    uint64_t bound = (uint64_t)M * (uint64_t)(spc + 1);
-    unsigned grid = (unsigned)((bound + 255) / 256);
-    if (grid > 8192u) grid = 8192u;
+    const unsigned grid = (unsigned)(((uint64_t)M + AM_ECB - 1) / AM_ECB);
     hipLaunchKernelGGL(am_k_energy, dim3(grid), dim3(256), 0, s, bb, pos, dcount, off_local, blk_base, M, spc,
                        energy);
     return hipGetLastError();
@@ -749,6 +793,155 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Blocked greedy chain (single-GPU path).  The radix-16 tables above cost ~15 dependent global
+// loads per level and launch; but a successor is never far away (a jump spans at most
+// 241*spc + 1 positions), so the candidates are cut into blocks of AM_CB nodes and
+//   1. am_k_cblk_exit : per block, in LDS: for EVERY node the first node of its orbit that lies
+//      beyond the block (pointer jumping on the block's successor array), plus the size of the
+//      block's "head" -- the nodes a jump from an earlier block can land on;
+//   2. am_k_cblk_walk : one workgroup copies the heads' exit nodes to LDS and one lane walks
+//      block to block (one LDS read per block): the node at which the scan enters each block;
+//   3. am_k_cblk_mark : per block, in LDS: log2(AM_CB) jump levels, top-down marking from the
+//      block's entry node, visited[] out.
+// Three launches with a handful of dependent global loads in all.
+// ------------------------------------------------------------------------------------------
+#define AM_CB 2048                  /* nodes per block */
+#define AM_CB_THREADS 256
+#define AM_CB_PER (AM_CB / AM_CB_THREADS)
+#define AM_CB_LEVELS 11             /* 2^11 = AM_CB */
+#define AM_CB_HEADW 128             /* head nodes per block the walk keeps in LDS ... */
+#define AM_CB_HEADCAP 36864         /* ... as long as all of them fit (144 KB) */
+#define AM_CB_NONE 0xFFFFFFFFu
+
+__global__ void __launch_bounds__(AM_CB_THREADS)
+am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ jump0, uint32_t M, uint32_t headw,
+               uint32_t cur0, uint32_t *__restrict__ exitnode, uint32_t *__restrict__ headexit,
+               uint32_t *__restrict__ root)
+{
+    __shared__ uint32_t e[2][AM_CB];
+    const uint32_t base = blockIdx.x * AM_CB;
+    const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
+    const uint32_t n = end - base;
+    for (int k = 0; k < AM_CB_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+        e[0][i] = (i < n) ? jump0[base + i] : end;
+        // root of the scan = first candidate with pos >= cur0: exactly one node (or the end) qualifies
+        if (i < n) {
+            const uint32_t g = base + i;
+            if (pos[g] >= cur0 && (g == 0 || pos[g - 1] < cur0)) *root = g;
+            if (g == M - 1 && pos[g] < cur0) *root = M;
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int r = 0; r < AM_CB_LEVELS; ++r) {                 // successors strictly increase: <= 2^11 hops inside
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            const uint32_t t = e[cur][i];
+            e[cur ^ 1][i] = (t < end) ? e[cur][t - base] : t;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    for (int k = 0; k < AM_CB_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+        if (i < n) exitnode[base + i] = e[cur][i];
+        // the block's head (the nodes a jump from an earlier block can land on: a jump spans at most
+        // 241*spc + 1 positions, a few dozen candidates) once more, densely, for the walk's LDS copy
+        if (i < headw) headexit[(size_t)blockIdx.x * headw + i] = (i < n) ? e[cur][i] : M;
+    }
+}
+
+// entry[b] = node at which the scan enters block b, AM_CB_NONE if it jumps over the block.
+// scalars[0] = cur0, scalars[1] = 0 (as am_k_chain_init leaves them).
+__global__ void __launch_bounds__(1024)
+am_k_cblk_walk(const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ headexit,
+               const uint32_t *__restrict__ root, uint32_t M, uint32_t nblk, uint32_t headw, uint32_t cur0,
+               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars)
+{
+    HIP_DYNAMIC_SHARED(uint32_t, hx);          // [nblk * headw] exit nodes of the heads
+    const uint32_t total = nblk * headw;
+    // batches of 8 independent loads per thread (one memory round trip per batch, not per word)
+    for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t f = f0 + (uint32_t)k * blockDim.x;
+            t[k] = headexit[f < total ? f : total - 1u];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t f = f0 + (uint32_t)k * blockDim.x;
+            if (f < total) hx[f] = t[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        scalars[0] = cur0;
+        scalars[1] = 0u;
+        uint32_t cur = *root;
+        for (uint32_t b = 0; b < nblk; ++b) {
+            const uint32_t base = b * AM_CB;
+            const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
+            if (cur >= end) { entry[b] = AM_CB_NONE; continue; }
+            entry[b] = cur;
+            const uint32_t idx = cur - base;
+            cur = (idx < headw) ? hx[b * headw + idx] : exitnode[cur];    // (root, or an unusually long head)
+        }
+    }
+}
+
+__global__ void __launch_bounds__(AM_CB_THREADS)
+am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ entry, uint32_t M,
+               uint8_t *__restrict__ visited)
+{
+    __shared__ uint16_t J[AM_CB_LEVELS][AM_CB];
+    __shared__ uint8_t V[AM_CB];
+    const uint32_t base = blockIdx.x * AM_CB;
+    const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
+    const uint32_t n = end - base;
+    const uint32_t ent = entry[blockIdx.x];
+    if (ent == AM_CB_NONE) {                                  // uniform: the scan jumps over this block
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            if (i < n) visited[base + i] = 0;
+        }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) visited[M] = 0;
+        return;
+    }
+    const uint16_t OUT = (uint16_t)AM_CB;                    // "leaves the block"
+    for (int k = 0; k < AM_CB_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+        uint16_t t = OUT;
+        if (i < n) { const uint32_t j = jump0[base + i]; if (j < end) t = (uint16_t)(j - base); }
+        J[0][i] = t;
+        V[i] = (base + i == ent) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int l = 1; l < AM_CB_LEVELS; ++l) {
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            const uint16_t t = J[l - 1][i];
+            J[l][i] = (t == OUT) ? OUT : J[l - 1][t];
+        }
+        __syncthreads();
+    }
+    // top-down: every marked node marks the node 2^l hops ahead (marks only ever land on the orbit)
+    for (int l = AM_CB_LEVELS - 1; l >= 0; --l) {
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            if (V[i]) { const uint16_t t = J[l][i]; if (t != OUT) V[t] = 1; }
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < AM_CB_PER; ++k) {
+        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+        if (i < n) visited[base + i] = V[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) visited[M] = 0;
+}
+
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
@@ -784,6 +977,46 @@ hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M
     hipLaunchKernelGGL(am_k_chain_mark, dim3(am_grid(M, 256)), dim3(256), 0, s, jk, visited, M, hops);
     return hipGetLastError();
 }
+static uint32_t am_chain_headw(uint32_t nblk)
+{
+    uint32_t w = AM_CB_HEADW;
+    while (w > 1 && (uint64_t)nblk * w > AM_CB_HEADCAP) w >>= 1;
+    return ((uint64_t)nblk * w > AM_CB_HEADCAP) ? 0u : w;       // 0: every step of the walk reads global memory
+}
+
+size_t am_chain_blocked_scratch(uint32_t M)
+{
+    const size_t nblk = ((size_t)M + AM_CB - 1) / AM_CB;
+    // exitnode[M+1] | entry[nblk] | root | headexit[nblk * headw]
+    return ((size_t)M + 1 + nblk + 8 + nblk * am_chain_headw((uint32_t)nblk)) * sizeof(uint32_t);
+}
+
+// visited[] for the scan that starts at position cur0, given the successor array jump0[] (am_k_chain_succ)
+hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0, int spc,
+                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s)
+{
+    (void)spc;
+    if (M == 0) return hipSuccess;
+    const uint32_t nblk = (M + AM_CB - 1) / AM_CB;
+    const uint32_t headw = am_chain_headw(nblk);
+    uint32_t *exitnode = scratch, *entry = scratch + ((size_t)M + 1), *root = entry + nblk, *headexit = root + 8;
+    hipLaunchKernelGGL(am_k_cblk_exit, dim3(nblk), dim3(AM_CB_THREADS), 0, s, pos, jump0, M, headw, cur0, exitnode,
+                       headexit, root);
+    const size_t lds = ((size_t)nblk * headw + 1) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_cblk_walk),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)((AM_CB_HEADCAP + 1) * sizeof(uint32_t)));
+        if (rc != hipSuccess) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, exitnode, headexit, root, M, nblk, headw, cur0,
+                       entry, scalars);
+    hipLaunchKernelGGL(am_k_cblk_mark, dim3(nblk), dim3(AM_CB_THREADS), 0, s, jump0, entry, M, visited);
+    return hipGetLastError();
+}
+
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,

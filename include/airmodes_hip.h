@@ -191,6 +191,10 @@ const char *am_last_error(const am_ctx *ctx);
  * (front-end + detection) kernel.  Used by bench.py for the roofline line. */
 int am_last_timing(const am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
 
+/* Diagnostic: number of first-stage preamble candidates (positions passing preamble_impl.cc:172-179)
+ * the last scan refined and chained.  Negative error code on a null context. */
+long long am_last_num_candidates(const am_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

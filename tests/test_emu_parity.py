@@ -115,3 +115,22 @@ def test_crc_and_format_helpers(emu_lib):
     assert emu_lib.crc24(bytes.fromhex("8D4840D6202CC371C32CE0")) == int("576098", 16)
     for h in ("02E197B0A9A3B1", "8D40621D58C382D690C8AC2863A7"):
         assert emu_lib.crc24(bytes.fromhex(h)) == oracle.crc24(bytes.fromhex(h))
+
+
+@pytest.mark.parametrize("tables", ["0", "1"])
+def test_greedy_chain_many_blocks(emu_lib, monkeypatch, tables):
+    """Dense traffic: several thousand first-stage candidates per call, so the blocked chain runs
+    over many 2048-node blocks (and, with AIRMODES_CHAIN_TABLES=1, the radix-16 jump tables the
+    sharded path uses); resumed across calls at odd cut points."""
+    from air_modes import _capi
+    monkeypatch.setenv("AIRMODES_CHAIN_TABLES", tables)
+    rate = 8e6
+    iq, _ = synth.synth_capture(rate, 4000000, 20000.0, seed=606)
+    want = oracle.demod(iq, rate, 7.0, True)
+    ctx = _capi.Context(rate, 7.0, True, lib=emu_lib)
+    got = [ctx.process_iq(iq[:2000001], flush=False)]
+    m1 = ctx.last_num_candidates()
+    got.append(ctx.process_iq(iq[2000001:], flush=True))
+    ctx.close()
+    assert m1 > 3 * 2048, m1
+    assert np.array_equal(np.concatenate(got), want) and len(want) > 100
