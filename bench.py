@@ -116,7 +116,7 @@ def main():
         last = [r for r in results if r is not None]
         return last[-1] if last else None, [x for f in fe for x in f]
 
-    pk, _ = run_steps(max(args.warmup, inflight if args.warmup else 0))
+    pk, _ = run_steps(max(args.warmup, 3 * inflight if args.warmup else 0))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -134,7 +134,7 @@ def main():
         # next.  Reported separately so that `value`, `roofline` and the rocprof summaries stay one-to-one.
         inflight = 3
         ctxs = [ctx] + [_capi.Context(rate, 7.0, True, device=local) for _ in range(inflight - 1)]
-        run_steps(inflight)
+        run_steps(3 * inflight)            # every context past its first (allocating) and second (capacity) call
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         pk3, _ = run_steps(args.steps)

@@ -18,6 +18,9 @@
 
 namespace {
 
+// internal (never leaves this file): a speculative scan must be redone with the exact candidate count
+#define AM_RETRY_EXACT 1000
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -37,6 +40,19 @@ struct am_ctx {
     float thr_lin = 0.0f;
     int use_pmf = 0;
     int tile = 0;
+    // Speculative launches: the candidate count of a scan is only known on the device when its kernels
+    // are enqueued.  Instead of a host round trip in the middle of the pipeline, the streaming path
+    // launches for a capacity extrapolated from the previous scan (spec_cap) and lets the kernels clip
+    // to the device-side count (Mdev); the real count comes back with the results, and a scan whose
+    // count exceeded the capacity is redone with the exact count.
+    bool allow_spec = true;       // AIRMODES_NO_SPEC=1 disables
+    bool spec_now = false;        // this scan was launched for a capacity
+    const uint32_t *Mdev = nullptr;
+    double spec_density = 0.0;    // candidates per position, previous scan
+    double spec_floor = 16384.0;  // slack added to the extrapolated capacity (AIRMODES_SPEC_FLOOR, tests)
+    uint32_t ref_nseg = 0, ref_stride = 0, ref_endj = 0;   // arguments of the last run_refine (for the redo)
+    int ref_mode = 0;
+    const float *ref_bb = nullptr, *ref_avg = nullptr;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool chain_tables = false;    // AIRMODES_CHAIN_TABLES=1: radix-16 jump tables instead of the blocked chain
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
@@ -106,7 +122,9 @@ int ensure(am_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return AM_OK;
     if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
-    size_t want = bytes + bytes / 8 + 4096;
+    // grow with headroom (hipFree / hipMalloc synchronise the whole device): half as much again for the
+    // per-candidate arrays, whose size follows the traffic; an eighth for the big sample arrays
+    size_t want = bytes + (bytes < ((size_t)64 << 20) ? bytes / 2 + ((size_t)256 << 10) : bytes / 8);
     hipError_t rc = hipMalloc(&b.p, want);
     if (rc != hipSuccess) { b.p = nullptr; return fail(c, AM_ENOMEM, "hipMalloc", rc); }
     b.cap = want;
@@ -190,15 +208,27 @@ int run_frontend(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_ab
 // refinement kernel (generic path: candidates only) or the gather of the records the fused
 // kernel already produced.  Leaves the flat records (pos, e, tgt, inavg, valid) on the device.
 int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint32_t seg_stride, int mode,
-               uint32_t *M_out, uint32_t end_j = 0xFFFFFFFFu)
+               uint32_t *M_out, uint32_t end_j = 0xFFFFFFFFu, uint32_t spec_cap = 0)
 {
     *M_out = 0;
+    c->spec_now = false;
+    c->Mdev = nullptr;
     if (nseg == 0) return AM_OK;
     HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg, c->stream));
+    c->ref_bb = bb; c->ref_avg = avg; c->ref_nseg = nseg; c->ref_stride = seg_stride; c->ref_mode = mode;
+    c->ref_endj = end_j;
     uint32_t M = 0;
-    HIPCHK(c, hipMemcpyAsync(&M, (uint32_t *)c->blk_off.p + nseg, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                             c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t *Mp = nullptr;
+    if (spec_cap && mode == 2) {
+        M = spec_cap;                                        // capacity; the kernels clip to *Mp
+        Mp = (const uint32_t *)c->blk_off.p + nseg;
+        c->spec_now = true;
+        c->Mdev = Mp;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(&M, (uint32_t *)c->blk_off.p + nseg, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (M) {
         ENSURE(c, c->pos, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->e, ((size_t)M + 1) * sizeof(uint32_t));
@@ -215,16 +245,16 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             ENSURE(c, c->blk_base2, ((size_t)nb + 2) * sizeof(uint32_t));
             ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
             HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
-                                           c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream));
+                                           c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             HIPCHK(c, am_launch_exscan_blocks((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
-                                              (uint32_t *)c->blk_tot2.p, M, c->stream));
+                                              (uint32_t *)c->blk_tot2.p, M, c->stream, Mp));
             HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_tot2.p, (uint32_t *)c->blk_base2.p, nb, c->stream));
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
-                                       (uint32_t *)c->blk_base2.p, M, c->spc, (double *)c->energy.p, c->stream));
+                                       (uint32_t *)c->blk_base2.p, M, c->spc, (double *)c->energy.p, c->stream, Mp));
             HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
                                      (uint32_t *)c->off_local.p, (uint32_t *)c->blk_base2.p, (double *)c->energy.p, M,
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
-                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream));
+                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream, Mp));
         } else if (mode == 1)
             HIPCHK(c, am_launch_flatten((uint32_t *)c->cand_seg.p, (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p,
                                         (uint8_t *)c->seg_valid.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
@@ -258,9 +288,12 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
 // IQ -> bb, avg and the refined candidate records for positions [j0, j1): the fused
 // specialisation when this samples-per-chip has one, the generic kernel pair otherwise.
 int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_abs1, uint64_t out_abs0,
-                             uint64_t out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, uint32_t *M_out)
+                             uint64_t out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, uint32_t *M_out,
+                             bool may_speculate = false)
 {
     *M_out = 0;
+    c->spec_now = false;
+    c->Mdev = nullptr;
     const unsigned T2 = c->force_generic ? 0u : am_fe2_tile(c->spc);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     unsigned span_segs = 0;
@@ -307,8 +340,15 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                             nullptr, nullptr, nullptr, avg_sparse, (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const uint64_t endj = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
+    uint32_t spec_cap = 0;
+    if (may_speculate && c->allow_spec && !c->chain_tables && avg_sparse && c->spec_density > 0.0) {
+        // (a capacity of 0 would mean "exact": at least one slot)
+        const double npos = (double)(j1 - j0);
+        const double want = c->spec_density * npos * 1.25 + c->spec_floor;
+        spec_cap = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
+    }
     return run_refine(c, bb, avg_sparse ? avg_sparse : avg, nt, tl, avg_sparse ? 2 : 1, M_out,
-                      (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull));
+                      (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull), spec_cap);
 }
 
 // Greedy chain, part 1: successor pointers and radix-16 jump tables over the M flat records.
@@ -343,7 +383,8 @@ int chain_build(am_ctx *c, uint32_t M)
 // Fills h_packets / h_tags (+ h_bursts).
 int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, uint64_t base_abs,
                  bool keep_bursts, uint32_t *final_cur, uint32_t max_hits, uint32_t own_lo = 0,
-                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0, bool marked = false)
+                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0, bool marked = false,
+                 const uint32_t *Mp = nullptr)
 {
     const uint32_t M = c->chain_M;
     c->h_packets.clear();
@@ -369,7 +410,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
                                    (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
                                    (uint8_t *)c->emit.p, (uint32_t *)c->cblk_cnt.p, (uint32_t *)c->scalars.p,
-                                   emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream));
+                                   emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
     HIPCHK(c, am_launch_scan_u32((uint32_t *)c->cblk_cnt.p, (uint32_t *)c->cblk_off.p, nb, c->stream));
     // Hits are at least 240*spc apart, so their number is bounded by the span of the candidates;
     // everything downstream is launched for that bound and reads the real count on the device.
@@ -389,17 +430,23 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     }
     if (!c->pin_scalars) HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
-                                     (uint32_t *)c->emit_idx.p, c->stream));
+                                     (uint32_t *)c->emit_idx.p, c->stream, Mp));
     HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                 (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
                                 (float *)c->bursts.p, c->pin_tags, c->stream));
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
+    c->pin_scalars[2] = 0;
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, c->pin_tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
-                              c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream));
+                              c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tail_synced = true;
+    if (Mp) {
+        // launched for a capacity: now the real candidate count is known
+        c->last_M = c->pin_scalars[2];
+        if (c->pin_scalars[2] > M) return AM_RETRY_EXACT;    // capacity too small: results are incomplete
+    }
     const uint32_t n_emit = c->pin_scalars[0];
     *final_cur = c->pin_scalars[1];
     if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
@@ -436,12 +483,13 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *, uint32_t M, u
     ENSURE(c, c->jump, c->chain_stride * sizeof(uint32_t));
     ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
     ENSURE(c, c->cscratch, am_chain_blocked_scratch(M));
+    const uint32_t *Mp = c->spec_now ? c->Mdev : nullptr;
     HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, 0, (uint32_t *)c->jump.p, nullptr,
-                                   c->stream));
+                                   c->stream, Mp));
     HIPCHK(c, am_launch_chain_blocked((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, c->spc,
                                       (uint32_t *)c->cscratch.p, (uint8_t *)c->visited.p, (uint32_t *)c->scalars.p,
-                                      c->stream));
-    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits, 0, 0xFFFFFFFFu, 0, true);
+                                      c->stream, Mp));
+    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits, 0, 0xFFFFFFFFu, 0, true, Mp);
 }
 
 void collect_accepted(am_ctx *c)
@@ -531,6 +579,9 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->no_span = !(ns && ns[0] == '1');
             const char *ct = getenv("AIRMODES_CHAIN_TABLES");
             c->chain_tables = ct && ct[0] == '1';
+            const char *sp = getenv("AIRMODES_NO_SPEC");
+            c->allow_spec = !(sp && sp[0] == '1');
+            if (const char *sf = getenv("AIRMODES_SPEC_FLOOR")) c->spec_floor = atof(sf);
         }
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
@@ -671,14 +722,24 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         }
         const uint32_t j0 = (uint32_t)(P0 - out_abs0), j1 = (uint32_t)(P1 - out_abs0);
         uint32_t M = 0;
-        int rc = run_front_and_candidates(c, src, src_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M);
+        int rc = run_front_and_candidates(c, src, src_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M, true);
         if (rc != AM_OK) return rc;
         const uint32_t cur0 = c->chain_cur > out_abs0 ? (uint32_t)std::min<uint64_t>(c->chain_cur - out_abs0, 0xFFFFFFF0u) : 0u;
         const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - out_abs0);
         uint32_t fin = cur0;
         const uint32_t max_hits = (uint32_t)((P1 - P0 + S) / ((uint64_t)AM_BURST * S) + 2);
         rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, out_abs0, false, &fin, max_hits);
+        if (rc == AM_RETRY_EXACT) {
+            if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: capacity %u < %u candidates, scan redone\n", M, c->last_M);
+            // more candidates than the capacity this scan was launched for: redo the refinement and
+            // the chain with the exact count (the fused kernel's outputs are still in place)
+            rc = run_refine(c, c->ref_bb, c->ref_avg, c->ref_nseg, c->ref_stride, c->ref_mode, &M, c->ref_endj, 0);
+            if (rc != AM_OK) return rc;
+            fin = cur0;
+            rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, out_abs0, false, &fin, max_hits);
+        }
         if (rc != AM_OK) return rc;
+        c->spec_density = (j1 > j0) ? (double)c->last_M / (double)(j1 - j0) : 0.0;
         c->last_tags = c->h_packets.size();
         collect_accepted(c);
         if (out_abs0 + fin > c->chain_cur) c->chain_cur = out_abs0 + fin;

@@ -46,16 +46,16 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
                                 uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
-                                hipStream_t s);
+                                hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
-                                   hipStream_t s);
+                                   hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s);
+                            double *energy, hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, hipStream_t s);
+                          uint8_t *valid, hipStream_t s, const uint32_t *Mp = nullptr);
 /* segmented records of the fused kernel -> flat, position-ordered arrays */
 hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, const float *seg_inavg,
                              const uint8_t *seg_valid, uint32_t seg_stride, const uint32_t *blk_off,
@@ -70,6 +70,8 @@ hipError_t am_launch_span(int spc, const float *iq, long long src_abs0, long lon
                           float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg, uint8_t *seg_valid,
                           uint32_t *blk_cnt, unsigned *nseg, unsigned *seg_stride, hipStream_t s);
 
+/* Launchers that take a candidate count M also take an optional device pointer Mp: when given, the
+ * kernels use min(M, *Mp), so that the host may launch for a capacity without knowing the count. */
 /* ---- preamble detection / refinement / greedy chain ----------------------------------- */
 #define AM_DET_THREADS 256
 #define AM_DET_PER_THREAD 8
@@ -104,19 +106,20 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
                             float *inavg, uint8_t *valid, hipStream_t s);
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
-                                uint32_t *jump0, uint8_t *visited, hipStream_t s);
+                                uint32_t *jump0, uint8_t *visited, hipStream_t s, const uint32_t *Mp = nullptr);
 size_t am_chain_blocked_scratch(uint32_t M);
 hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0, int spc,
-                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s);
+                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
+                                   const uint32_t *Mp = nullptr);
 hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s);
 hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s);
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
-                                uint32_t *scalars, int want_resume, hipStream_t s);
+                                uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
-                                  uint32_t *out_idx, hipStream_t s);
+                                  uint32_t *out_idx, hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_chain_init(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited,
                                 uint32_t *scalars, hipStream_t s);
 hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
@@ -132,6 +135,6 @@ hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const
 /* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,
-                           uint32_t *host_out, hipStream_t s);
+                           uint32_t *host_out, hipStream_t s, const uint32_t *Mp = nullptr);
 
 #endif

@@ -434,10 +434,21 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
 // ------------------------------------------------------------------------------------------
 #define AM_SCAN_BLK 2048
 
+// Candidate count: `cap` from the host (exact, or a capacity when the host speculates to avoid a
+// round trip) clipped by the device-side count when one is given.
+__device__ __forceinline__ uint32_t am_count(uint32_t cap, const uint32_t *__restrict__ Mp)
+{
+    if (!Mp) return cap;
+    const uint32_t m = *Mp;
+    return m < cap ? m : cap;
+}
+
 __global__ void __launch_bounds__(256)
 am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const uint32_t *__restrict__ blk_off,
-                uint32_t nseg, uint32_t M, int spc, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount)
+                uint32_t nseg, uint32_t Mcap, int spc, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
+                const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
     uint32_t lo = 0, hi = nseg;
@@ -471,8 +482,9 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 // block-local exclusive scan (2048 elements per workgroup) + block totals
 __global__ void __launch_bounds__(256)
 am_k_exscan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out_local, uint32_t *__restrict__ blk_tot,
-                   uint32_t n)
+                   uint32_t ncap, const uint32_t *__restrict__ Mp)
 {
+    const uint32_t n = am_count(ncap, Mp);
     __shared__ uint32_t ws[256 / AM_WAVE];
     const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
     const uint32_t base = blockIdx.x * AM_SCAN_BLK + threadIdx.x * 8;
@@ -512,9 +524,10 @@ __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_l
 
 __global__ void __launch_bounds__(256)
 am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,
-            const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t M, int spc,
-            double *__restrict__ energy)
+            const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t Mcap, int spc,
+            double *__restrict__ energy, const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     __shared__ uint32_t coff[AM_ECB + 1];   // compact offset of each candidate of this group (+ end)
     __shared__ uint32_t cq[AM_ECB];         // position of the candidate's first compact index
     __shared__ uint32_t qr[2];
@@ -586,10 +599,11 @@ am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, cons
 __global__ void __launch_bounds__(256)
 am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
           const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ off_local,
-          const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t M, int spc,
+          const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t Mcap, int spc,
           float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
-          float *__restrict__ inavg, uint8_t *__restrict__ valid)
+          float *__restrict__ inavg, uint8_t *__restrict__ valid, const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
     const uint32_t j = pos[g];
@@ -616,39 +630,39 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
 
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
                                 uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
-                                hipStream_t s)
+                                hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_gather_pos, dim3((M + 255) / 256), dim3(256), 0, s, seg_pos, seg_stride, blk_off, nseg,
-                       M, spc, pos, dcount);
+                       M, spc, pos, dcount, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
-                                   hipStream_t s)
+                                   hipStream_t s, const uint32_t *Mp)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_exscan_blocks, dim3((n + AM_SCAN_BLK - 1) / AM_SCAN_BLK), dim3(256), 0, s, in,
-                       out_local, blk_tot, n);
+                       out_local, blk_tot, n, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s)
+                            double *energy, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     const unsigned grid = (unsigned)(((uint64_t)M + AM_ECB - 1) / AM_ECB);
     hipLaunchKernelGGL(am_k_energy, dim3(grid), dim3(256), 0, s, bb, pos, dcount, off_local, blk_base, M, spc,
-                       energy);
+                       energy, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, hipStream_t s)
+                          uint8_t *valid, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_cand, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg_sparse, pos, dcount, off_local,
-                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid);
+                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, Mp);
     return hipGetLastError();
 }
 
@@ -673,9 +687,11 @@ __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ 
 }
 
 __global__ void __launch_bounds__(256)
-am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt, uint32_t M,
-                uint32_t cur0, uint32_t *__restrict__ jump0, uint8_t *__restrict__ visited)
+am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt, uint32_t Mcap,
+                uint32_t cur0, uint32_t *__restrict__ jump0, uint8_t *__restrict__ visited,
+                const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < M) jump0[g] = am_lower_bound(pos, g + 1, M, tgt[g]);
     if (g == M) jump0[M] = M;
@@ -754,10 +770,11 @@ am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M, i
 __global__ void __launch_bounds__(AM_DET_THREADS)
 am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ valid,
                 const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
-                const uint32_t *__restrict__ tgt, uint32_t M, uint32_t emit_max, uint32_t own_lo,
+                const uint32_t *__restrict__ tgt, uint32_t Mcap, uint32_t emit_max, uint32_t own_lo,
                 uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *__restrict__ blk_cnt, uint32_t *scalars,
-                int want_resume)
+                int want_resume, const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     // emit flags + their per-2048 block counts (for the ordered compaction) in one pass.
     // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is not
     // emitted (and nothing after it can be).  [own_lo, own_hi) restricts the output to the hits
@@ -815,12 +832,18 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
 #define AM_CB_NONE 0xFFFFFFFFu
 
 __global__ void __launch_bounds__(AM_CB_THREADS)
-am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ jump0, uint32_t M, uint32_t headw,
+am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw,
                uint32_t cur0, uint32_t *__restrict__ exitnode, uint32_t *__restrict__ headexit,
-               uint32_t *__restrict__ root)
+               uint32_t *__restrict__ root, const uint32_t *__restrict__ Mp)
 {
     __shared__ uint32_t e[2][AM_CB];
+    const uint32_t M = am_count(Mcap, Mp);
     const uint32_t base = blockIdx.x * AM_CB;
+    if (base >= M) {                                          // (capacity launch: nothing here)
+        for (uint32_t i = threadIdx.x; i < headw; i += blockDim.x) headexit[(size_t)blockIdx.x * headw + i] = M;
+        if (M == 0 && blockIdx.x == 0 && threadIdx.x == 0) *root = 0;
+        return;
+    }
     const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
     const uint32_t n = end - base;
     for (int k = 0; k < AM_CB_PER; ++k) {
@@ -857,9 +880,10 @@ am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ju
 // scalars[0] = cur0, scalars[1] = 0 (as am_k_chain_init leaves them).
 __global__ void __launch_bounds__(1024)
 am_k_cblk_walk(const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ headexit,
-               const uint32_t *__restrict__ root, uint32_t M, uint32_t nblk, uint32_t headw, uint32_t cur0,
-               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars)
+               const uint32_t *__restrict__ root, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
+               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     HIP_DYNAMIC_SHARED(uint32_t, hx);          // [nblk * headw] exit nodes of the heads
     const uint32_t total = nblk * headw;
     // batches of 8 independent loads per thread (one memory round trip per batch, not per word)
@@ -884,7 +908,7 @@ am_k_cblk_walk(const uint32_t *__restrict__ exitnode, const uint32_t *__restrict
         for (uint32_t b = 0; b < nblk; ++b) {
             const uint32_t base = b * AM_CB;
             const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
-            if (cur >= end) { entry[b] = AM_CB_NONE; continue; }
+            if (cur >= end || base >= M) { entry[b] = AM_CB_NONE; continue; }
             entry[b] = cur;
             const uint32_t idx = cur - base;
             cur = (idx < headw) ? hx[b * headw + idx] : exitnode[cur];    // (root, or an unusually long head)
@@ -893,12 +917,17 @@ am_k_cblk_walk(const uint32_t *__restrict__ exitnode, const uint32_t *__restrict
 }
 
 __global__ void __launch_bounds__(AM_CB_THREADS)
-am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ entry, uint32_t M,
-               uint8_t *__restrict__ visited)
+am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ entry, uint32_t Mcap,
+               uint8_t *__restrict__ visited, const uint32_t *__restrict__ Mp)
 {
     __shared__ uint16_t J[AM_CB_LEVELS][AM_CB];
     __shared__ uint8_t V[AM_CB];
+    const uint32_t M = am_count(Mcap, Mp);
     const uint32_t base = blockIdx.x * AM_CB;
+    if (base >= M) {                                          // (capacity launch: nothing here)
+        if (base == 0 && threadIdx.x == 0) visited[0] = 0;
+        return;
+    }
     const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
     const uint32_t n = end - base;
     const uint32_t ent = entry[blockIdx.x];
@@ -907,7 +936,7 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
             const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
             if (i < n) visited[base + i] = 0;
         }
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) visited[M] = 0;
+        if (end == M && threadIdx.x == 0) visited[M] = 0;
         return;
     }
     const uint16_t OUT = (uint16_t)AM_CB;                    // "leaves the block"
@@ -939,16 +968,16 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
         if (i < n) visited[base + i] = V[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) visited[M] = 0;
+    if (end == M && threadIdx.x == 0) visited[M] = 0;
 }
 
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
-                                uint32_t *jump0, uint8_t *visited, hipStream_t s)
+                                uint32_t *jump0, uint8_t *visited, hipStream_t s, const uint32_t *Mp)
 {
     hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M,
-                       cur0, jump0, visited);
+                       cur0, jump0, visited, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_chain_init(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited,
@@ -993,7 +1022,8 @@ size_t am_chain_blocked_scratch(uint32_t M)
 
 // visited[] for the scan that starts at position cur0, given the successor array jump0[] (am_k_chain_succ)
 hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0, int spc,
-                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s)
+                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
+                                   const uint32_t *Mp)
 {
     (void)spc;
     if (M == 0) return hipSuccess;
@@ -1001,7 +1031,7 @@ hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, u
     const uint32_t headw = am_chain_headw(nblk);
     uint32_t *exitnode = scratch, *entry = scratch + ((size_t)M + 1), *root = entry + nblk, *headexit = root + 8;
     hipLaunchKernelGGL(am_k_cblk_exit, dim3(nblk), dim3(AM_CB_THREADS), 0, s, pos, jump0, M, headw, cur0, exitnode,
-                       headexit, root);
+                       headexit, root, Mp);
     const size_t lds = ((size_t)nblk * headw + 1) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1012,19 +1042,19 @@ hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, u
         attr_set = true;
     }
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, exitnode, headexit, root, M, nblk, headw, cur0,
-                       entry, scalars);
-    hipLaunchKernelGGL(am_k_cblk_mark, dim3(nblk), dim3(AM_CB_THREADS), 0, s, jump0, entry, M, visited);
+                       entry, scalars, Mp);
+    hipLaunchKernelGGL(am_k_cblk_mark, dim3(nblk), dim3(AM_CB_THREADS), 0, s, jump0, entry, M, visited, Mp);
     return hipGetLastError();
 }
 
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
-                                uint32_t *scalars, int want_resume, hipStream_t s)
+                                uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, visited,
-                       valid, pos, e, tgt, M, emit_max, own_lo, own_hi, emit, blk_cnt, scalars, want_resume);
+                       valid, pos, e, tgt, M, emit_max, own_lo, own_hi, emit, blk_cnt, scalars, want_resume, Mp);
     return hipGetLastError();
 }
 
@@ -1054,9 +1084,10 @@ am_k_flag_count(const uint8_t *__restrict__ flags, uint32_t M, uint32_t *__restr
 }
 
 __global__ void __launch_bounds__(AM_DET_THREADS)
-am_k_flag_scatter(const uint8_t *__restrict__ flags, uint32_t M, const uint32_t *__restrict__ blk_off,
-                  uint32_t *__restrict__ out_idx)
+am_k_flag_scatter(const uint8_t *__restrict__ flags, uint32_t Mcap, const uint32_t *__restrict__ blk_off,
+                  uint32_t *__restrict__ out_idx, const uint32_t *__restrict__ Mp)
 {
+    const uint32_t M = am_count(Mcap, Mp);
     __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const int w = threadIdx.x / AM_WAVE;
@@ -1088,11 +1119,11 @@ hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_
     return hipGetLastError();
 }
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
-                                  uint32_t *out_idx, hipStream_t s)
+                                  uint32_t *out_idx, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_flag_scatter, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, flags,
-                       M, blk_off, out_idx);
+                       M, blk_off, out_idx, Mp);
     return hipGetLastError();
 }
 
@@ -1173,12 +1204,16 @@ __device__ __forceinline__ uint32_t am_bitrev8(uint32_t v)
 __global__ void __launch_bounds__(256)
 am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, const uint32_t *__restrict__ n_ptr,
            const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets,
-           const uint32_t *__restrict__ scalars, uint32_t *__restrict__ host_out)
+           const uint32_t *__restrict__ scalars, uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
 {
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
     // hit count and scan resume position go straight to pinned host memory (no extra copies)
-    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) { host_out[0] = *n_ptr; host_out[1] = scalars[0]; }
+    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        host_out[0] = *n_ptr;
+        host_out[1] = scalars[0];
+        host_out[2] = Mp ? *Mp : 0u;                          // actual candidate count (speculative launches)
+    }
     if (i >= *n_ptr) return;                              // wave-uniform; device-side burst count
     const float *b = bursts + (size_t)i * AM_BURST;
     float s = b[0] + b[2];                                // slicer_impl.cc:128-131
@@ -1238,10 +1273,10 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
 
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,
-                           uint32_t *host_out, hipStream_t s)
+                           uint32_t *host_out, hipStream_t s, const uint32_t *Mp)
 {
     if (n_max == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bursts, tags, n_ptr, crc_pow, packets,
-                       scalars, host_out);
+                       scalars, host_out, Mp);
     return hipGetLastError();
 }

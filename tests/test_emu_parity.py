@@ -134,3 +134,30 @@ def test_greedy_chain_many_blocks(emu_lib, monkeypatch, tables):
     ctx.close()
     assert m1 > 3 * 2048, m1
     assert np.array_equal(np.concatenate(got), want) and len(want) > 100
+
+
+def test_speculative_capacity_overflow_is_redone(emu_lib, monkeypatch):
+    """The streaming path launches a scan for a candidate capacity extrapolated from the previous
+    scan.  Quiet stretch first, dense traffic next, no slack: the second scan overflows its capacity
+    and must be redone with the exact count -- same packets as ever."""
+    from air_modes import _capi
+    monkeypatch.setenv("AIRMODES_SPEC_FLOOR", "0")
+    rate = 8e6
+    quiet, _ = synth.synth_capture(rate, 600000, 40.0, seed=611)
+    busy, _ = synth.synth_capture(rate, 900000, 20000.0, seed=612)
+    iq = np.concatenate([quiet, busy])
+    want = oracle.demod(iq, rate, 7.0, True)
+    ctx = _capi.Context(rate, 7.0, True, lib=emu_lib)
+    got = [ctx.process_iq(iq[:300000]), ctx.process_iq(iq[300000:600000])]
+    m_quiet = ctx.last_num_candidates()
+    got.append(ctx.process_iq(iq[600000:1100000]))
+    m_busy = ctx.last_num_candidates()
+    got.append(ctx.process_iq(iq[1100000:], flush=True))
+    ctx.close()
+    assert m_busy > 4 * max(m_quiet, 1)                      # the capacity (1.25 x extrapolation) was exceeded
+    assert np.array_equal(np.concatenate(got), want) and len(want) > 50
+    monkeypatch.setenv("AIRMODES_NO_SPEC", "1")              # and the non-speculative path agrees
+    ctx = _capi.Context(rate, 7.0, True, lib=emu_lib)
+    got = [ctx.process_iq(iq[:700001]), ctx.process_iq(iq[700001:], flush=True)]
+    ctx.close()
+    assert np.array_equal(np.concatenate(got), want)
