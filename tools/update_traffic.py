@@ -1,0 +1,30 @@
+"""profiles/current_traffic.json from a gpu_prof.sh summary (rocprofv3 FETCH_SIZE / WRITE_SIZE passes).
+
+    python tools/update_traffic.py profiles/<round>/summary.txt 64msps
+FETCH_SIZE is doubled (gfx950 reports half the bytes of a wide coalesced read: MI355X_MICROARCH.md,
+HBM section); WRITE_SIZE is taken as reported."""
+import json
+import re
+import sys
+
+text = open(sys.argv[1]).read()
+workload = sys.argv[2] if len(sys.argv) > 2 else "64msps"
+
+
+def mean_of(section):
+    part = text.split("== %s per dispatch" % section)[1]
+    m = re.search(r"am_k_fe2<(\d+), (\d+)>.*?mean ([0-9.e+]+)", part)
+    return "am_k_fe2<%s,%s>" % (m.group(1), m.group(2)), float(m.group(3))
+
+
+kernel, fetch = mean_of("FETCH_SIZE")
+_, write = mean_of("WRITE_SIZE")
+doc = {"workload": workload, "kernel": kernel, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
+       "fetch_bytes_corrected": int(fetch * 1024 * 2), "write_bytes": int(write * 1024),
+       "traffic_bytes": int(fetch * 1024 * 2 + write * 1024), "source": sys.argv[1],
+       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 "
+               "--warmup 1 --no-cpu-baseline --no-pipelined`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
+               "reports half of a coalesced stream); WRITE_SIZE uncalibrated (matches the dense bb array + sparse "
+               "avg + candidate lists)"}
+json.dump(doc, open("profiles/current_traffic.json", "w"), indent=1)
+print(doc)
