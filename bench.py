@@ -199,6 +199,27 @@ def main():
                                    "host_cores_available": os.cpu_count()}
             res["parity"] = bool(np.array_equal(pk, want))
             res["speedup_vs_cpu_baseline"] = value / (n / cpu_dt)
+            # the same port on every host core: the batch cut into one time chunk per thread (each with the
+            # look-ahead a chunk needs), timed only -- SURVEY 8(d) asks for both figures
+            from concurrent.futures import ThreadPoolExecutor
+            P = max(1, os.cpu_count() or 1)
+            halo = 400 * spc
+            cuts = [(k * n) // P for k in range(P + 1)]
+            def chunk(k):
+                a, b = cuts[k], min(n, cuts[k + 1] + halo)
+                return len(oracle.demod(iq[a:b], rate, 7.0, True))
+            with ThreadPoolExecutor(P) as ex:
+                list(ex.map(chunk, range(min(P, 8))))            # threads up, library loaded
+                best = None
+                for _ in range(3):
+                    t2 = time.perf_counter()
+                    list(ex.map(chunk, range(P)))
+                    d = time.perf_counter() - t2
+                    best = d if best is None or d < best else best
+            res["cpu_baseline_all_cores"] = {"value": n / best, "unit": "samples/s", "cores": P, "kind": "port",
+                                             "sample": "the same batch cut into %d time chunks (+%d samples of "
+                                                       "look-ahead each), one oracle thread per chunk, best of 3 "
+                                                       "passes, %.3f s" % (P, halo, best)}
         if pipelined:
             res["pipelined"] = pipelined
         print(json.dumps(res))

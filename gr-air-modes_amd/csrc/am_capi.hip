@@ -1050,9 +1050,20 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
     const uint32_t cur0 = cur_in > c->shard_base ? (uint32_t)std::min<uint64_t>(cur_in - c->shard_base, 0xFFFFFFF0u) : 0u;
     const uint32_t emax = (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
     uint32_t fin = 0;
-    int rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin,
-                          (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
-                                     ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2));
+    const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
+                                         ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
+    int rc;
+    if (c->chain_tables) {
+        rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits);
+    } else {
+        // visited[] from the blocked chain on the successor array (level 0 of the tables am_shard_scan built)
+        ENSURE(c, c->cscratch, am_chain_blocked_scratch(c->chain_M));
+        HIPCHK(c, am_launch_chain_blocked((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, c->chain_M, cur0, c->spc,
+                                          (uint32_t *)c->cscratch.p, (uint8_t *)c->visited.p,
+                                          (uint32_t *)c->scalars.p, c->stream));
+        rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits, 0,
+                          0xFFFFFFFFu, 0, true);
+    }
     if (rc != AM_OK) return rc;
     c->last_tags = c->h_packets.size();
     collect_accepted(c);
