@@ -56,8 +56,6 @@ struct am_ctx {
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool chain_tables = false;    // AIRMODES_CHAIN_TABLES=1: radix-16 jump tables instead of the blocked chain
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
-    bool fe2_inkernel = false;    // AIRMODES_FE2_INKERNEL=1: refine inside the fused kernel (A/B testing)
-    bool no_span = true;          // AIRMODES_SPAN=1: experimental per-wave span kernel instead of the tiled fused kernel
     char err[256] = "";
 
     // stream state (absolute sample indices)
@@ -69,7 +67,7 @@ struct am_ctx {
     DevBuf carry, carry2;
 
     // work buffers (grow only)
-    DevBuf src, bb, avg, cand_seg, seg_e, seg_inavg, seg_valid, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
+    DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         visited, emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch;
 
@@ -255,12 +253,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
                                      (uint32_t *)c->off_local.p, (uint32_t *)c->blk_base2.p, (double *)c->energy.p, M,
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
                                      (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream, Mp));
-        } else if (mode == 1)
-            HIPCHK(c, am_launch_flatten((uint32_t *)c->cand_seg.p, (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p,
-                                        (uint8_t *)c->seg_valid.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
-                                        c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
-                                        (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream));
-        else
+        } else
             HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
                                        (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p,
                                        (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, (float *)c->inavg.p,
@@ -296,25 +289,6 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     c->Mdev = nullptr;
     const unsigned T2 = c->force_generic ? 0u : am_fe2_tile(c->spc);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    unsigned span_segs = 0;
-    const size_t span_slots = (c->force_generic || c->no_span || avg) ? 0 : am_span_slots(c->spc, (long long)out_n, &span_segs);
-    if (span_slots) {
-        // barrier-free per-wave spans (16..64 Msps)
-        ENSURE(c, c->cand_seg, span_slots * sizeof(uint32_t));
-        ENSURE(c, c->seg_e, span_slots * sizeof(uint32_t));
-        ENSURE(c, c->seg_inavg, span_slots * sizeof(float));
-        ENSURE(c, c->seg_valid, span_slots);
-        ENSURE(c, c->blk_cnt, ((size_t)span_segs + 8) * sizeof(uint32_t));
-        ENSURE(c, c->blk_off, ((size_t)span_segs + 9) * sizeof(uint32_t));
-        unsigned ns = 0, st = 0;
-        HIPCHK(c, am_launch_span(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
-                                 (long long)out_n, bb, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
-                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
-                                 (uint32_t *)c->seg_e.p, (float *)c->seg_inavg.p, (uint8_t *)c->seg_valid.p,
-                                 (uint32_t *)c->blk_cnt.p, &ns, &st, c->stream));
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        return run_refine(c, bb, avg, ns, st, 1, M_out);
-    }
     if (T2 == 0) {
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
@@ -327,8 +301,8 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     ENSURE(c, c->blk_cnt, ((size_t)ntiles + 8) * sizeof(uint32_t));
     ENSURE(c, c->blk_off, ((size_t)ntiles + 9) * sizeof(uint32_t));
     unsigned nt = 0, tl = 0;
-    // split refinement (default): the fused kernel stops after detection and leaves avg[] around the
-    // candidates; AIRMODES_FE2_INKERNEL=1 refines inside the kernel instead
+    // the fused kernel stops after detection and leaves avg[] around the candidates (or all of it, when
+    // the caller wants the dense array); the refinement runs as separate kernels
     float *avg_sparse = nullptr;
     if (!avg) {
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
@@ -337,7 +311,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     HIPCHK(c, am_launch_fe2(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
                             (long long)out_n, bb, avg, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                             (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
-                            nullptr, nullptr, nullptr, avg_sparse, (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
+                            avg_sparse, (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const uint64_t endj = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
     uint32_t spec_cap = 0;
@@ -347,7 +321,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         const double want = c->spec_density * npos * 1.25 + c->spec_floor;
         spec_cap = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
     }
-    return run_refine(c, bb, avg_sparse ? avg_sparse : avg, nt, tl, avg_sparse ? 2 : 1, M_out,
+    return run_refine(c, bb, avg_sparse ? avg_sparse : avg, nt, tl, 2, M_out,
                       (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull), spec_cap);
 }
 
@@ -573,10 +547,6 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
-            const char *ik = getenv("AIRMODES_FE2_INKERNEL");
-            c->fe2_inkernel = ik && ik[0] == '1';
-            const char *ns = getenv("AIRMODES_SPAN");
-            c->no_span = !(ns && ns[0] == '1');
             const char *ct = getenv("AIRMODES_CHAIN_TABLES");
             c->chain_tables = ct && ct[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");
@@ -607,8 +577,7 @@ void am_destroy(am_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->seg_e, &c->seg_inavg,
-                     &c->seg_valid, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
+    DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,

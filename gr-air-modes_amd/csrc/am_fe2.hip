@@ -1,7 +1,7 @@
 // am_fe2.hip -- fused front end + preamble detection for gfx950, specialised per samples-per-chip.
 //
-// One workgroup (384 threads = 6 waves) owns a tile of T = 384 * R samples; every thread owns a
-// RUN of R = SPC * CPT consecutive samples (CPT whole chips) and keeps it in registers:
+// One workgroup (768 threads = 12 waves, one per CU) owns a tile of T = 768 * R samples; every thread
+// owns a RUN of R = SPC * CPT consecutive samples (CPT whole chips) and keeps it in registers:
 //
 //   P1  IQ (HBM, 16 B per lane, coalesced) -> |.|^2 -> LDS X            (tile + halos)
 //   P2  pulse matched filter: thread reads chip(q-1), its own chips from X, forms the in-chip
@@ -14,11 +14,11 @@
 //       and avg[] for the runs that hold or follow a candidate (all the refinement kernels
 //       am_k_energy / am_k_cand in am_kernels.hip need)
 //
-// LDS holds ONE float per sample (X), so a 12 K-sample tile fits twice per CU; the left halo is
-// one 48-chip block + one chip (13 % at 64 Msps) and is served from L2 because consecutive
-// tiles are mapped to the same XCD.  Summation order = DESIGN.md section 3 (identical to the
-// generic kernel am_k_frontend and to the oracle).  Reference: python/rx_path.py:38-54,
-// lib/preamble_impl.cc:172-179.
+// LDS holds ONE float per sample (X) plus per-chip side arrays (about 120 KB at 64 Msps).  The left
+// halo is one 48-chip block + one chip (6 % at 64 Msps) and is served from L2 because consecutive
+// tiles are mapped to the same XCD; the right halo is the 9 chips the test looks ahead.
+// Summation order = DESIGN.md section 3 (identical to the generic kernel am_k_frontend and to the
+// oracle).  Reference: python/rx_path.py:38-54, lib/preamble_impl.cc:172-179.
 #include "am_internal.h"
 
 #include <stdio.h>
@@ -144,13 +144,9 @@ struct am_fe2_args {
     long long out_n;                // outputs wanted
     float *bb;                      // dense pulse-matched power (read by burst extraction); may be null
     float *avg;                     // dense reference level; only written when non-null (block-level API)
-    float *avg_sparse;              // split mode: avg runs around candidates only (read by am_k_cand)
-    int split_refine;               // 1: stop after detection, refinement runs as separate kernels
+    float *avg_sparse;              // avg runs around candidates only (read by am_k_cand); may be null
     uint32_t j0, j1;                // positions (array coordinates) whose preamble test is wanted
-    uint32_t *seg_pos;              // per tile: T candidate positions ...
-    uint32_t *seg_e;                // ... shifted starts
-    float *seg_inavg;               // ... reference level at the shifted start
-    uint8_t *seg_valid;             // ... quiet-zone verdict
+    uint32_t *seg_pos;              // per tile: up to T candidate positions, in order
     uint32_t *blk_cnt;              // ntiles
     unsigned ntiles;
     int use_pmf;
@@ -507,9 +503,9 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     __syncthreads();
     FE2_STAMP(9);
 
-    // split mode: the refinement kernels need avg[e] for e in a candidate's run or the next one;
+    // the refinement kernels need avg[e] for e in a candidate's run or the next one;
     // write those runs only (plus the tile's first run, for candidates at the end of the previous tile)
-    if (a.split_refine && a.avg_sparse && !(a.ablate & 64u)) {
+    if (a.avg_sparse && !(a.ablate & 64u)) {
         const bool need = tid == 0 || RUNANY[tid] != 0u || RUNANY[tid - 1] != 0u;
         if (need) {
 #pragma unroll
@@ -652,16 +648,13 @@ unsigned am_fe2_tile(int spc)
 
 hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
-                         float sL, float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg,
-                         uint8_t *seg_valid, float *avg_sparse, uint32_t *blk_cnt, unsigned *ntiles,
-                         unsigned *tile_len, hipStream_t s)
+                         float sL, float thr_lin, uint32_t *seg_pos, float *avg_sparse, uint32_t *blk_cnt,
+                         unsigned *ntiles, unsigned *tile_len, hipStream_t s)
 {
     am_fe2_args a;
     a.avg_sparse = avg_sparse;
-    a.split_refine = avg_sparse != nullptr;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
-    a.bb = bb; a.avg = avg; a.j0 = j0; a.j1 = j1; a.seg_pos = seg_pos; a.seg_e = seg_e; a.seg_inavg = seg_inavg;
-    a.seg_valid = seg_valid; a.blk_cnt = blk_cnt; a.ntiles = 0;
+    a.bb = bb; a.avg = avg; a.j0 = j0; a.j1 = j1; a.seg_pos = seg_pos; a.blk_cnt = blk_cnt; a.ntiles = 0;
     a.use_pmf = use_pmf; a.s1 = s1; a.sL = sL; a.thr_lin = thr_lin;
     {
         const char *ab = getenv("AIRMODES_FE2_ABLATE");

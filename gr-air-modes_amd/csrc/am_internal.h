@@ -39,9 +39,8 @@ hipError_t am_launch_frontend(const am_fe_args &a, hipStream_t s);
 unsigned am_fe2_tile(int spc);
 hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
-                         float sL, float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg,
-                         uint8_t *seg_valid, float *avg_sparse, uint32_t *blk_cnt, unsigned *ntiles,
-                         unsigned *tile_len, hipStream_t s);
+                         float sL, float thr_lin, uint32_t *seg_pos, float *avg_sparse, uint32_t *blk_cnt,
+                         unsigned *ntiles, unsigned *tile_len, hipStream_t s);
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
@@ -56,20 +55,6 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
                           uint8_t *valid, hipStream_t s, const uint32_t *Mp = nullptr);
-/* segmented records of the fused kernel -> flat, position-ordered arrays */
-hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, const float *seg_inavg,
-                             const uint8_t *seg_valid, uint32_t seg_stride, const uint32_t *blk_off,
-                             uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *e, uint32_t *tgt,
-                             float *inavg, uint8_t *valid, hipStream_t s);
-
-/* barrier-free per-wave span kernel (am_span.hip): spc in {8,10,16,20,32}.
- * am_span_slots: candidate slots needed for out_n outputs (0 = no specialisation for this spc). */
-size_t am_span_slots(int spc, long long out_n, unsigned *nseg_max);
-hipError_t am_launch_span(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0,
-                          long long out_n, float *bb, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                          float thr_lin, uint32_t *seg_pos, uint32_t *seg_e, float *seg_inavg, uint8_t *seg_valid,
-                          uint32_t *blk_cnt, unsigned *nseg, unsigned *seg_stride, hipStream_t s);
-
 /* Launchers that take a candidate count M also take an optional device pointer Mp: when given, the
  * kernels use min(M, *Mp), so that the host may launch for a capacity without knowing the count. */
 /* ---- preamble detection / refinement / greedy chain ----------------------------------- */

@@ -374,42 +374,6 @@ am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc
     tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
 }
 
-// Fused path: the records already exist per tile segment; gather them into flat arrays.
-__global__ void __launch_bounds__(256)
-am_k_flatten(const uint32_t *__restrict__ seg_pos, const uint32_t *__restrict__ seg_e,
-             const float *__restrict__ seg_inavg, const uint8_t *__restrict__ seg_valid, uint32_t seg_stride,
-             const uint32_t *__restrict__ blk_off, uint32_t nseg, uint32_t M, int spc,
-             uint32_t *__restrict__ pos, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
-             float *__restrict__ inavg, uint8_t *__restrict__ valid)
-{
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    uint32_t lo = 0, hi = nseg;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (blk_off[mid] <= g) lo = mid; else hi = mid;
-    }
-    const size_t so = (size_t)lo * seg_stride + (g - blk_off[lo]);
-    const uint32_t e = seg_e[so];
-    const bool ok = seg_valid[so] != 0;
-    pos[g] = seg_pos[so];
-    eo[g] = e;
-    inavg[g] = seg_inavg[so];
-    valid[g] = ok ? 1 : 0;
-    tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);
-}
-
-hipError_t am_launch_flatten(const uint32_t *seg_pos, const uint32_t *seg_e, const float *seg_inavg,
-                             const uint8_t *seg_valid, uint32_t seg_stride, const uint32_t *blk_off,
-                             uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *e, uint32_t *tgt,
-                             float *inavg, uint8_t *valid, hipStream_t s)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_flatten, dim3((M + 255) / 256), dim3(256), 0, s, seg_pos, seg_e, seg_inavg, seg_valid,
-                       seg_stride, blk_off, nseg, M, spc, pos, e, tgt, inavg, valid);
-    return hipGetLastError();
-}
-
 hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
                             const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,

@@ -65,22 +65,8 @@ def test_sharded(emu_lib, rate, n, G):
 
 def test_tiled_fused_kernel_still_matches(emu_lib, monkeypatch):
     """The tiled fused kernel is the default everywhere it is specialised."""
-    monkeypatch.delenv("AIRMODES_SPAN", raising=False)
     for rate, n in ((16e6, 200000), (20e6, 300000), (64e6, 500000)):
         assert pc.check_stages(emu_lib, rate, n, 6000.0, 51) > 3
-
-
-def test_span_geometry_variants(emu_lib, monkeypatch):
-    """Span length must not matter (1 block per span ... everything in one span)."""
-    iq, _ = synth.synth_capture(64e6, 400000, 20000.0, seed=61)
-    want = oracle.demod(iq, 64e6)
-    monkeypatch.setenv("AIRMODES_SPAN", "1")
-    for bps in ("1", "2", "5", "1000"):
-        monkeypatch.setenv("AIRMODES_SPAN_BLOCKS", bps)
-        ctx = _capi.Context(64e6, 7.0, True, lib=emu_lib)
-        got = ctx.process_iq(iq, flush=True)
-        ctx.close()
-        assert np.array_equal(got, want), bps
 
 
 def test_generic_kernels_still_match(emu_lib, monkeypatch):

@@ -38,21 +38,8 @@ def test_stages(lib, rate, n, lam, seed, pmf):
 
 
 def test_tiled_fused_kernel_still_matches(lib, monkeypatch):
-    monkeypatch.delenv("AIRMODES_SPAN", raising=False)
     for rate, n in ((16e6, 2000000), (20e6, 2000000), (64e6, 6000000)):
         assert pc.check_stages(lib, rate, n, 6000.0, 51) > 3
-
-
-def test_span_geometry_variants(lib, monkeypatch):
-    iq, _ = synth.synth_capture(64e6, 4000000, 20000.0, seed=61)
-    want = oracle.demod(iq, 64e6)
-    monkeypatch.setenv("AIRMODES_SPAN", "1")
-    for bps in ("1", "3", "64", "100000"):
-        monkeypatch.setenv("AIRMODES_SPAN_BLOCKS", bps)
-        ctx = _capi.Context(64e6, 7.0, True, lib=lib)
-        got = ctx.process_iq(iq, flush=True)
-        ctx.close()
-        assert np.array_equal(got, want), bps
 
 
 def test_generic_kernels_still_match(lib, monkeypatch):
