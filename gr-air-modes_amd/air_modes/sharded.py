@@ -9,7 +9,7 @@ samples into the next chunk.  Per step:
   1. halo exchange   every rank publishes [its last `left` samples | its first `right` samples]
                      in ONE all_gather of fixed-size slabs (KB-scale: latency bound, far below
                      the 153 GB/s per xGMI link) and keeps its two neighbours' slabs;
-  2. local scan      am_shard_scan: front end, detection, refinement and the jump tables of the
+  2. local scan      am_shard_scan: front end, detection, refinement, the successor array and block exits of the
                      chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan
                      could enter the chunk at (those in its first 241*spc samples), where the
                      scan would leave the chunk;

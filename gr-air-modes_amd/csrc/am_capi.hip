@@ -54,7 +54,6 @@ struct am_ctx {
     int ref_mode = 0;
     const float *ref_bb = nullptr, *ref_avg = nullptr;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
-    bool chain_tables = false;    // AIRMODES_CHAIN_TABLES=1: radix-16 jump tables instead of the blocked chain
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     char err[256] = "";
 
@@ -79,9 +78,8 @@ struct am_ctx {
     std::vector<am_shard_exit> h_exit;  // exit table of the resident chunk
     uint64_t last_tags = 0;
     uint32_t last_M = 0;
-    uint32_t chain_M = 0;               // records the jump tables were built for
-    int chain_levels = 0;
-    size_t chain_stride = 0;
+    uint32_t chain_M = 0;               // records (or capacity) chain_prepare ran for
+    const uint32_t *chain_Mp = nullptr; // device-side count when chain_M is a capacity
 
     // time-sharded mode: the chunk whose bb/avg are resident
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
@@ -315,7 +313,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     const uint64_t endj = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
     uint32_t spec_cap = 0;
-    if (may_speculate && c->allow_spec && !c->chain_tables && avg_sparse && c->spec_density > 0.0) {
+    if (may_speculate && c->allow_spec && avg_sparse && c->spec_density > 0.0) {
         // (a capacity of 0 would mean "exact": at least one slot)
         const double npos = (double)(j1 - j0);
         const double want = c->spec_density * npos * 1.25 + c->spec_floor;
@@ -325,30 +323,21 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                       (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull), spec_cap);
 }
 
-// Greedy chain, part 1: successor pointers and radix-16 jump tables over the M flat records.
-const int AM_CHAIN_RADIX = 16;
-int chain_build(am_ctx *c, uint32_t M)
+// Greedy chain, part 1 (independent of where the scan starts): successor array and per-block exits
+// over the M flat records (M may be a capacity, with the device-side count in Mp).
+int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nullptr)
 {
     c->chain_M = M;
-    c->chain_levels = 0;
-    c->chain_stride = (size_t)M + 1;
+    c->chain_Mp = Mp;
     if (M == 0) return AM_OK;
-    int levels = 1;
-    {
-        uint64_t reach = AM_CHAIN_RADIX;
-        while (reach < (uint64_t)M + 1) { reach *= AM_CHAIN_RADIX; levels++; }
-    }
-    c->chain_levels = levels;
-    const size_t stride = c->chain_stride;
+    const size_t stride = (size_t)M + 1;
     ENSURE(c, c->visited, stride);
     ENSURE(c, c->emit, stride);
-    ENSURE(c, c->jump, (size_t)(levels + 1) * stride * sizeof(uint32_t));
+    ENSURE(c, c->jump, stride * sizeof(uint32_t));
     ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
-    uint32_t *jump = (uint32_t *)c->jump.p;
-    HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, 0, jump, nullptr, c->stream));
-    for (int k = 0; k < levels; k++)
-        HIPCHK(c, am_launch_chain_double(jump + (size_t)k * stride, jump + (size_t)(k + 1) * stride, M,
-                                         AM_CHAIN_RADIX, c->stream));
+    ENSURE(c, c->cscratch, am_chain_scratch_bytes(M));
+    HIPCHK(c, am_launch_chain_prepare((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, (uint32_t *)c->jump.p,
+                                      (uint32_t *)c->cscratch.p, want_last ? 1 : 0, c->stream, Mp));
     return AM_OK;
 }
 
@@ -357,27 +346,18 @@ int chain_build(am_ctx *c, uint32_t M)
 // Fills h_packets / h_tags (+ h_bursts).
 int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, uint64_t base_abs,
                  bool keep_bursts, uint32_t *final_cur, uint32_t max_hits, uint32_t own_lo = 0,
-                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0, bool marked = false,
-                 const uint32_t *Mp = nullptr)
+                 uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
 {
     const uint32_t M = c->chain_M;
+    const uint32_t *Mp = c->chain_Mp;
     c->h_packets.clear();
     c->h_tags.clear();
     c->h_bursts.clear();
     c->last_M = M;
     *final_cur = cur0;
     if (M == 0) return AM_OK;
-    const int levels = c->chain_levels;
-    const size_t stride = c->chain_stride;
-    uint32_t *jump = (uint32_t *)c->jump.p;
-    (void)stride;
-    if (!marked) {
-        HIPCHK(c, am_launch_chain_init((uint32_t *)c->pos.p, M, cur0, (uint8_t *)c->visited.p,
-                                       (uint32_t *)c->scalars.p, c->stream));
-        for (int k = levels; k >= 0; k--)
-            HIPCHK(c, am_launch_chain_mark(jump + (size_t)k * stride, (uint8_t *)c->visited.p, M, AM_CHAIN_RADIX,
-                                           c->stream));
-    }
+    HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
+                                    (uint8_t *)c->visited.p, (uint32_t *)c->scalars.p, c->stream, Mp));
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
@@ -443,27 +423,9 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *, uint32_t M, u
     c->h_bursts.clear();
     c->last_M = M;
     *final_cur = cur0;
-    if (c->chain_tables || M == 0 || am_chain_blocked_scratch(M) / sizeof(uint32_t) > 0xFFFFFFFFull) {
-        int rc = chain_build(c, M);
-        if (rc != AM_OK || M == 0) return rc;
-        return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits);
-    }
-    // blocked chain: successor array only (no jump tables), visited[] from three LDS-resident launches
-    c->chain_M = M;
-    c->chain_levels = 0;
-    c->chain_stride = (size_t)M + 1;
-    ENSURE(c, c->visited, c->chain_stride);
-    ENSURE(c, c->emit, c->chain_stride);
-    ENSURE(c, c->jump, c->chain_stride * sizeof(uint32_t));
-    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
-    ENSURE(c, c->cscratch, am_chain_blocked_scratch(M));
-    const uint32_t *Mp = c->spec_now ? c->Mdev : nullptr;
-    HIPCHK(c, am_launch_chain_succ((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, 0, (uint32_t *)c->jump.p, nullptr,
-                                   c->stream, Mp));
-    HIPCHK(c, am_launch_chain_blocked((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, c->spc,
-                                      (uint32_t *)c->cscratch.p, (uint8_t *)c->visited.p, (uint32_t *)c->scalars.p,
-                                      c->stream, Mp));
-    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits, 0, 0xFFFFFFFFu, 0, true, Mp);
+    int rc = chain_prepare(c, M, false, c->spec_now ? c->Mdev : nullptr);
+    if (rc != AM_OK || M == 0) return rc;
+    return chain_finish(c, bb, cur0, emit_max, base_abs, keep_bursts, final_cur, max_hits);
 }
 
 void collect_accepted(am_ctx *c)
@@ -547,8 +509,6 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
-            const char *ct = getenv("AIRMODES_CHAIN_TABLES");
-            c->chain_tables = ct && ct[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");
             c->allow_spec = !(sp && sp[0] == '1');
             if (const char *sf = getenv("AIRMODES_SPEC_FLOOR")) c->spec_floor = atof(sf);
@@ -935,6 +895,8 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     const uint64_t out_n = src_abs1 - out_abs0;
     const uint64_t pad = zero_pad(c->spc);
     uint32_t M = 0;
+    c->spec_now = false;
+    c->Mdev = nullptr;
     if (P1 > P0 && out_n) {
         const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
@@ -946,34 +908,47 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
             HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
         }
         int rc = run_front_and_candidates(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg,
-                                          (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M);
+                                          (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M, true);
         if (rc != AM_OK) return rc;
     }
     c->shard_base = out_abs0;
     c->shard_start = abs_start;
     c->shard_end = abs_end;
     c->shard_total = total_n;
-    int rc = chain_build(c, M);
-    if (rc != AM_OK) return rc;
     // exit table for the candidates the scan can enter at: those in the first 241*spc samples of
     // the chunk (the farthest a predecessor's skip can reach) and the first one after them
     const uint64_t lead = (uint64_t)(AM_BURST + 1) * S + 1;
     const uint64_t lead_end = abs_start + lead;                 // absolute, exclusive
-    const uint32_t n_dev = (uint32_t)std::min<uint64_t>(M, lead + 1);
-    uint64_t nt = 0;
-    if (n_dev) {
-        ENSURE(c, c->exit_tab, (size_t)n_dev * sizeof(am_shard_exit));
-        HIPCHK(c, am_launch_chain_exit((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, (uint32_t *)c->jump.p,
-                                       c->chain_stride, c->chain_levels, AM_CHAIN_RADIX, M, n_dev, out_abs0,
-                                       (am_shard_exit *)c->exit_tab.p, c->stream));
-        c->h_exit.resize(n_dev);
-        HIPCHK(c, hipMemcpyAsync(c->h_exit.data(), c->exit_tab.p, (size_t)n_dev * sizeof(am_shard_exit),
-                                 hipMemcpyDeviceToHost, c->stream));
+    uint32_t n_dev = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint32_t *Mp = c->spec_now ? c->Mdev : nullptr;
+        int rc = chain_prepare(c, M, true, Mp);
+        if (rc != AM_OK) return rc;
+        n_dev = (uint32_t)std::min<uint64_t>(M, lead + 1);
+        uint32_t actual = M;
+        if (n_dev) {
+            ENSURE(c, c->exit_tab, (size_t)n_dev * sizeof(am_shard_exit));
+            HIPCHK(c, am_launch_chain_exit_table((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, n_dev,
+                                                 (uint32_t)std::min<uint64_t>(lead_end - out_abs0, 0xFFFFFFFFull),
+                                                 (uint32_t *)c->cscratch.p, out_abs0, (am_shard_exit *)c->exit_tab.p,
+                                                 c->stream, Mp));
+            c->h_exit.resize(n_dev);
+            HIPCHK(c, hipMemcpyAsync(c->h_exit.data(), c->exit_tab.p, (size_t)n_dev * sizeof(am_shard_exit),
+                                     hipMemcpyDeviceToHost, c->stream));
+        }
+        if (Mp) HIPCHK(c, hipMemcpyAsync(&actual, Mp, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!Mp || actual <= M) { c->last_M = actual; break; }
+        // more candidates than the capacity this scan was launched for: once more with the exact count
+        if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: shard capacity %u < %u candidates, scan redone\n", M, actual);
+        rc = run_refine(c, c->ref_bb, c->ref_avg, c->ref_nseg, c->ref_stride, c->ref_mode, &M, c->ref_endj, 0);
+        if (rc != AM_OK) return rc;
     }
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->spec_density = (P1 > P0) ? (double)c->last_M / (double)(P1 - P0) : 0.0;
     (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
     (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
+    uint64_t nt = 0;
     for (uint32_t i = 0; i < n_dev; i++) {
         nt = i + 1;
         if (c->h_exit[i].pos >= lead_end) break;                // first candidate past the lead-in: last entry
@@ -1021,18 +996,7 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
     uint32_t fin = 0;
     const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
-    int rc;
-    if (c->chain_tables) {
-        rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits);
-    } else {
-        // visited[] from the blocked chain on the successor array (level 0 of the tables am_shard_scan built)
-        ENSURE(c, c->cscratch, am_chain_blocked_scratch(c->chain_M));
-        HIPCHK(c, am_launch_chain_blocked((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, c->chain_M, cur0, c->spc,
-                                          (uint32_t *)c->cscratch.p, (uint8_t *)c->visited.p,
-                                          (uint32_t *)c->scalars.p, c->stream));
-        rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits, 0,
-                          0xFFFFFFFFu, 0, true);
-    }
+    int rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits);
     if (rc != AM_OK) return rc;
     c->last_tags = c->h_packets.size();
     collect_accepted(c);

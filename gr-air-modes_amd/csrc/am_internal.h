@@ -90,14 +90,17 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
                             const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
                             float *inavg, uint8_t *valid, hipStream_t s);
-hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
-                                uint32_t *jump0, uint8_t *visited, hipStream_t s, const uint32_t *Mp = nullptr);
-size_t am_chain_blocked_scratch(uint32_t M);
-hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0, int spc,
-                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
-                                   const uint32_t *Mp = nullptr);
-hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s);
-hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s);
+/* greedy chain (am_kernels.hip): step 1 is independent of where the scan starts */
+size_t am_chain_scratch_bytes(uint32_t M);
+hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t *jump0,
+                                   uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp = nullptr);
+hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
+                                 uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
+                                 const uint32_t *Mp = nullptr);
+/* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
+hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
+                                      uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
+                                      hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
                                 const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
                                 uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
@@ -105,11 +108,6 @@ hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, co
 hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
                                   uint32_t *out_idx, hipStream_t s, const uint32_t *Mp = nullptr);
-hipError_t am_launch_chain_init(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited,
-                                uint32_t *scalars, hipStream_t s);
-hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
-                                int levels, int radix, uint32_t M, uint32_t n, uint64_t base_abs,
-                                am_shard_exit *table, hipStream_t s);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
 /* n_ptr: device-side number of hits; n_max: upper bound used for the grid */

@@ -633,8 +633,22 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
 // ------------------------------------------------------------------------------------------
 // Greedy chain.  The reference scan visits candidates in position order; after visiting c it
 // resumes at tgt[c], so the next visited candidate is succ(c) = first candidate with
-// pos >= tgt[c].  The visited set is the orbit of the root under succ: computed with
-// pointer doubling (jump tables) and top-down marking.  Node M is the end sentinel.
+// pos >= tgt[c] (node M is the end sentinel), and the visited set is the orbit of the root (the
+// first candidate at or after the position the scan starts from) under succ.  A successor is never
+// far away (a jump spans at most 241*spc + 1 positions), so the candidates are cut into blocks of
+// AM_CB nodes and
+//   1. am_k_cblk_exit : per block, in LDS, pointer jumping on the block's successor array: for
+//      EVERY node the first node of its orbit beyond the block (and, for the time-sharded path,
+//      the last one inside it); the exits of the block's first AM_CB_HEADW nodes -- its "head",
+//      where a jump from an earlier block lands -- also go to a dense table;
+//   2. am_k_cblk_walk : one workgroup copies the head table to LDS, finds the root and walks block
+//      to block (one LDS read per block; global memory only for the root and for an unusually
+//      long head): the node at which the scan enters each block;
+//   3. am_k_cblk_mark : per block, in LDS: log2(AM_CB) levels of 2^l-hop tables, top-down marking
+//      from the block's entry node, visited[] out.
+// Exact for any input, O(M) work, a handful of dependent global loads in all.  Step 1 does not
+// depend on where the scan starts, so a time shard runs it before its entry position is known and
+// derives its exit table (am_k_cblk_exit_table) from the same arrays.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ pos, uint32_t lo,
                                                    uint32_t hi, uint32_t key)
@@ -652,83 +666,12 @@ __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt, uint32_t Mcap,
-                uint32_t cur0, uint32_t *__restrict__ jump0, uint8_t *__restrict__ visited,
-                const uint32_t *__restrict__ Mp)
+                uint32_t *__restrict__ jump0, const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < M) jump0[g] = am_lower_bound(pos, g + 1, M, tgt[g]);
     if (g == M) jump0[M] = M;
-    if (g == 0 && visited) {
-        const uint32_t root = am_lower_bound(pos, 0, M, cur0);
-        if (root < M) visited[root] = 1;
-    }
-}
-
-// visited[] = {the first candidate the scan reaches when it (re)starts at cur0}; scalars[0] = cur0.
-// One launch instead of memset + copy + a one-thread kernel: every workgroup finds the root itself.
-__global__ void __launch_bounds__(256)
-am_k_chain_init(const uint32_t *__restrict__ pos, uint32_t M, uint32_t cur0, uint8_t *__restrict__ visited,
-                uint32_t *__restrict__ scalars)
-{
-    __shared__ uint32_t root_s;
-    if (threadIdx.x == 0) root_s = am_lower_bound(pos, 0, M, cur0);
-    __syncthreads();
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g <= M) visited[g] = (g == root_s && g < M) ? 1 : 0;
-    if (g == 0) { scalars[0] = cur0; scalars[1] = 0u; }
-}
-
-// Exit table of a time chunk (am_shard_scan): for each of the first n candidates, the scan
-// position after the chunk's LAST visited candidate if the scan enters at that candidate.
-// Walk the radix-R jump tables top-down, taking up to R-1 jumps per level while they stay
-// inside the list.
-__global__ void __launch_bounds__(256)
-am_k_chain_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt,
-                const uint32_t *__restrict__ jump, size_t stride, int levels, int radix, uint32_t M,
-                uint32_t n, uint64_t base_abs, am_shard_exit *__restrict__ table)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = i;
-    for (int k = levels; k >= 0; --k) {
-        const uint32_t *jk = jump + (size_t)k * stride;
-        for (int h = 1; h < radix; ++h) {
-            const uint32_t nx = jk[c];
-            if (nx >= M) break;
-            c = nx;
-        }
-    }
-    am_shard_exit t;
-    t.pos = base_abs + pos[i];
-    t.exit = base_abs + tgt[c];
-    table[i] = t;
-}
-
-__global__ void __launch_bounds__(256)
-am_k_chain_double(const uint32_t *__restrict__ jk, uint32_t *__restrict__ jk1, uint32_t M, int hops)
-{
-    // jk1 = jk applied `hops` times (radix-16 pointer jumping: fewer, fatter launches)
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > M) return;
-    uint32_t t = g;
-    for (int h = 0; h < hops && t < M; ++h) t = jk[t];
-    jk1[g] = t;
-}
-
-__global__ void __launch_bounds__(256)
-am_k_chain_mark(const uint32_t *__restrict__ jk, uint8_t *visited, uint32_t M, int hops)
-{
-    // every node already known to be visited marks its next hops-1 successors under jk
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < M && visited[g]) {
-        uint32_t t = g;
-        for (int h = 1; h < hops; ++h) {
-            t = jk[t];
-            if (t >= M) break;
-            visited[t] = 1;
-        }
-    }
 }
 
 __global__ void __launch_bounds__(AM_DET_THREADS)
@@ -774,19 +717,6 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Blocked greedy chain (single-GPU path).  The radix-16 tables above cost ~15 dependent global
-// loads per level and launch; but a successor is never far away (a jump spans at most
-// 241*spc + 1 positions), so the candidates are cut into blocks of AM_CB nodes and
-//   1. am_k_cblk_exit : per block, in LDS: for EVERY node the first node of its orbit that lies
-//      beyond the block (pointer jumping on the block's successor array), plus the size of the
-//      block's "head" -- the nodes a jump from an earlier block can land on;
-//   2. am_k_cblk_walk : one workgroup copies the heads' exit nodes to LDS and one lane walks
-//      block to block (one LDS read per block): the node at which the scan enters each block;
-//   3. am_k_cblk_mark : per block, in LDS: log2(AM_CB) jump levels, top-down marking from the
-//      block's entry node, visited[] out.
-// Three launches with a handful of dependent global loads in all.
-// ------------------------------------------------------------------------------------------
 #define AM_CB 2048                  /* nodes per block */
 #define AM_CB_THREADS 256
 #define AM_CB_PER (AM_CB / AM_CB_THREADS)
@@ -796,16 +726,15 @@ am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__
 #define AM_CB_NONE 0xFFFFFFFFu
 
 __global__ void __launch_bounds__(AM_CB_THREADS)
-am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw,
-               uint32_t cur0, uint32_t *__restrict__ exitnode, uint32_t *__restrict__ headexit,
-               uint32_t *__restrict__ root, const uint32_t *__restrict__ Mp)
+am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw, uint32_t *__restrict__ exitnode,
+               uint32_t *__restrict__ lastnode, uint32_t *__restrict__ headexit, const uint32_t *__restrict__ Mp)
 {
-    __shared__ uint32_t e[2][AM_CB];
+    __shared__ uint32_t e[2][AM_CB];           // orbit node 2^r hops ahead, clipped to the first one outside
+    __shared__ uint32_t l[2][AM_CB];           // the orbit node just before it (always inside the block)
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t base = blockIdx.x * AM_CB;
     if (base >= M) {                                          // (capacity launch: nothing here)
         for (uint32_t i = threadIdx.x; i < headw; i += blockDim.x) headexit[(size_t)blockIdx.x * headw + i] = M;
-        if (M == 0 && blockIdx.x == 0 && threadIdx.x == 0) *root = 0;
         return;
     }
     const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
@@ -813,12 +742,7 @@ am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ju
     for (int k = 0; k < AM_CB_PER; ++k) {
         const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
         e[0][i] = (i < n) ? jump0[base + i] : end;
-        // root of the scan = first candidate with pos >= cur0: exactly one node (or the end) qualifies
-        if (i < n) {
-            const uint32_t g = base + i;
-            if (pos[g] >= cur0 && (g == 0 || pos[g - 1] < cur0)) *root = g;
-            if (g == M - 1 && pos[g] < cur0) *root = M;
-        }
+        l[0][i] = base + i;
     }
     __syncthreads();
     int cur = 0;
@@ -826,31 +750,26 @@ am_k_cblk_exit(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ju
         for (int k = 0; k < AM_CB_PER; ++k) {
             const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
             const uint32_t t = e[cur][i];
-            e[cur ^ 1][i] = (t < end) ? e[cur][t - base] : t;
+            const bool in = t < end;
+            e[cur ^ 1][i] = in ? e[cur][t - base] : t;
+            l[cur ^ 1][i] = in ? l[cur][t - base] : l[cur][i];
         }
         cur ^= 1;
         __syncthreads();
     }
     for (int k = 0; k < AM_CB_PER; ++k) {
         const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-        if (i < n) exitnode[base + i] = e[cur][i];
-        // the block's head (the nodes a jump from an earlier block can land on: a jump spans at most
-        // 241*spc + 1 positions, a few dozen candidates) once more, densely, for the walk's LDS copy
+        if (i < n) {
+            exitnode[base + i] = e[cur][i];
+            if (lastnode) lastnode[base + i] = l[cur][i];
+        }
         if (i < headw) headexit[(size_t)blockIdx.x * headw + i] = (i < n) ? e[cur][i] : M;
     }
 }
 
-// entry[b] = node at which the scan enters block b, AM_CB_NONE if it jumps over the block.
-// scalars[0] = cur0, scalars[1] = 0 (as am_k_chain_init leaves them).
-__global__ void __launch_bounds__(1024)
-am_k_cblk_walk(const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ headexit,
-               const uint32_t *__restrict__ root, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
-               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
+// head table -> LDS, in batches of 8 independent loads per thread (one memory round trip per batch)
+__device__ __forceinline__ void am_cblk_load_heads(uint32_t *hx, const uint32_t *__restrict__ headexit, uint32_t total)
 {
-    const uint32_t M = am_count(Mcap, Mp);
-    HIP_DYNAMIC_SHARED(uint32_t, hx);          // [nblk * headw] exit nodes of the heads
-    const uint32_t total = nblk * headw;
-    // batches of 8 independent loads per thread (one memory round trip per batch, not per word)
     for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {
         uint32_t t[8];
 #pragma unroll
@@ -864,19 +783,84 @@ am_k_cblk_walk(const uint32_t *__restrict__ exitnode, const uint32_t *__restrict
             if (f < total) hx[f] = t[k];
         }
     }
+}
+
+// one step of the block walk: where the orbit that is at node `cur` leaves cur's block
+__device__ __forceinline__ uint32_t am_cblk_step(const uint32_t *hx, const uint32_t *__restrict__ exitnode,
+                                                 uint32_t headw, uint32_t cur)
+{
+    const uint32_t b = cur / AM_CB, idx = cur % AM_CB;
+    return (idx < headw) ? hx[b * headw + idx] : exitnode[cur];     // (root, or an unusually long head)
+}
+
+// entry[b] = node at which the scan that starts at position cur0 enters block b, AM_CB_NONE if it
+// jumps over the block.  scalars[0] = cur0 (the emit kernel raises it to the resume position),
+// scalars[1] = 0.
+__global__ void __launch_bounds__(1024)
+am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
+               const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
+               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
+{
+    const uint32_t M = am_count(Mcap, Mp);
+    HIP_DYNAMIC_SHARED(uint32_t, hx);          // [nblk * headw] exit nodes of the heads
+    __shared__ uint32_t seg, root_s;
+    am_cblk_load_heads(hx, headexit, nblk * headw);
+    // root = first candidate with pos >= cur0, in two parallel rounds (two dependent loads in all):
+    // which of 1024 equal segments holds it, then which node of that segment
+    const uint32_t stride = (M + blockDim.x - 1u) / blockDim.x;
+    if (threadIdx.x == 0) { seg = M; root_s = M; scalars[0] = cur0; scalars[1] = 0u; }
+    __syncthreads();
+    if (stride) {
+        const uint32_t lo = threadIdx.x * stride;
+        const uint32_t hi = (lo + stride < M) ? lo + stride : M;
+        if (lo < M && pos[hi - 1u] >= cur0 && (lo == 0 || pos[lo - 1u] < cur0)) seg = lo;
+    }
+    __syncthreads();
+    for (uint32_t g = seg + threadIdx.x; g < M && g < seg + stride; g += blockDim.x)
+        if (pos[g] >= cur0 && (g == 0 || pos[g - 1u] < cur0)) root_s = g;
     __syncthreads();
     if (threadIdx.x == 0) {
-        scalars[0] = cur0;
-        scalars[1] = 0u;
-        uint32_t cur = *root;
+        uint32_t cur = root_s;
         for (uint32_t b = 0; b < nblk; ++b) {
             const uint32_t base = b * AM_CB;
             const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
             if (cur >= end || base >= M) { entry[b] = AM_CB_NONE; continue; }
             entry[b] = cur;
-            const uint32_t idx = cur - base;
-            cur = (idx < headw) ? hx[b * headw + idx] : exitnode[cur];    // (root, or an unusually long head)
+            cur = am_cblk_step(hx, exitnode, headw, cur);
         }
+    }
+}
+
+// Exit table of a time chunk (am_shard_scan): for each of the chunk's first n candidates, the scan
+// position after the chunk's LAST visited candidate if the scan enters at that candidate.
+__global__ void __launch_bounds__(1024)
+am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt,
+                     const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ lastnode,
+                     const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t n,
+                     uint32_t lead_end, uint64_t base_abs, am_shard_exit *__restrict__ table,
+                     const uint32_t *__restrict__ Mp)
+{
+    const uint32_t M = am_count(Mcap, Mp);
+    HIP_DYNAMIC_SHARED(uint32_t, hx);
+    am_cblk_load_heads(hx, headexit, nblk * headw);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        am_shard_exit t;
+        if (i >= M) {                                        // (capacity launch) end marker: "no candidate here"
+            t.pos = ~(uint64_t)0;
+            t.exit = 0;
+            table[i] = t;
+            continue;
+        }
+        t.pos = base_abs + pos[i];
+        t.exit = 0;
+        // the table ends with the first candidate at or past lead_end: later entries are never read
+        if (i == 0 || pos[i - 1u] < lead_end) {
+            uint32_t cur = i, ent = i;                       // ent: entry node of the last block the orbit touches
+            while (cur < M) { ent = cur; cur = am_cblk_step(hx, exitnode, headw, cur); }
+            t.exit = base_abs + tgt[lastnode[ent]];
+        }
+        table[i] = t;
     }
 }
 
@@ -937,39 +921,6 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
 
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
-hipError_t am_launch_chain_succ(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t cur0,
-                                uint32_t *jump0, uint8_t *visited, hipStream_t s, const uint32_t *Mp)
-{
-    hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M,
-                       cur0, jump0, visited, Mp);
-    return hipGetLastError();
-}
-hipError_t am_launch_chain_init(const uint32_t *pos, uint32_t M, uint32_t cur0, uint8_t *visited,
-                                uint32_t *scalars, hipStream_t s)
-{
-    hipLaunchKernelGGL(am_k_chain_init, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, M, cur0, visited,
-                       scalars);
-    return hipGetLastError();
-}
-hipError_t am_launch_chain_exit(const uint32_t *pos, const uint32_t *tgt, const uint32_t *jump, size_t stride,
-                                int levels, int radix, uint32_t M, uint32_t n, uint64_t base_abs,
-                                am_shard_exit *table, hipStream_t s)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_chain_exit, dim3(am_grid(n, 256)), dim3(256), 0, s, pos, tgt, jump, stride, levels,
-                       radix, M, n, base_abs, table);
-    return hipGetLastError();
-}
-hipError_t am_launch_chain_double(const uint32_t *jk, uint32_t *jk1, uint32_t M, int hops, hipStream_t s)
-{
-    hipLaunchKernelGGL(am_k_chain_double, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, jk, jk1, M, hops);
-    return hipGetLastError();
-}
-hipError_t am_launch_chain_mark(const uint32_t *jk, uint8_t *visited, uint32_t M, int hops, hipStream_t s)
-{
-    hipLaunchKernelGGL(am_k_chain_mark, dim3(am_grid(M, 256)), dim3(256), 0, s, jk, visited, M, hops);
-    return hipGetLastError();
-}
 static uint32_t am_chain_headw(uint32_t nblk)
 {
     uint32_t w = AM_CB_HEADW;
@@ -977,37 +928,78 @@ static uint32_t am_chain_headw(uint32_t nblk)
     return ((uint64_t)nblk * w > AM_CB_HEADCAP) ? 0u : w;       // 0: every step of the walk reads global memory
 }
 
-size_t am_chain_blocked_scratch(uint32_t M)
+struct am_chain_layout {
+    uint32_t nblk, headw;
+    size_t off_last, off_entry, off_head, words;    // offsets (in words) into the scratch buffer
+};
+static am_chain_layout am_chain_layout_of(uint32_t M)
 {
-    const size_t nblk = ((size_t)M + AM_CB - 1) / AM_CB;
-    // exitnode[M+1] | entry[nblk] | root | headexit[nblk * headw]
-    return ((size_t)M + 1 + nblk + 8 + nblk * am_chain_headw((uint32_t)nblk)) * sizeof(uint32_t);
+    am_chain_layout L;
+    L.nblk = (M + AM_CB - 1) / AM_CB;
+    L.headw = am_chain_headw(L.nblk);
+    L.off_last = (size_t)M + 1;                     // exitnode[M+1] | lastnode[M+1] | entry[nblk+8] | headexit
+    L.off_entry = L.off_last + (size_t)M + 1;
+    L.off_head = L.off_entry + L.nblk + 8;
+    L.words = L.off_head + (size_t)L.nblk * L.headw + 8;
+    return L;
+}
+size_t am_chain_scratch_bytes(uint32_t M) { return am_chain_layout_of(M).words * sizeof(uint32_t); }
+
+static hipError_t am_chain_walk_lds(const void *kernel)
+{
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((AM_CB_HEADCAP + 1) * sizeof(uint32_t)));
 }
 
-// visited[] for the scan that starts at position cur0, given the successor array jump0[] (am_k_chain_succ)
-hipError_t am_launch_chain_blocked(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0, int spc,
-                                   uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
-                                   const uint32_t *Mp)
+// step 1 (independent of where the scan starts): successor array + per-block exits
+hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t *jump0,
+                                   uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp)
 {
-    (void)spc;
     if (M == 0) return hipSuccess;
-    const uint32_t nblk = (M + AM_CB - 1) / AM_CB;
-    const uint32_t headw = am_chain_headw(nblk);
-    uint32_t *exitnode = scratch, *entry = scratch + ((size_t)M + 1), *root = entry + nblk, *headexit = root + 8;
-    hipLaunchKernelGGL(am_k_cblk_exit, dim3(nblk), dim3(AM_CB_THREADS), 0, s, pos, jump0, M, headw, cur0, exitnode,
-                       headexit, root, Mp);
-    const size_t lds = ((size_t)nblk * headw + 1) * sizeof(uint32_t);
+    const am_chain_layout L = am_chain_layout_of(M);
+    hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M, jump0, Mp);
+    hipLaunchKernelGGL(am_k_cblk_exit, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, M, L.headw, scratch,
+                       want_last ? scratch + L.off_last : nullptr, scratch + L.off_head, Mp);
+    return hipGetLastError();
+}
+
+// steps 2 + 3: visited[] for the scan that starts at position cur0
+hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
+                                 uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
+                                 const uint32_t *Mp)
+{
+    if (M == 0) return hipSuccess;
+    const am_chain_layout L = am_chain_layout_of(M);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_cblk_walk),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)((AM_CB_HEADCAP + 1) * sizeof(uint32_t)));
+        hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_walk));
         if (rc != hipSuccess) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, exitnode, headexit, root, M, nblk, headw, cur0,
-                       entry, scalars, Mp);
-    hipLaunchKernelGGL(am_k_cblk_mark, dim3(nblk), dim3(AM_CB_THREADS), 0, s, jump0, entry, M, visited, Mp);
+    const size_t lds = ((size_t)L.nblk * L.headw + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, scratch + L.off_head, M, L.nblk,
+                       L.headw, cur0, scratch + L.off_entry, scalars, Mp);
+    hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M,
+                       visited, Mp);
+    return hipGetLastError();
+}
+
+// exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))
+hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
+                                      uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
+                                      hipStream_t s, const uint32_t *Mp)
+{
+    if (n == 0 || M == 0) return hipSuccess;
+    const am_chain_layout L = am_chain_layout_of(M);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_exit_table));
+        if (rc != hipSuccess) return rc;
+        attr_set = true;
+    }
+    const size_t lds = ((size_t)L.nblk * L.headw + 1) * sizeof(uint32_t);
+    hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
+                       scratch + L.off_head, M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
     return hipGetLastError();
 }
 

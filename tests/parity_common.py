@@ -93,12 +93,15 @@ def check_chunked(lib, rate, iq, edges, thr=7.0, pmf=True, want=None):
     return len(got)
 
 
-def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None):
-    """Time-sharded operation (G chunks, exit-table exchange) == whole-stream result."""
+def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None, ctxs=None):
+    """Time-sharded operation (G chunks, exit-table exchange) == whole-stream result.  `ctxs`: reuse
+    these contexts (one per chunk, as a receiver that steps over many batches does) and keep them open."""
     n = len(iq)
     if want is None:
         want = oracle.demod(iq, rate, thr, pmf)
-    ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
+    keep = ctxs is not None
+    if not keep:
+        ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
     hl, hr = ctxs[0].shard_halo()
     bounds = [(g * n) // G for g in range(G + 1)]
     tables = []
@@ -107,8 +110,9 @@ def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None):
         tables.append(ctxs[g].shard_scan(iq[max(0, a - hl):min(n, b + hr)], a, b, n))
     entry = _capi.shard_entries(lib, tables, bounds[:-1])
     got = np.concatenate([ctxs[g].shard_resolve(int(entry[g])) for g in range(G)])
-    for c in ctxs:
-        c.close()
+    if not keep:
+        for c in ctxs:
+            c.close()
     assert np.array_equal(got, want), "sharded result differs (%d vs %d packets)" % (len(got), len(want))
     return len(got)
 

@@ -103,13 +103,10 @@ def test_crc_and_format_helpers(emu_lib):
         assert emu_lib.crc24(bytes.fromhex(h)) == oracle.crc24(bytes.fromhex(h))
 
 
-@pytest.mark.parametrize("tables", ["0", "1"])
-def test_greedy_chain_many_blocks(emu_lib, monkeypatch, tables):
+def test_greedy_chain_many_blocks(emu_lib):
     """Dense traffic: several thousand first-stage candidates per call, so the blocked chain runs
-    over many 2048-node blocks (and, with AIRMODES_CHAIN_TABLES=1, the radix-16 jump tables the
-    sharded path uses); resumed across calls at odd cut points."""
+    over many 2048-node blocks; resumed across calls at odd cut points, and time-sharded."""
     from air_modes import _capi
-    monkeypatch.setenv("AIRMODES_CHAIN_TABLES", tables)
     rate = 8e6
     iq, _ = synth.synth_capture(rate, 4000000, 20000.0, seed=606)
     want = oracle.demod(iq, rate, 7.0, True)
@@ -120,6 +117,7 @@ def test_greedy_chain_many_blocks(emu_lib, monkeypatch, tables):
     ctx.close()
     assert m1 > 3 * 2048, m1
     assert np.array_equal(np.concatenate(got), want) and len(want) > 100
+    assert pc.check_sharded(emu_lib, rate, iq, 3, want=want) == len(want)
 
 
 def test_speculative_capacity_overflow_is_redone(emu_lib, monkeypatch):
@@ -147,3 +145,18 @@ def test_speculative_capacity_overflow_is_redone(emu_lib, monkeypatch):
     got = [ctx.process_iq(iq[:700001]), ctx.process_iq(iq[700001:], flush=True)]
     ctx.close()
     assert np.array_equal(np.concatenate(got), want)
+
+
+def test_sharded_steps_with_capacity_overflow(emu_lib, monkeypatch):
+    """A time-sharded receiver steps over batch after batch with the same contexts, so its scans are
+    launched for an extrapolated candidate capacity too: quiet batch, then a dense one with no slack."""
+    from air_modes import _capi
+    monkeypatch.setenv("AIRMODES_SPEC_FLOOR", "0")
+    rate, G = 8e6, 3
+    ctxs = [_capi.Context(rate, 7.0, True, lib=emu_lib) for _ in range(G)]
+    quiet, _ = synth.synth_capture(rate, 900000, 40.0, seed=621)
+    busy, _ = synth.synth_capture(rate, 900000, 20000.0, seed=622)
+    for iq in (quiet, quiet, busy, busy, quiet):
+        pc.check_sharded(emu_lib, rate, iq, G, ctxs=ctxs)
+    for c in ctxs:
+        c.close()
