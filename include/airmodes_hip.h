@@ -153,8 +153,8 @@ int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
  * result depends on its predecessor only through which of its first few candidates (those in
  * its first 241*spc samples, the "lead-in") the scan enters at.  Protocol per step:
  *   1. every rank attaches its neighbours' boundary samples (am_shard_halo) and runs
- *      am_shard_scan on its chunk: front end, detection, refinement, successor array and block exits of its own
- *      greedy chain -- and an EXIT TABLE: for each lead-in candidate (plus the first candidate
+ *      am_shard_scan on its chunk: front end, detection, refinement, successor array and block
+ *      exits of its own greedy chain -- and an EXIT TABLE: for each lead-in candidate (plus the first candidate
  *      after the lead-in, if any) the position at which the scan would leave the chunk if it
  *      entered at that candidate;
  *   2. the small tables are exchanged (all-gather, a few KB), every rank composes them
