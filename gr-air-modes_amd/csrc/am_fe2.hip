@@ -152,6 +152,7 @@ struct am_fe2_args {
     int use_pmf;
     float s1, sL, thr_lin;
     unsigned ablate;                // profiling only (AIRMODES_FE2_ABLATE): skip phases, results invalid
+    unsigned stagger, stagger_n;    // start-up delay (shader clocks) spread over the first stagger_n workgroups
     long long *clk;                 // profiling only (AIRMODES_FE2_CLOCK): per tile, 2 waves x 16 phase stamps
 };
 
@@ -575,6 +576,12 @@ __global__ void __launch_bounds__(FE2_NT, FE2_WPS) am_k_fe2(am_fe2_args a)
     if (fwd >= nb) return;                                  // whole workgroup (uniform)
     const unsigned tile = nb - 1u - fwd;
     if (a.ablate & 1024u) { if (threadIdx.x == 0) a.blk_cnt[tile] = 0; return; }
+    if (a.stagger && blockIdx.x < a.stagger_n) {
+        // first round of workgroups (one per CU): spread their start over `stagger` clocks so that the
+        // CUs do not all load, and then all compute, at the same time
+        const long long until = (long long)clock64() + (long long)(((blockIdx.x * 2654435769u) >> 8) % a.stagger);
+        while ((long long)clock64() < until) __builtin_amdgcn_s_sleep(32);
+    }
     const long long jt0 = (long long)tile * T;              // array coordinate of the tile start
     const long long rel0 = a.out_abs0 + jt0 - LH - a.src_abs0;
     const bool interior = rel0 >= 1 && rel0 + W + 2 <= a.src_abs1 - a.src_abs0 &&
@@ -582,6 +589,18 @@ __global__ void __launch_bounds__(FE2_NT, FE2_WPS) am_k_fe2(am_fe2_args a)
                           jt0 + T <= (long long)a.j1 && jt0 + T <= a.out_n && !(a.ablate & (16u | 2048u));
     if (interior) fe2_tile<SPC, CPT, false>(a, tile, smem);
     else fe2_tile<SPC, CPT, true>(a, tile, smem);
+}
+
+static int ncu_for_stagger()
+{
+    static int ncu = 0;
+    if (ncu == 0) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return ncu;
 }
 
 template <int SPC, int CPT>
@@ -604,6 +623,14 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
     if (rc != hipSuccess) return rc;
     const unsigned grid = ((a.ntiles + 7u) / 8u) * 8u;     // whole XCD rounds (extra groups exit)
+    // Workgroups that start together stay in lockstep (same work per tile): the whole chip would load
+    // (HBM saturated), then compute (HBM idle), in turns.  The first round of workgroups -- one per CU
+    // -- therefore starts spread over about one tile time (measured optimum: 0.85-0.95 tile times,
+    // -12 % kernel time at 64 Msps, -9 % at 20 Msps, nothing at 2-4 Msps where tiles are compute bound);
+    // later workgroups inherit the offsets because each starts when its CU becomes free.
+    a.stagger = (SPC >= 8) ? 1300u * (unsigned)R : 0u;
+    a.stagger_n = (unsigned)ncu_for_stagger();
+    if (const char *x = getenv("AIRMODES_FE2_STAGGER")) a.stagger = (unsigned)atoi(x);
     // profiling only: per-phase clock stamps, printed as average cycles between stamps (blocking)
     static const bool want_clk = getenv("AIRMODES_FE2_CLOCK") != nullptr;
     a.clk = nullptr;

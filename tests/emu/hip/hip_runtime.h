@@ -32,7 +32,8 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __shared__ static
 #define __constant__
 #define __launch_bounds__(...)
-static inline long long clock64() { return 0; }
+// a clock that always advances (kernels may wait on it)
+static inline long long clock64() { static long long t = 0; return t += 1000; }
 #define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(hipemu::dyn_smem());
 
 typedef int hipError_t;
@@ -53,6 +54,7 @@ uint64_t shuffle(uint64_t v, int src_lane_rel, int width, int mode);   // mode 0
 inline void __syncthreads() { hipemu::barrier(); }
 // wave-level compiler fence in the product = a real rendezvous of the wave's fibers here
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::ballot(0))
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
@@ -82,6 +84,8 @@ template <class T> inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; 
 
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 3; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "ok" : "emu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
