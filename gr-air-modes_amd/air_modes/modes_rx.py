@@ -26,6 +26,8 @@ def build_parser():
                     help="pulse detection threshold above noise in dB [default=%(default)s]")            # :114
     ap.add_argument("-p", "--pmf", action="store_true", default=True, help="use pulse matched filtering")  # :116
     ap.add_argument("--no-pmf", dest="pmf", action="store_false")
+    ap.add_argument("-d", "--dcblock", action="store_true", default=False,
+                    help="use a DC blocking filter (best for HackRF Jawbreaker)")                         # :118
     ap.add_argument("-l", "--location", default=None, help="receiver position as lat,lon (enables range/bearing "
                     "and surface positions)")                                                            # modes_rx:40
     ap.add_argument("-n", "--no-print", action="store_true", help="do not print decoded reports")       # modes_rx:45
@@ -40,7 +42,7 @@ def main(argv=None, out=None):
     from . import cpr_decoder, make_parser, msg_queue, output_print, pubsub, rx_path
 
     queue = msg_queue()
-    rx = rx_path(args.rate, args.threshold, queue, use_pmf=args.pmf)
+    rx = rx_path(args.rate, args.threshold, queue, use_pmf=args.pmf, use_dcblock=args.dcblock)
     publisher = pubsub()
     feed = make_parser(publisher)
     my_position = [float(n) for n in args.location.split(",")] if args.location else None

@@ -53,6 +53,7 @@ struct am_ctx {
     uint32_t ref_nseg = 0, ref_stride = 0, ref_endj = 0;   // arguments of the last run_refine (for the redo)
     int ref_mode = 0;
     const float *ref_bb = nullptr, *ref_avg = nullptr;
+    int use_dcblock = 0;          // a2: dc_blocker_cc(100*spc, False) in front of |.|^2 (rx_path.py:39-41)
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     char err[256] = "";
@@ -68,7 +69,7 @@ struct am_ctx {
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         visited, emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
-        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch;
+        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch, dc_m1, dc_y;
 
     // results of the last scan
     std::vector<am_packet> h_packets;   // every sliced burst, reserved[0] = accepted
@@ -179,6 +180,26 @@ void reset_stream(am_ctx *c)
 
 // positions beyond the end of the data read zeros: every bb/avg array carries this pad
 inline uint64_t zero_pad(int spc) { return (uint64_t)260 * (uint64_t)spc + 64; }
+
+// a2: when the DC blocker is on, the path runs on y = dcblock(x) instead of x.  `*src`/`*src_abs0`
+// describe the raw samples present, [need0, src_abs1) is what the front end will read; on return
+// they describe the filtered samples.  Raw history of am_dcblock_history() samples before need0
+// (or back to sample 0) must be present.
+int apply_dcblock(am_ctx *c, const float **src, uint64_t *src_abs0, uint64_t src_abs1, uint64_t need0)
+{
+    if (!c->use_dcblock || src_abs1 <= need0) return AM_OK;
+    const uint64_t H = am_dcblock_history(c->spc);
+    const uint64_t raw0 = need0 > H ? need0 - H : 0;
+    if (*src_abs0 > raw0) return fail(c, AM_EINVAL, "internal: DC blocker history was not carried");
+    const uint64_t yn = src_abs1 - need0;
+    ENSURE(c, c->dc_y, yn * 2 * sizeof(float));
+    ENSURE(c, c->dc_m1, (yn + H / 2 + 1) * 2 * sizeof(float));
+    HIPCHK(c, am_launch_dcblock(*src, (long long)*src_abs0, (long long)src_abs1, (long long)need0, (long long)yn,
+                                c->spc, (float *)c->dc_m1.p, (float *)c->dc_y.p, c->stream));
+    *src = (const float *)c->dc_y.p;
+    *src_abs0 = need0;
+    return AM_OK;
+}
 
 int run_frontend(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_abs1, uint64_t out_abs0,
                  uint64_t out_n, float *bb, float *avg)
@@ -475,11 +496,6 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
     am_ctx *c = nullptr;
     g_create_err[0] = 0;
     do {
-        if (use_dcblock) {
-            snprintf(g_create_err, sizeof(g_create_err), "use_dcblock is not implemented");
-            code = AM_ENOTSUP;
-            break;
-        }
         int ndev = 0;
         hipError_t rc = hipGetDeviceCount(&ndev);
         if (rc != hipSuccess || ndev <= 0) {
@@ -506,6 +522,7 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         }
         for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
         c->use_pmf = use_pmf ? 1 : 0;
+        c->use_dcblock = use_dcblock ? 1 : 0;
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
@@ -541,7 +558,7 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->exit_tab, &c->cscratch};
+                     &c->recs, &c->exit_tab, &c->cscratch, &c->dc_m1, &c->dc_y};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -638,7 +655,13 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         const uint64_t out_abs0 = (P0 / L) * L;
         const uint64_t out_n = S1 - out_abs0;
         const uint64_t need0 = out_abs0 > LH ? out_abs0 - LH : 0;
-        if (src_abs0 > need0) return fail(c, AM_EINVAL, "internal: stream history was not carried");
+        const float *fsrc = src;
+        uint64_t fsrc_abs0 = src_abs0;
+        {
+            int rc = apply_dcblock(c, &fsrc, &fsrc_abs0, S1, need0);
+            if (rc != AM_OK) return rc;
+        }
+        if (fsrc_abs0 > need0) return fail(c, AM_EINVAL, "internal: stream history was not carried");
         const uint64_t pad = zero_pad(c->spc);
         const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
@@ -651,7 +674,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         }
         const uint32_t j0 = (uint32_t)(P0 - out_abs0), j1 = (uint32_t)(P1 - out_abs0);
         uint32_t M = 0;
-        int rc = run_front_and_candidates(c, src, src_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M, true);
+        int rc = run_front_and_candidates(c, fsrc, fsrc_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M, true);
         if (rc != AM_OK) return rc;
         const uint32_t cur0 = c->chain_cur > out_abs0 ? (uint32_t)std::min<uint64_t>(c->chain_cur - out_abs0, 0xFFFFFFF0u) : 0u;
         const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - out_abs0);
@@ -680,7 +703,8 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         reset_stream(c);
     } else {
         const uint64_t blk = (c->next_pos / L) * L;
-        const uint64_t C0 = blk > LH ? blk - LH : 0;
+        const uint64_t hist = LH + (c->use_dcblock ? am_dcblock_history(c->spc) : 0);
+        const uint64_t C0 = blk > hist ? blk - hist : 0;
         const uint64_t keep = S1 - C0;
         if (keep) {
             ENSURE(c, c->carry2, keep * 2 * sizeof(float));
@@ -731,7 +755,9 @@ int am_frontend_work(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, flo
         dbb = (float *)c->bb.p;
         davg = (float *)c->avg.p;
     }
-    int rc;
+    uint64_t s0 = 0;
+    int rc = apply_dcblock(c, &src, &s0, n, 0);
+    if (rc != AM_OK) return rc;
     if (!c->force_generic && am_fe2_tile(c->spc)) {
         uint32_t M = 0;      // fused kernel with an empty detection range: bb/avg only
         rc = run_front_and_candidates(c, src, 0, n, 0, n, dbb, davg, 0, 0, &M);
@@ -856,6 +882,7 @@ int am_shard_halo(const am_ctx *c, uint64_t *left, uint64_t *right)
     if (!c || !left || !right) return AM_EINVAL;
     const uint64_t S = (uint64_t)c->spc;
     *left = 2 * (uint64_t)AM_CHIPS_AVG * S + S;     // up to one block (alignment) + one block + one chip
+    if (c->use_dcblock) *left += am_dcblock_history(c->spc);
     *right = (uint64_t)(AM_BURST + 4) * S;          // late shift + 240-chip burst
     return AM_OK;
 }
@@ -891,7 +918,12 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     if (flush_limits(total_n, c->spc, &em)) P1 = std::max(P0, std::min(abs_end, em + 1));
     const uint64_t out_abs0 = (abs_start / L) * L;
     const uint64_t need0 = out_abs0 > LH ? out_abs0 - LH : 0;
-    if (src_abs0 > need0) return fail(c, AM_EINVAL, "internal: left halo too short");
+    uint64_t fsrc_abs0 = src_abs0;
+    {
+        int rc = apply_dcblock(c, &src, &fsrc_abs0, src_abs1, need0);
+        if (rc != AM_OK) return rc;
+    }
+    if (fsrc_abs0 > need0) return fail(c, AM_EINVAL, "internal: left halo too short");
     const uint64_t out_n = src_abs1 - out_abs0;
     const uint64_t pad = zero_pad(c->spc);
     uint32_t M = 0;
@@ -907,7 +939,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
             avg = (float *)c->avg.p;
             HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
         }
-        int rc = run_front_and_candidates(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg,
+        int rc = run_front_and_candidates(c, src, fsrc_abs0, src_abs1, out_abs0, out_n, bb, avg,
                                           (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M, true);
         if (rc != AM_OK) return rc;
     }

@@ -55,6 +55,12 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
                           uint8_t *valid, hipStream_t s, const uint32_t *Mp = nullptr);
+/* ---- optional DC blocker in front of the path (am_dcblock.hip) ---------------------------- */
+#define AM_DC_CHIPS 100              /* rx_path.py:40  dc_blocker_cc(100*spc, False) */
+unsigned long long am_dcblock_history(int spc);
+hipError_t am_launch_dcblock(const float *raw, long long raw_abs0, long long raw_abs1, long long y_abs0, long long y_n,
+                             int spc, float *m1, float *y, hipStream_t s);
+
 /* Launchers that take a candidate count M also take an optional device pointer Mp: when given, the
  * kernels use min(M, *Mp), so that the host may launch for a capacity without knowing the count. */
 /* ---- preamble detection / refinement / greedy chain ----------------------------------- */

@@ -32,7 +32,7 @@ extern "C" {
 #define AM_ENOMEM     (-3)   /* host or device allocation failed                            */
 #define AM_EHIP       (-4)   /* a HIP runtime call failed (see am_last_error)               */
 #define AM_ECAPACITY  (-5)   /* output did not fit; *n_out holds the required count         */
-#define AM_ENOTSUP    (-6)   /* option not implemented (use_dcblock)                        */
+#define AM_ENOTSUP    (-6)   /* option not implemented (none at present)                    */
 
 /* flags for the *_work / am_process_iq calls */
 #define AM_F_DEVICE_IN  0x1u  /* input pointers are device memory on the context's GPU      */
@@ -79,7 +79,11 @@ uint32_t am_abi_version(void);
  *           (include/gr_air_modes/preamble.h:39), gr::air_modes::slicer::make(queue)
  *           (include/gr_air_modes/slicer.h:41).
  * rate must be a positive multiple of 2 MHz (integer samples per chip).
- * use_dcblock != 0 -> NULL + AM_ENOTSUP (python/radio.py:118 default is off).
+ * use_dcblock != 0 puts filter.dc_blocker_cc(100*spc, False) in front of the path
+ * (python/rx_path.py:39-41; default off, python/radio.py:118): two cascaded 100-chip moving
+ * averages subtracted from the input delayed by 100*spc - 1 samples -- so, as in the reference,
+ * every timestamp is later by that delay.  GNU Radio's gr-filter source is not part of the
+ * reference tree (parity unpinned): the window sums use the canonical order of DESIGN.md section 3.
  * device < 0 selects the current HIP device.  Returns NULL on failure; *err (optional)
  * receives the code. */
 am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock,

@@ -97,12 +97,15 @@ static int moving_sum_chip(const float *x, uint64_t n, int spc, float scale,
     return 0;
 }
 
-static int moving_sum_block(const float *x, uint64_t n, int spc, float scale,
-                            float *out, float *pre, float *suf)
+/* window = `chips` chips, blocks of `chips` chips aligned to sample 0; out[i] = sum * scale when
+ * divisor == 0, sum / divisor otherwise */
+static int moving_sum_blockc(const float *x, uint64_t n, int spc, int chips, float scale, float divisor,
+                             float *out, float *pre, float *suf)
 {
-    const uint64_t L = (uint64_t)CHIPS_PER_AVG * (uint64_t)spc;
+    const uint64_t CH = (uint64_t)chips;
+    const uint64_t L = CH * (uint64_t)spc;
     const uint64_t nchips = (n + (uint64_t)spc - 1) / (uint64_t)spc;
-    const uint64_t nchips_pad = (nchips + CHIPS_PER_AVG - 1) / CHIPS_PER_AVG * CHIPS_PER_AVG;
+    const uint64_t nchips_pad = (nchips + CH - 1) / CH * CH;
     float *tot = (float *)calloc(nchips_pad ? nchips_pad : 1, sizeof(float));
     float *PT = (float *)calloc(nchips_pad ? nchips_pad : 1, sizeof(float));
     float *ST = (float *)calloc(nchips_pad ? nchips_pad : 1, sizeof(float));
@@ -114,11 +117,11 @@ static int moving_sum_block(const float *x, uint64_t n, int spc, float scale,
         if (last >= n) last = n - 1;
         tot[q] = pre[last];
     }
-    for (uint64_t b = 0; b < nchips_pad; b += CHIPS_PER_AVG) {
+    for (uint64_t b = 0; b < nchips_pad; b += CH) {
         float acc = 0.0f;
-        for (int j = 0; j < CHIPS_PER_AVG; j++) { PT[b + j] = acc; acc = acc + tot[b + j]; }
+        for (int j = 0; j < chips; j++) { PT[b + j] = acc; acc = acc + tot[b + j]; }
         acc = 0.0f;
-        for (int j = CHIPS_PER_AVG - 1; j >= 0; j--) { ST[b + j] = acc; acc = acc + tot[b + j]; }
+        for (int j = chips - 1; j >= 0; j--) { ST[b + j] = acc; acc = acc + tot[b + j]; }
     }
     for (uint64_t i = 0; i < n; i++) {
         uint64_t q = i / (uint64_t)spc;
@@ -131,10 +134,50 @@ static int moving_sum_block(const float *x, uint64_t n, int spc, float scale,
             float SUF = suf[a] + ST[a / (uint64_t)spc];
             s = SUF + PRE;
         }
-        out[i] = s * scale;
+        out[i] = (divisor != 0.0f) ? (s / divisor) : (s * scale);
     }
     free(tot); free(PT); free(ST);
     return 0;
+}
+
+static int moving_sum_block(const float *x, uint64_t n, int spc, float scale,
+                            float *out, float *pre, float *suf)
+{
+    return moving_sum_blockc(x, n, spc, CHIPS_PER_AVG, scale, 0.0f, out, pre, suf);
+}
+
+/* a2: filter.dc_blocker_cc(100*spc, False) -- python/rx_path.py:39-41 (GNU Radio 3.8 gr-filter,
+ * source not under /root/reference: PARITY UNPINNED).  Published algorithm (R. Lyons, "DC blocker
+ * algorithms", the linear-phase form GNU Radio documents for long_form = False): two cascaded
+ * D-sample moving averages and a (D-1)-sample delay,
+ *     m1 = MA_D(x),  m2 = MA_D(m1),  y[n] = x[n - (D-1)] - m2[n],      x, m1 = 0 before the stream,
+ * each moving average being sum / (float)D as in GNU Radio's moving_averager_c.  GNU Radio forms
+ * the window sums with a recursive running sum whose rounding depends on the whole history; as
+ * for a3/a4 the order is fixed here instead: the chip-aligned two-level order above with blocks
+ * of 100 chips, I and Q treated as two real streams.  Output is interleaved like the input. */
+#define CHIPS_PER_DCBLOCK 100
+int amo_dcblock(const float *iq, uint64_t n, int spc, float *out)
+{
+    if (spc < 1) return -1;
+    if (n == 0) return 0;
+    const uint64_t D = (uint64_t)CHIPS_PER_DCBLOCK * (uint64_t)spc;
+    float *x = (float *)malloc(n * sizeof(float));
+    float *m1 = (float *)malloc(n * sizeof(float));
+    float *m2 = (float *)malloc(n * sizeof(float));
+    float *pre = (float *)malloc(n * sizeof(float));
+    float *suf = (float *)malloc(n * sizeof(float));
+    int rc = (x && m1 && m2 && pre && suf) ? 0 : -1;
+    for (int c = 0; c < 2 && rc == 0; c++) {
+        for (uint64_t i = 0; i < n; i++) x[i] = iq[2 * i + c];
+        rc = moving_sum_blockc(x, n, spc, CHIPS_PER_DCBLOCK, 0.0f, (float)D, m1, pre, suf);
+        if (rc == 0) rc = moving_sum_blockc(m1, n, spc, CHIPS_PER_DCBLOCK, 0.0f, (float)D, m2, pre, suf);
+        for (uint64_t i = 0; i < n && rc == 0; i++) {
+            const float d = (i >= D - 1) ? x[i - (D - 1)] : 0.0f;
+            out[2 * i + c] = d - m2[i];
+        }
+    }
+    free(x); free(m1); free(m2); free(pre); free(suf);
+    return rc;
 }
 
 int amo_frontend(const float *iq, uint64_t n, int spc, int use_pmf,
@@ -373,6 +416,20 @@ int amo_slice(const float *b, const amo_tag *tag, amo_packet *out)
 }
 
 /* ------------------------------------------------------------ whole path ---- */
+uint64_t amo_demod2(const float *iq, uint64_t n, double rate, float thr_db, int use_pmf, int use_dcblock,
+                    amo_packet *out, uint64_t cap, uint64_t *n_tags)
+{
+    if (!use_dcblock) return amo_demod(iq, n, rate, thr_db, use_pmf, out, cap, n_tags);
+    int spc = (int)(rate / 2e6);
+    if (n_tags) *n_tags = 0;
+    if (spc < 1 || n == 0) return 0;
+    float *y = (float *)malloc(2 * n * sizeof(float));
+    uint64_t npk = 0;
+    if (y && amo_dcblock(iq, n, spc, y) == 0) npk = amo_demod(y, n, rate, thr_db, use_pmf, out, cap, n_tags);
+    free(y);
+    return npk;
+}
+
 uint64_t amo_demod(const float *iq, uint64_t n, double rate, float thr_db,
                    int use_pmf, amo_packet *out, uint64_t cap, uint64_t *n_tags)
 {

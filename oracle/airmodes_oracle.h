@@ -91,6 +91,12 @@ uint64_t amo_demod(const float *iq, uint64_t n, double rate, float thr_db,
                    int use_pmf, amo_packet *out, uint64_t cap,
                    uint64_t *n_tags);
 
+/* a2 (optional, python/rx_path.py:39-41): dc_blocker_cc(100*spc, False) in front of |.|^2, canonical
+ * summation order (see the .c file); out = 2n floats.  amo_demod2 = amo_demod with that option. */
+int amo_dcblock(const float *iq, uint64_t n, int spc, float *out);
+uint64_t amo_demod2(const float *iq, uint64_t n, double rate, float thr_db, int use_pmf, int use_dcblock,
+                    amo_packet *out, uint64_t cap, uint64_t *n_tags);
+
 /* slicer_impl.cc:186-192 message text incl. the sticky-precision quirk:
  * first != 0 -> reference level printed with 6 significant digits, else 10. */
 int amo_format_message(const amo_packet *p, int first, char *buf, size_t cap);

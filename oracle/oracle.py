@@ -55,6 +55,10 @@ def lib():
         L.amo_slice.argtypes = [_f32p, C.c_void_p, C.c_void_p]
         L.amo_crc24.restype = C.c_uint32
         L.amo_crc24.argtypes = [_u8p, C.c_int]
+        L.amo_dcblock.argtypes = [_f32p, C.c_uint64, C.c_int, _f32p]
+        L.amo_demod2.restype = C.c_uint64
+        L.amo_demod2.argtypes = [_f32p, C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_uint64, C.POINTER(C.c_uint64)]
         L.amo_demod.restype = C.c_uint64
         L.amo_demod.argtypes = [_f32p, C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_void_p,
                                 C.c_uint64, C.POINTER(C.c_uint64)]
@@ -144,14 +148,24 @@ def crc24(data):
     return int(lib().amo_crc24(d, d.size))
 
 
-def demod(iq, rate, thr_db=7.0, use_pmf=True, return_tags=False):
+def dcblock(iq, spc):
+    """a2: the optional DC blocker in front of the path; returns complex64."""
+    f = as_iq_f32(iq)
+    out = np.empty_like(f)
+    if lib().amo_dcblock(f, f.size // 2, spc, out) != 0:
+        raise RuntimeError("amo_dcblock failed")
+    return out.view(np.complex64)
+
+
+def demod(iq, rate, thr_db=7.0, use_pmf=True, return_tags=False, use_dcblock=False):
     f = as_iq_f32(iq)
     n = f.size // 2
     spc = max(int(rate / 2e6), 1)
     cap = n // (240 * spc) + 2
     out = np.zeros(cap, PACKET_DTYPE)
     ntags = C.c_uint64(0)
-    npk = lib().amo_demod(f, n, float(rate), thr_db, int(use_pmf), out.ctypes.data, cap, C.byref(ntags))
+    npk = lib().amo_demod2(f, n, float(rate), thr_db, int(use_pmf), int(use_dcblock), out.ctypes.data, cap,
+                           C.byref(ntags))
     assert npk <= cap
     return (out[:npk], int(ntags.value)) if return_tags else out[:npk]
 

@@ -53,13 +53,15 @@ def check_golden(lib, path):
     ctx.close()
 
 
-def check_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True):
+def check_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True, dcblock=False, dc_offset=0.0):
     """Stage-by-stage and end-to-end, product path vs oracle, on a seeded capture."""
     spc = int(rate / 2e6)
     iq, _ = synth.synth_capture(rate, n, lam, seed)
-    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    if dc_offset:
+        iq = (iq + np.complex64(dc_offset * (1 + 0.6j))).astype(np.complex64)
+    ctx = _capi.Context(rate, thr, pmf, use_dcblock=dcblock, lib=lib)
     bb, avg = ctx.frontend_work(iq)
-    obb, oavg = oracle.frontend(iq, spc, pmf)
+    obb, oavg = oracle.frontend(oracle.dcblock(iq, spc) if dcblock else iq, spc, pmf)
     assert np.array_equal(u32(bb), u32(obb)), "bb differs"
     assert np.array_equal(u32(avg), u32(oavg)), "avg differs"
     bursts, tags = ctx.preamble_work(obb, oavg)
@@ -70,18 +72,18 @@ def check_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True):
     opk = oracle.slice_bursts(ob, ot)
     assert np.array_equal(pk, opk), "slicer differs"
     whole = ctx.process_iq(iq, flush=True)
-    want = oracle.demod(iq, rate, thr, pmf)
+    want = oracle.demod(iq, rate, thr, pmf, use_dcblock=dcblock)
     assert np.array_equal(whole, want), "end-to-end differs"
     assert messages(lib, whole) == oracle.format_messages(want)
     ctx.close()
     return len(want)
 
 
-def check_chunked(lib, rate, iq, edges, thr=7.0, pmf=True, want=None):
+def check_chunked(lib, rate, iq, edges, thr=7.0, pmf=True, want=None, dcblock=False):
     """Results must not depend on how the stream is cut into am_process_iq calls."""
     if want is None:
-        want = oracle.demod(iq, rate, thr, pmf)
-    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+        want = oracle.demod(iq, rate, thr, pmf, use_dcblock=dcblock)
+    ctx = _capi.Context(rate, thr, pmf, use_dcblock=dcblock, lib=lib)
     parts = []
     n = len(iq)
     edges = [0] + [e for e in edges if 0 < e < n] + [n]
@@ -93,15 +95,15 @@ def check_chunked(lib, rate, iq, edges, thr=7.0, pmf=True, want=None):
     return len(got)
 
 
-def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None, ctxs=None):
+def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None, ctxs=None, dcblock=False):
     """Time-sharded operation (G chunks, exit-table exchange) == whole-stream result.  `ctxs`: reuse
     these contexts (one per chunk, as a receiver that steps over many batches does) and keep them open."""
     n = len(iq)
     if want is None:
-        want = oracle.demod(iq, rate, thr, pmf)
+        want = oracle.demod(iq, rate, thr, pmf, use_dcblock=dcblock)
     keep = ctxs is not None
     if not keep:
-        ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
+        ctxs = [_capi.Context(rate, thr, pmf, use_dcblock=dcblock, lib=lib) for _ in range(G)]
     hl, hr = ctxs[0].shard_halo()
     bounds = [(g * n) // G for g in range(G + 1)]
     tables = []

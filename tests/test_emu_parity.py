@@ -89,8 +89,6 @@ def test_setters_and_errors(emu_lib):
     assert ctx.get_rate() == 20e6
     with pytest.raises(_capi.AirModesError):
         ctx.set_rate(3e6)                       # fractional samples per chip: out of scope
-    with pytest.raises(_capi.AirModesError):
-        _capi.Context(4e6, 7.0, True, use_dcblock=True, lib=emu_lib)
     iq, _ = synth.synth_capture(20e6, 100000, 3000.0, seed=3)
     got = ctx.process_iq(iq, flush=True)
     assert np.array_equal(got, oracle.demod(iq, 20e6, 5.0, True))
@@ -160,3 +158,15 @@ def test_sharded_steps_with_capacity_overflow(emu_lib, monkeypatch):
         pc.check_sharded(emu_lib, rate, iq, G, ctxs=ctxs)
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("rate,n", [(2e6, 150000), (4e6, 200000), (20e6, 400000), (64e6, 700000)])
+def test_dcblock_option(emu_lib, rate, n):
+    """rx_path(..., use_dcblock=True): the DC blocker in front of the path (a2), stage by stage and end to
+    end against the oracle's canonical definition, on a capture with a DC offset; chunked; sharded."""
+    assert pc.check_stages(emu_lib, rate, n, 2500.0, 71, dcblock=True, dc_offset=0.04) > 3
+    iq, _ = synth.synth_capture(rate, n, 2500.0, 72)
+    iq = (iq + np.complex64(0.03 - 0.02j)).astype(np.complex64)
+    spc = int(rate / 2e6)
+    pc.check_chunked(emu_lib, rate, iq, [n // 3 + 1, n // 3 + 150 * spc, 2 * n // 3 + 7], dcblock=True)
+    pc.check_sharded(emu_lib, rate, iq, 3, dcblock=True)

@@ -163,3 +163,15 @@ def test_modes_rx_cli_on_gpu(lib, tmp_path):
         except IndexError:              # a reference table bug the command line survives (see modes_rx.py)
             pass
     assert parsed.getvalue().splitlines() == lines and len(lines) > 20
+
+
+@pytest.mark.parametrize("rate,n", [(2e6, 1000000), (4e6, 1000000), (20e6, 2000000), (64e6, 4000000), (100e6, 3000000)])
+def test_dcblock_option(lib, rate, n):
+    """rx_path(..., use_dcblock=True) (a2): stage by stage and end to end against the oracle's canonical
+    definition on a capture with a DC offset; chunking and sharding invariance."""
+    assert pc.check_stages(lib, rate, n, 2500.0, 71, dcblock=True, dc_offset=0.04) > 10
+    iq, _ = synth.synth_capture(rate, n, 2500.0, 72)
+    iq = (iq + np.complex64(0.03 - 0.02j)).astype(np.complex64)
+    spc = int(rate / 2e6)
+    pc.check_chunked(lib, rate, iq, [n // 3 + 1, n // 3 + 150 * spc, 2 * n // 3 + 7], dcblock=True)
+    pc.check_sharded(lib, rate, iq, 4, dcblock=True)
