@@ -471,18 +471,20 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
                 }
                 any = any | c[i];
             }
-            constexpr int offs[3] = {2 * SPC, 7 * SPC, 9 * SPC};
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                // wave-uniform early out: in quiet stretches no lane has a survivor left
-                if (__ballot(any) == 0ull) break;
-                float t[CH];
-                fe2_lds_load<CH, SHIFT_AL && (CH % 4 == 0), (SPC % CH == 0) && (32 % CH == 0)>(X, run_base + offs[o] + h, t);
-                any = false;
+            // The three later pulses must not be below the threshold (:177-179): one test on the
+            // smallest of them.  fminf ignores a NaN operand exactly as `NaN < thr` is false, so
+            // this is the same predicate.  Wave-uniform early out: in quiet stretches no lane has
+            // a survivor of the first test.
+            if (__ballot(any) != 0ull) {
+                constexpr bool AL = SHIFT_AL && (CH % 4 == 0), IG = (SPC % CH == 0) && (32 % CH == 0);
+                float t2[CH], t7[CH], t9[CH];
+                fe2_lds_load<CH, AL, IG>(X, run_base + 2 * SPC + h, t2);
+                fe2_lds_load<CH, AL, IG>(X, run_base + 7 * SPC + h, t7);
+                fe2_lds_load<CH, AL, IG>(X, run_base + 9 * SPC + h, t9);
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    c[i] = c[i] & !(t[i] < thr[i]);                      // :177-179
-                    any = any | c[i];
+                    const float weakest = fminf(fminf(t2[i], t7[i]), t9[i]);
+                    c[i] = c[i] & !(weakest < thr[i]);
                 }
             }
 #pragma unroll
