@@ -173,7 +173,8 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     constexpr int NCH = FE2_LH_CHIPS + FE2_NT * CPT + FE2_RH_CHIPS;   // chips resident
     constexpr int NBLK = 1 + (FE2_NT * CPT) / AM_CHIPS_AVG;           // 48-chip blocks incl. halo block
     constexpr bool RUN_AL = (R % 4 == 0);
-    constexpr bool CHIP_AL = (SPC % 4 == 0);
+    constexpr bool CHIP_AL = (SPC % 4 == 0);     // chips start on 16-byte LDS boundaries (LHP - LH is then a multiple of 4)
+    static_assert(SPC % 4 != 0 || (LHP - LH) % 4 == 0, "chip alignment");
     constexpr bool SHIFT_AL = RUN_AL && ((2 * SPC) % 4 == 0) && ((7 * SPC) % 4 == 0) && ((9 * SPC) % 4 == 0);
     // padded-index shortcuts (LHP is a multiple of 32; chips sit at LHP - 49*SPC + c*SPC)
     constexpr bool RUN_IG = (32 % R == 0);       // a run lies inside one padding group
@@ -319,10 +320,10 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     const bool do_pmf = a.use_pmf && SPC > 1 && !(a.ablate & 1u);
     float hb[SPC] = {};
     if (has_halo) {
-        fe2_lds_load<SPC, false, CHIP_IG>(X, chip_base(hq), hb);
+        fe2_lds_load<SPC, CHIP_AL, CHIP_IG>(X, chip_base(hq), hb);
         if (do_pmf) {
             float hp[SPC];
-            fe2_lds_load<SPC, false, CHIP_IG>(X, chip_base(hq) - SPC, hp);
+            fe2_lds_load<SPC, CHIP_AL, CHIP_IG>(X, chip_base(hq) - SPC, hp);
             fe2_pmf_chip<SPC>(hp, &hb[0], a.s1);
         }
     }
@@ -376,7 +377,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     __syncthreads();                                       // everyone has read its |.|^2
     FE2_STAMP(4);
     fe2_lds_store<R, RUN_AL, RUN_IG>(X, run_base, bbv);
-    if (has_halo) fe2_lds_store<SPC, false, CHIP_IG>(X, chip_base(hq), hb);
+    if (has_halo) fe2_lds_store<SPC, CHIP_AL, CHIP_IG>(X, chip_base(hq), hb);
 
     // ---- P4: exclusive prefix / suffix of chip totals inside each 48-chip block ----------------
     // (the 48 totals are fetched in one batch; the additions keep the canonical sequential order)
