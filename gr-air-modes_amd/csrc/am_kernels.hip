@@ -785,26 +785,62 @@ __device__ __forceinline__ void am_cblk_load_heads(uint32_t *hx, const uint32_t 
     }
 }
 
-// one step of the block walk: where the orbit that is at node `cur` leaves cur's block
-__device__ __forceinline__ uint32_t am_cblk_step(const uint32_t *hx, const uint32_t *__restrict__ exitnode,
+// one step of the block walk: where the orbit that is at node `cur` leaves cur's block.
+// (Two separate loads on purpose: folded into one load from a selected pointer they become a FLAT
+// load, which is several times slower than an LDS read even when the address is in LDS.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(3))) uint32_t *am_lds_u32p;   // an LDS pointer the optimiser cannot mistake
+#else
+typedef const uint32_t *am_lds_u32p;
+#endif
+__device__ __forceinline__ uint32_t am_cblk_step(const uint32_t *hx_generic, const uint32_t *__restrict__ exitnode,
                                                  uint32_t headw, uint32_t cur)
 {
     const uint32_t b = cur / AM_CB, idx = cur % AM_CB;
-    return (idx < headw) ? hx[b * headw + idx] : exitnode[cur];     // (root, or an unusually long head)
+    if (headw == 0) return exitnode[cur];
+    am_lds_u32p hx = (am_lds_u32p)hx_generic;
+    uint32_t nxt = hx[b * headw + (idx < headw ? idx : headw - 1u)];
+    if (idx >= headw) nxt = __builtin_nontemporal_load(&exitnode[cur]);   // root, or an unusually long head
+    return nxt;
 }
 
 // entry[b] = node at which the scan that starts at position cur0 enters block b, AM_CB_NONE if it
 // jumps over the block.  scalars[0] = cur0 (the emit kernel raises it to the resume position),
 // scalars[1] = 0.
+// The walk itself is sequential (one hop per block), so its inner loop is made as short as it can
+// be: the head table is turned into "next table slot" links (16 bit: slot = block * headw + index),
+// and a hop is one dependent LDS read plus one LDS write that records the block's entry; node
+// numbers, global memory and the entry array only appear outside that loop.
+#define AM_CB_END 0xFFFFu            /* link: the orbit leaves the candidate list */
+#define AM_CB_OUT 0xFFFEu            /* link: it lands beyond the next block's head (resolved through exitnode[]) */
+
 __global__ void __launch_bounds__(1024)
 am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
                const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
                uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
-    HIP_DYNAMIC_SHARED(uint32_t, hx);          // [nblk * headw] exit nodes of the heads
+    HIP_DYNAMIC_SHARED(uint16_t, lnk);         // [nblk * headw] links | [nblk] index of each block's entry node
+    const uint32_t total = nblk * headw;
+    uint16_t *ent = lnk + total;
     __shared__ uint32_t seg, root_s;
-    am_cblk_load_heads(hx, headexit, nblk * headw);
+    for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {      // 8 independent loads per batch
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t f = f0 + (uint32_t)k * blockDim.x;
+            t[k] = headexit[f < total ? f : total - 1u];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t f = f0 + (uint32_t)k * blockDim.x;
+            if (f < total) {
+                const uint32_t g = t[k], kb = g / AM_CB, ki = g % AM_CB;
+                lnk[f] = (uint16_t)(g >= M ? AM_CB_END : (ki < headw ? kb * headw + ki : AM_CB_OUT));   // headw = 2^k
+            }
+        }
+    }
+    for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) ent[bb] = (uint16_t)AM_CB_END;
     // root = first candidate with pos >= cur0, in two parallel rounds (two dependent loads in all):
     // which of 1024 equal segments holds it, then which node of that segment
     const uint32_t stride = (M + blockDim.x - 1u) / blockDim.x;
@@ -820,14 +856,26 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
         if (pos[g] >= cur0 && (g == 0 || pos[g - 1u] < cur0)) root_s = g;
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t cur = root_s;
-        for (uint32_t b = 0; b < nblk; ++b) {
-            const uint32_t base = b * AM_CB;
-            const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
-            if (cur >= end || base >= M) { entry[b] = AM_CB_NONE; continue; }
-            entry[b] = cur;
-            cur = am_cblk_step(hx, exitnode, headw, cur);
+        const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
+        uint32_t g = root_s;                                 // node the orbit is at (outside the fast loop)
+        while (g < M) {
+            uint32_t kb = g / AM_CB, ki = g % AM_CB;
+            ent[kb] = (uint16_t)ki;
+            if (ki >= headw) { g = __builtin_nontemporal_load(&exitnode[g]); continue; }   // root / long head
+            uint32_t slot = (kb << hs) + ki, nx;
+            while ((nx = lnk[slot]) < AM_CB_OUT) {           // the fast loop: one hop per block
+                slot = nx;
+                ent[slot >> hs] = (uint16_t)(slot & hm);
+            }
+            if (nx == AM_CB_END) break;
+            // lands beyond a head: one hop through global memory
+            g = __builtin_nontemporal_load(&exitnode[(slot >> hs) * AM_CB + (slot & hm)]);
         }
+    }
+    __syncthreads();
+    for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) {
+        const uint32_t ki = ent[bb];
+        entry[bb] = (ki == AM_CB_END) ? AM_CB_NONE : bb * AM_CB + ki;
     }
 }
 
@@ -976,7 +1024,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
         if (rc != hipSuccess) return rc;
         attr_set = true;
     }
-    const size_t lds = ((size_t)L.nblk * L.headw + 1) * sizeof(uint32_t);
+    const size_t lds = ((size_t)L.nblk * L.headw + L.nblk + 2) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, scratch + L.off_head, M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp);
     hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M,

@@ -55,10 +55,16 @@ inline void __syncthreads() { hipemu::barrier(); }
 // wave-level compiler fence in the product = a real rendezvous of the wave's fibers here
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+// only used on values that are already the same in every lane of the wave
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#ifndef __clang__
+#define __builtin_nontemporal_load(p) (*(p))
+#endif
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::ballot(0))
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 
 template <class T> inline T hipemu_shfl(T v, int arg, int width, int mode)
 {
