@@ -7,6 +7,7 @@
 // There is no CPU fallback: every entry point that computes needs a HIP device.
 #include "am_internal.h"
 
+#include <chrono>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,6 +21,11 @@ namespace {
 
 // internal (never leaves this file): a speculative scan must be redone with the exact candidate count
 #define AM_RETRY_EXACT 1000
+
+static inline double am_now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 struct DevBuf {
     void *p = nullptr;
@@ -54,6 +60,13 @@ struct am_ctx {
     int ref_mode = 0;
     const float *ref_bb = nullptr, *ref_avg = nullptr;
     int use_dcblock = 0;          // a2: dc_blocker_cc(100*spc, False) in front of |.|^2 (rx_path.py:39-41)
+    const float *zt_base[2] = {nullptr, nullptr};   // where the zero tail of bb / avg was last written
+    uint64_t zt_n[2] = {0, 0};
+    // host-side wall-clock trace (AIRMODES_HOST_TRACE): cumulative microseconds per section
+    double ht[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned ht_n = 0;
+    uint32_t ticket_seq = 0;      // completion tickets (wait_for_ticket)
+    bool dom_timed = false;       // ev[3] / ev[1] bracket the dominant kernel of this call
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     char err[256] = "";
@@ -180,6 +193,38 @@ void reset_stream(am_ctx *c)
 
 // positions beyond the end of the data read zeros: every bb/avg array carries this pad
 inline uint64_t zero_pad(int spc) { return (uint64_t)260 * (uint64_t)spc + 64; }
+
+// Wait for the end of a scan: the last launch stores a ticket number into pinned host memory and the
+// host polls that word.  Asking the runtime instead (hipStreamSynchronize, hipEventQuery) adds tens of
+// microseconds per scan -- its completion path runs through a helper thread.  After 50 ms of polling
+// the thread blocks in the runtime.
+hipError_t wait_for_ticket(am_ctx *c, uint32_t seq)
+{
+    volatile uint32_t *word = c->pin_scalars + 8;
+    const double t0 = am_now_us();
+    unsigned spins = 0;
+    while (*word != seq) {
+        if ((++spins & 1023u) == 0 && am_now_us() - t0 > 50000.0) return hipStreamSynchronize(c->stream);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return hipSuccess;
+}
+
+// The `pad` floats after the n valid ones of a bb/avg array read as zero.  The kernels never write there,
+// so the fill is skipped when the same place was zeroed last time (a launch less per call).
+int zero_tail(am_ctx *c, float *base, uint64_t n, uint64_t pad, const float **last_base, uint64_t *last_n)
+{
+    if (*last_base == base && *last_n == n) return AM_OK;
+    HIPCHK(c, hipMemsetAsync(base + n, 0, pad * sizeof(float), c->stream));
+    *last_base = base;
+    *last_n = n;
+    return AM_OK;
+}
+#define ZERO_TAIL(c, which, base, n, pad)                                                        \
+    do {                                                                                          \
+        int rc__ = zero_tail((c), (base), (n), (pad), &(c)->zt_base[which], &(c)->zt_n[which]);   \
+        if (rc__ != AM_OK) return rc__;                                                           \
+    } while (0)
 
 // a2: when the DC blocker is on, the path runs on y = dcblock(x) instead of x.  `*src`/`*src_abs0`
 // describe the raw samples present, [need0, src_abs1) is what the front end will read; on return
@@ -312,6 +357,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->dom_timed = true;
         return run_candidates(c, bb, avg, j0, j1, M_out);
     }
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
@@ -332,6 +378,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                             (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->cand_seg.p,
                             avg_sparse, (uint32_t *)c->blk_cnt.p, &nt, &tl, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->dom_timed = true;
     const uint64_t endj = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
     uint32_t spec_cap = 0;
     if (may_speculate && c->allow_spec && avg_sparse && c->spec_density > 0.0) {
@@ -415,7 +462,11 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, c->pin_tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
                               c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t seq = ++c->ticket_seq;
+    HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream));
+    const double TS = am_now_us();
+    HIPCHK(c, wait_for_ticket(c, seq));
+    c->ht[5] += am_now_us() - TS;
     c->tail_synced = true;
     if (Mp) {
         // launched for a capacity: now the real candidate count is known
@@ -520,7 +571,9 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             code = AM_EHIP;
             break;
         }
-        for (int i = 0; i < 4; i++) (void)hipEventCreate(&c->ev[i]);
+        // timing events only: no system-scope cache flush when they execute (results reach the host through
+        // pinned memory written by the kernels themselves, and through explicit copies)
+        for (int i = 0; i < 4; i++) (void)hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence);
         c->use_pmf = use_pmf ? 1 : 0;
         c->use_dcblock = use_dcblock ? 1 : 0;
         {
@@ -553,6 +606,9 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
 void am_destroy(am_ctx *c)
 {
     if (!c) return;
+    if (getenv("AIRMODES_HOST_TRACE") && c->ht_n)
+        fprintf(stderr, "airmodes host trace over %u calls (us/call): setup %.1f, front end + refinement enqueue %.1f, chain + tail incl. sync %.1f (of which waiting %.1f), timing + hand-over %.1f, whole call %.1f, event-not-ready %.0f\n",
+                c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->blk_cnt, &c->blk_off,
@@ -602,6 +658,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     if (!c) return AM_EINVAL;
     if (n_out) *n_out = 0;
     if (n && !iq) return fail(c, AM_EINVAL, "null iq");
+    const double T0 = am_now_us();
     HIPCHK(c, hipSetDevice(c->device));
     c->pending.clear();
     c->last_tags = 0;
@@ -612,8 +669,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     const uint64_t LH = L + S;
     if (c->carry_n + n > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "chunk larger than 2^31 samples");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->dom_timed = false;
     c->tail_synced = false;
 
     // 1. one contiguous device view of [src_abs0, S1): carried tail + new samples
@@ -666,21 +722,25 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
         float *bb = (float *)c->bb.p, *avg = nullptr;
-        HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
+        ZERO_TAIL(c, 0, bb, out_n, pad);
         if (generic) {          // the fused kernel carries the reference level in the candidate records
             ENSURE(c, c->avg, (out_n + pad) * sizeof(float));
             avg = (float *)c->avg.p;
-            HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+            ZERO_TAIL(c, 1, avg, out_n, pad);
         }
         const uint32_t j0 = (uint32_t)(P0 - out_abs0), j1 = (uint32_t)(P1 - out_abs0);
         uint32_t M = 0;
+        const double T1 = am_now_us();
         int rc = run_front_and_candidates(c, fsrc, fsrc_abs0, S1, out_abs0, out_n, bb, avg, j0, j1, &M, true);
         if (rc != AM_OK) return rc;
+        const double T2 = am_now_us();
+        c->ht[0] += T1 - T0; c->ht[1] += T2 - T1;
         const uint32_t cur0 = c->chain_cur > out_abs0 ? (uint32_t)std::min<uint64_t>(c->chain_cur - out_abs0, 0xFFFFFFF0u) : 0u;
         const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - out_abs0);
         uint32_t fin = cur0;
         const uint32_t max_hits = (uint32_t)((P1 - P0 + S) / ((uint64_t)AM_BURST * S) + 2);
         rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, out_abs0, false, &fin, max_hits);
+        c->ht[2] += am_now_us() - T2;
         if (rc == AM_RETRY_EXACT) {
             if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: capacity %u < %u candidates, scan redone\n", M, c->last_M);
             // more candidates than the capacity this scan was launched for: redo the refinement and
@@ -723,9 +783,13 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    const double T5 = am_now_us();
     (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
-    (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
-    return hand_out(c, out, cap, n_out);
+    c->last_dom_ms = 0.0f;
+    if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
+    const int hrc = hand_out(c, out, cap, n_out);
+    c->ht[3] += am_now_us() - T5; c->ht[4] += am_now_us() - T0; c->ht_n++;
+    return hrc;
 }
 
 int am_fetch_packets(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
@@ -789,8 +853,8 @@ int am_preamble_work(am_ctx *c, const float *in, const float *inavg, uint64_t n,
     const hipMemcpyKind kind = (flags & AM_F_DEVICE_IN) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIPCHK(c, hipMemcpyAsync(bb, in, n * sizeof(float), kind, c->stream));
     HIPCHK(c, hipMemcpyAsync(avg, inavg, n * sizeof(float), kind, c->stream));
-    HIPCHK(c, hipMemsetAsync(bb + n, 0, pad * sizeof(float), c->stream));
-    HIPCHK(c, hipMemsetAsync(avg + n, 0, pad * sizeof(float), c->stream));
+    ZERO_TAIL(c, 0, bb, n, pad);
+    ZERO_TAIL(c, 1, avg, n, pad);
     uint64_t em = 0;
     c->h_packets.clear();
     c->h_tags.clear();
@@ -904,8 +968,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     if (nsrc > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "chunk larger than 2^31 samples");
     if (nsrc && !iq) return fail(c, AM_EINVAL, "null iq");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->dom_timed = false;
     const float *src = iq;
     if (!(flags & AM_F_DEVICE_IN) && nsrc) {
         ENSURE(c, c->src, nsrc * 2 * sizeof(float));
@@ -933,11 +996,11 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
         float *bb = (float *)c->bb.p, *avg = nullptr;
-        HIPCHK(c, hipMemsetAsync(bb + out_n, 0, pad * sizeof(float), c->stream));
+        ZERO_TAIL(c, 0, bb, out_n, pad);
         if (generic) {
             ENSURE(c, c->avg, (out_n + pad) * sizeof(float));
             avg = (float *)c->avg.p;
-            HIPCHK(c, hipMemsetAsync(avg + out_n, 0, pad * sizeof(float), c->stream));
+            ZERO_TAIL(c, 1, avg, out_n, pad);
         }
         int rc = run_front_and_candidates(c, src, fsrc_abs0, src_abs1, out_abs0, out_n, bb, avg,
                                           (uint32_t)(P0 - out_abs0), (uint32_t)(P1 - out_abs0), &M, true);
@@ -979,7 +1042,8 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     }
     c->spec_density = (P1 > P0) ? (double)c->last_M / (double)(P1 - P0) : 0.0;
     (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
-    (void)hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]);
+    c->last_dom_ms = 0.0f;
+    if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
     uint64_t nt = 0;
     for (uint32_t i = 0; i < n_dev; i++) {
         nt = i + 1;

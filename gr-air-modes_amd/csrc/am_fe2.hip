@@ -622,9 +622,16 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     *ntiles = a.ntiles;
     *tile_len = T;
     if (a.ntiles == 0) return hipSuccess;
-    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe2<SPC, CPT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
-    if (rc != hipSuccess) return rc;
+    // (once per device and LDS size: the call is not free and this launch is on the critical path)
+    static size_t attr_lds[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || attr_lds[dev] != lds_req) {
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe2<SPC, CPT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
+        if (rc != hipSuccess) return rc;
+        if (dev >= 0 && dev < 64) attr_lds[dev] = lds_req;
+    }
     const unsigned grid = ((a.ntiles + 7u) / 8u) * 8u;     // whole XCD rounds (extra groups exit)
     // Workgroups that start together stay in lockstep (same work per tile): the whole chip would load
     // (HBM saturated), then compute (HBM idle), in turns.  The first round of workgroups -- one per CU

@@ -1275,6 +1275,18 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
     }
 }
 
+// Completion ticket: the last launch of a scan.  The host polls the pinned word instead of asking the
+// runtime (whose completion path costs tens of microseconds per scan).
+__global__ void am_k_ticket(uint32_t *host_word, uint32_t seq)
+{
+    __hip_atomic_store(host_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_ticket, dim3(1), dim3(1), 0, s, host_word, seq);
+    return hipGetLastError();
+}
+
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,
                            uint32_t *host_out, hipStream_t s, const uint32_t *Mp)

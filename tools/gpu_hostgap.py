@@ -26,3 +26,4 @@ for _ in range(20):
 t_loop = (time.perf_counter() - t_loop0) * 1e3 / 20
 print("per step: loop %.3f ms, call %.3f ms, GPU span (first event .. last event) %.3f ms, candidates %d, packets %d"
       % (t_loop, np.mean(calls), np.mean(spans), ctx.last_num_candidates(), len(pk)))
+ctx.close()
