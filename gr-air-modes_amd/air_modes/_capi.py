@@ -210,18 +210,26 @@ class Context(object):
 
     def _process(self, ptr, n, flags, capacity):
         cap = int(capacity) if capacity is not None else max(64, n // 2000 + 64)
-        # one reusable receive buffer per context (a fresh megabyte-sized array per call costs an
-        # mmap/munmap pair); the caller gets a right-sized copy
-        out = getattr(self, "_rxbuf", None)
-        if out is None or len(out) < cap:
-            out = self._rxbuf = np.zeros(cap, PACKET_DTYPE)
+        out = self._receive_buffer(cap)
         got = C.c_uint64(0)
         rc = self.lib.L.am_process_iq(self._h, ptr, n, flags, out.ctypes.data, cap, C.byref(got))
         if rc == AM_ECAPACITY:
             return self._fetch(int(got.value))
         self._chk(rc)
-        # (copied as raw bytes: numpy copies a structured array with sub-array fields element by element)
-        nbytes = int(got.value) * PACKET_DTYPE.itemsize
+        return self._received(out, got.value)
+
+    def _receive_buffer(self, cap):
+        """One reusable receive buffer per context (a fresh megabyte-sized array per call costs an
+        mmap/munmap pair); the caller gets a right-sized copy (_received)."""
+        out = getattr(self, "_rxbuf", None)
+        if out is None or len(out) < cap:
+            out = self._rxbuf = np.zeros(cap, PACKET_DTYPE)
+        return out
+
+    @staticmethod
+    def _received(out, count):
+        # copied as raw bytes: numpy copies a structured array with sub-array fields element by element
+        nbytes = int(count) * PACKET_DTYPE.itemsize
         return out.view(np.uint8)[:nbytes].copy().view(PACKET_DTYPE)
 
     # block-level entry points
@@ -287,13 +295,13 @@ class Context(object):
 
     def shard_resolve(self, cur_in, capacity=None):
         cap = int(capacity) if capacity is not None else 4096
-        out = np.zeros(cap, PACKET_DTYPE)
+        out = self._receive_buffer(cap)
         got = C.c_uint64(0)
         rc = self.lib.L.am_shard_resolve(self._h, int(cur_in), out.ctypes.data, cap, C.byref(got))
         if rc == AM_ECAPACITY:
             return self._fetch(int(got.value))
         self._chk(rc)
-        return out[:got.value]
+        return self._received(out, got.value)
 
 
 def shard_entries(lib, tables, starts):

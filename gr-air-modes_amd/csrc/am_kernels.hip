@@ -767,43 +767,6 @@ am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw
     }
 }
 
-// head table -> LDS, in batches of 8 independent loads per thread (one memory round trip per batch)
-__device__ __forceinline__ void am_cblk_load_heads(uint32_t *hx, const uint32_t *__restrict__ headexit, uint32_t total)
-{
-    for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {
-        uint32_t t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t f = f0 + (uint32_t)k * blockDim.x;
-            t[k] = headexit[f < total ? f : total - 1u];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t f = f0 + (uint32_t)k * blockDim.x;
-            if (f < total) hx[f] = t[k];
-        }
-    }
-}
-
-// one step of the block walk: where the orbit that is at node `cur` leaves cur's block.
-// (Two separate loads on purpose: folded into one load from a selected pointer they become a FLAT
-// load, which is several times slower than an LDS read even when the address is in LDS.)
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(3))) uint32_t *am_lds_u32p;   // an LDS pointer the optimiser cannot mistake
-#else
-typedef const uint32_t *am_lds_u32p;
-#endif
-__device__ __forceinline__ uint32_t am_cblk_step(const uint32_t *hx_generic, const uint32_t *__restrict__ exitnode,
-                                                 uint32_t headw, uint32_t cur)
-{
-    const uint32_t b = cur / AM_CB, idx = cur % AM_CB;
-    if (headw == 0) return exitnode[cur];
-    am_lds_u32p hx = (am_lds_u32p)hx_generic;
-    uint32_t nxt = hx[b * headw + (idx < headw ? idx : headw - 1u)];
-    if (idx >= headw) nxt = __builtin_nontemporal_load(&exitnode[cur]);   // root, or an unusually long head
-    return nxt;
-}
-
 // entry[b] = node at which the scan that starts at position cur0 enters block b, AM_CB_NONE if it
 // jumps over the block.  scalars[0] = cur0 (the emit kernel raises it to the resume position),
 // scalars[1] = 0.
@@ -814,17 +777,12 @@ __device__ __forceinline__ uint32_t am_cblk_step(const uint32_t *hx_generic, con
 #define AM_CB_END 0xFFFFu            /* link: the orbit leaves the candidate list */
 #define AM_CB_OUT 0xFFFEu            /* link: it lands beyond the next block's head (resolved through exitnode[]) */
 
-__global__ void __launch_bounds__(1024)
-am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
-               const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
-               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
+// head table -> LDS as 16-bit links to the next table slot (slot = block * headw + index in block),
+// in batches of 8 independent loads per thread (one memory round trip per batch, not per word)
+__device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint32_t *__restrict__ headexit,
+                                                   uint32_t total, uint32_t headw, uint32_t M)
 {
-    const uint32_t M = am_count(Mcap, Mp);
-    HIP_DYNAMIC_SHARED(uint16_t, lnk);         // [nblk * headw] links | [nblk] index of each block's entry node
-    const uint32_t total = nblk * headw;
-    uint16_t *ent = lnk + total;
-    __shared__ uint32_t seg, root_s;
-    for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {      // 8 independent loads per batch
+    for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {
         uint32_t t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -840,6 +798,19 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(1024)
+am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
+               const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
+               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
+{
+    const uint32_t M = am_count(Mcap, Mp);
+    HIP_DYNAMIC_SHARED(uint16_t, lnk);         // [nblk * headw] links | [nblk] index of each block's entry node
+    const uint32_t total = nblk * headw;
+    uint16_t *ent = lnk + total;
+    __shared__ uint32_t seg, root_s;
+    am_cblk_load_links(lnk, headexit, total, headw, M);
     for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) ent[bb] = (uint16_t)AM_CB_END;
     // root = first candidate with pos >= cur0, in two parallel rounds (two dependent loads in all):
     // which of 1024 equal segments holds it, then which node of that segment
@@ -889,9 +860,10 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
                      const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
-    HIP_DYNAMIC_SHARED(uint32_t, hx);
-    am_cblk_load_heads(hx, headexit, nblk * headw);
+    HIP_DYNAMIC_SHARED(uint16_t, lnk);
+    am_cblk_load_links(lnk, headexit, nblk * headw, headw, M);
     __syncthreads();
+    const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         am_shard_exit t;
         if (i >= M) {                                        // (capacity launch) end marker: "no candidate here"
@@ -904,8 +876,17 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
         t.exit = 0;
         // the table ends with the first candidate at or past lead_end: later entries are never read
         if (i == 0 || pos[i - 1u] < lead_end) {
-            uint32_t cur = i, ent = i;                       // ent: entry node of the last block the orbit touches
-            while (cur < M) { ent = cur; cur = am_cblk_step(hx, exitnode, headw, cur); }
+            uint32_t g = i, ent = i;                         // ent: entry node of the last block the orbit touches
+            while (g < M) {
+                ent = g;
+                const uint32_t kb = g / AM_CB, ki = g % AM_CB;
+                if (ki >= headw) { g = __builtin_nontemporal_load(&exitnode[g]); continue; }
+                uint32_t slot = (kb << hs) + ki, nx;
+                while ((nx = lnk[slot]) < AM_CB_OUT) slot = nx;              // one LDS read per block
+                ent = (slot >> hs) * AM_CB + (slot & hm);
+                if (nx == AM_CB_END) break;
+                g = __builtin_nontemporal_load(&exitnode[ent]);
+            }
             t.exit = base_abs + tgt[lastnode[ent]];
         }
         table[i] = t;
@@ -1045,7 +1026,7 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
         if (rc != hipSuccess) return rc;
         attr_set = true;
     }
-    const size_t lds = ((size_t)L.nblk * L.headw + 1) * sizeof(uint32_t);
+    const size_t lds = ((size_t)L.nblk * L.headw + 2) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
                        scratch + L.off_head, M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
     return hipGetLastError();
