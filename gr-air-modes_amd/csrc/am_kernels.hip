@@ -407,40 +407,37 @@ __device__ __forceinline__ uint32_t am_count(uint32_t cap, const uint32_t *__res
     return m < cap ? m : cap;
 }
 
-__global__ void __launch_bounds__(256)
+// One workgroup per tile segment: its slice of the flat arrays is [blk_off[b], blk_off[b+1]), so the
+// copy is coalesced and needs no search; only the first candidate of a segment looks back for its
+// predecessor (last candidate of the nearest earlier non-empty segment).
+__global__ void __launch_bounds__(128)
 am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const uint32_t *__restrict__ blk_off,
                 uint32_t nseg, uint32_t Mcap, int spc, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
                 const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    uint32_t lo = 0, hi = nseg;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (blk_off[mid] <= g) lo = mid; else hi = mid;
+    const uint32_t b = blockIdx.x;
+    const uint32_t off = blk_off[b], cnt = blk_off[b + 1u] - off;
+    if (cnt == 0 || off >= M) return;                        // uniform
+    const uint32_t *src = seg_pos + (size_t)b * seg_stride;
+    uint32_t before = 0;                                     // position of the candidate before this segment's first
+    if (off > 0) {
+        uint32_t pb = b - 1u;
+        while (blk_off[pb + 1u] == blk_off[pb]) --pb;        // some earlier segment is non-empty because off > 0
+        before = seg_pos[(size_t)pb * seg_stride + (blk_off[pb + 1u] - blk_off[pb] - 1u)];
     }
-    const uint32_t slot = g - blk_off[lo];
-    const uint32_t p = seg_pos[(size_t)lo * seg_stride + slot];
-    uint32_t d = (uint32_t)spc + 1u;
-    if (g > 0) {
-        // previous candidate: same segment, or the last one of the nearest non-empty earlier segment
-        uint32_t pl = lo, ps = slot;
-        if (ps == 0) {
-            uint32_t l2 = 0, h2 = lo;       // last segment index < lo with blk_off[seg] < blk_off[lo] == g
-            while (h2 - l2 > 1) {
-                const uint32_t mid = (l2 + h2) >> 1;
-                if (blk_off[mid] < g) l2 = mid; else h2 = mid;
-            }
-            pl = l2;
-            ps = g - blk_off[pl];
+    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
+        const uint32_t g = off + k;
+        if (g >= M) break;
+        const uint32_t p = src[k];
+        uint32_t d = (uint32_t)spc + 1u;
+        if (g > 0) {
+            const uint32_t gap = p - (k ? src[k - 1u] : before);
+            d = gap < d ? gap : d;
         }
-        const uint32_t pp = seg_pos[(size_t)pl * seg_stride + (ps - 1)];
-        const uint32_t gap = p - pp;
-        d = gap < d ? gap : d;
+        pos[g] = p;
+        dcount[g] = d;
     }
-    pos[g] = p;
-    dcount[g] = d;
 }
 
 // block-local exclusive scan (2048 elements per workgroup) + block totals
@@ -569,12 +566,27 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= M) return;
-    const uint32_t j = pos[g];
+    const bool live = g < M;                                 // (no early return: the wave cooperates below)
+    const uint32_t gi = live ? g : 0u;
+    if (M == 0) return;
+    const uint32_t j = pos[gi];
     // late-peak search (preamble_impl.cc:184-192) over the precomputed energies
-    const double *E = energy + (am_off_at(off_local, blk_base, g) + dcount[g] - 1u - (uint32_t)spc);
+    const double *E = energy + (am_off_at(off_local, blk_base, gi) + dcount[gi] - 1u - (uint32_t)spc);
+    // (8 energies per round trip: a lane that slides all spc steps would otherwise hold its whole wave
+    // for spc dependent loads)
     int how_late = 0;
-    while (how_late < spc && E[how_late + 1] > E[how_late]) how_late++;
+    bool rising = true;
+    for (int k0 = 0; k0 < spc && rising; k0 += 8) {
+        double ev[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) ev[k] = E[(k0 + k <= spc) ? k0 + k : spc];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (rising && k0 + k < spc) {
+                if (ev[k + 1] > ev[k]) how_late++; else rising = false;
+            }
+        }
+    }
     const uint32_t e = j + (uint32_t)how_late;
     // quiet zones (preamble_impl.cc:198-209)
     const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
@@ -584,8 +596,11 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     ps = ps + p3;
     const float avgpeak = (float)((double)ps / 4.0);
     const float sthr = av + (avgpeak - av) / thr_lin;
-    const bool ok = !am_any_above(bb + e + 3 * spc, 3 * spc + 1, sthr) &&      // offsets 3spc .. 6spc
-                    !am_any_above(bb + e + 10 * spc, 5 * spc + 1, sthr);       // offsets 10spc .. 15spc
+    // (a wave-cooperative check of the survivors was tried: at the bench density too many candidates
+    // survive the first samples of both zones, 86 us instead of 32)
+    const bool ok = live && !am_any_above(bb + e + 3 * spc, 3 * spc + 1, sthr) &&      // offsets 3spc .. 6spc
+                    !am_any_above(bb + e + 10 * spc, 5 * spc + 1, sthr);              // offsets 10spc .. 15spc
+    if (!live) return;
     eo[g] = e;
     inavg[g] = av;
     valid[g] = ok ? 1 : 0;
@@ -596,9 +611,9 @@ hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, co
                                 uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
                                 hipStream_t s, const uint32_t *Mp)
 {
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_gather_pos, dim3((M + 255) / 256), dim3(256), 0, s, seg_pos, seg_stride, blk_off, nseg,
-                       M, spc, pos, dcount, Mp);
+    if (M == 0 || nseg == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_gather_pos, dim3(nseg), dim3(128), 0, s, seg_pos, seg_stride, blk_off, nseg, M, spc, pos,
+                       dcount, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
