@@ -170,3 +170,26 @@ def test_dcblock_option(emu_lib, rate, n):
     spc = int(rate / 2e6)
     pc.check_chunked(emu_lib, rate, iq, [n // 3 + 1, n // 3 + 150 * spc, 2 * n // 3 + 7], dcblock=True)
     pc.check_sharded(emu_lib, rate, iq, 3, dcblock=True)
+
+
+def test_dcblock_tiny_chunks_and_quiet_gaps(emu_lib):
+    """DC blocker + streaming state: chunks shorter than the blocker's history, a silent stretch (no
+    candidates at all: the capacity extrapolation sees zero density), then traffic again."""
+    rate = 4e6
+    a, _ = synth.synth_capture(rate, 60000, 3000.0, seed=81)
+    b, _ = synth.synth_capture(rate, 60000, 3000.0, seed=82)
+    iq = np.concatenate([a, np.zeros(50000, np.complex64), b]) + np.complex64(0.02 + 0.01j)
+    iq = iq.astype(np.complex64)
+    pc.check_chunked(emu_lib, rate, iq, list(range(137, len(iq), 137)), dcblock=True)
+    pc.check_chunked(emu_lib, rate, iq, [60000, 110000], dcblock=False)
+    pc.check_chunked(emu_lib, rate, iq, [60000, 110000], dcblock=True)
+
+
+def test_candidate_count_accessor(emu_lib):
+    from air_modes import _capi
+    iq, _ = synth.synth_capture(8e6, 400000, 5000.0, seed=83)
+    ctx = _capi.Context(8e6, 7.0, True, lib=emu_lib)
+    assert ctx.last_num_candidates() == 0
+    pk = ctx.process_iq(iq, flush=True)
+    assert ctx.last_num_candidates() >= ctx.last_num_tags() >= len(pk) > 0
+    ctx.close()
