@@ -450,7 +450,10 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
         HIPCHK(c, hipHostMalloc((void **)&c->pin_tags, want * sizeof(am_tag), hipHostMallocDefault));
         c->pin_cap = (uint32_t)want;
     }
-    if (!c->pin_scalars) HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
+    if (!c->pin_scalars) {
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
+        memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));     // [0..2] results of the slice launch, [8] completion ticket
+    }
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
                                      (uint32_t *)c->emit_idx.p, c->stream, Mp));
     HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
