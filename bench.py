@@ -36,6 +36,11 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def ctx_messages(ctx, packets):
+    """Message texts of a packet array as the library formats them (first message: 6 significant digits)."""
+    return [ctx.lib.format_message(packets[i:i + 1], i == 0) for i in range(len(packets))]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +221,23 @@ def main():
                     list(ex.map(chunk, range(P)))
                     d = time.perf_counter() - t2
                     best = d if best is None or d < best else best
+            # the reference's OWN C++ (lib/preamble_impl.cc, slicer_impl.cc, modes_crc.cc compiled by path into
+            # oracle/_ref, which travels with the repository) behind the port's front end, where it exists:
+            # bounded sample, messages compared with the GPU path's
+            if oracle.have_ref():
+                nr = min(n, 8 * 1000 * 1000)
+                t3 = time.perf_counter()
+                rbb, ravg = oracle.frontend(iq[:nr], spc, True)
+                rmsgs = oracle.ref_preamble_slicer(rbb, ravg, spc, 7.0, rate)[2]
+                ref_dt = time.perf_counter() - t3
+                sub = ctx.process_iq(iq[:nr], flush=True)
+                res["cpu_baseline_reference"] = {
+                    "value": nr / ref_dt, "unit": "samples/s", "cores": 1, "kind": "reference",
+                    "sample": "the first %d samples of the batch: port front end (|iq|^2, PMF, reference level) + "
+                              "the reference's preamble_impl/slicer_impl/modes_crc compiled from /root/reference "
+                              "against the GNU Radio API stub, 1 thread, %.2f s" % (nr, ref_dt),
+                    # (the reference driver also reports hits past the canonical end of the stream: a prefix match)
+                    "messages_match_gpu": bool(rmsgs[:len(sub)] == ctx_messages(ctx, sub) and len(sub) > 0)}
             res["cpu_baseline_all_cores"] = {"value": n / best, "unit": "samples/s", "cores": P, "kind": "port",
                                              "sample": "the same batch cut into %d time chunks (+%d samples of "
                                                        "look-ahead each), one oracle thread per chunk, best of 3 "
