@@ -175,3 +175,27 @@ def test_dcblock_option(lib, rate, n):
     spc = int(rate / 2e6)
     pc.check_chunked(lib, rate, iq, [n // 3 + 1, n // 3 + 150 * spc, 2 * n // 3 + 7], dcblock=True)
     pc.check_sharded(lib, rate, iq, 4, dcblock=True)
+
+
+@pytest.mark.parametrize("rate,n,lam", [(2e6, 2000000, 1500.0), (20e6, 3000000, 5000.0), (64e6, 6400000, 20000.0)])
+def test_live_reference_cpp(lib, rate, n, lam):
+    """The reference's OWN preamble_impl / slicer_impl / modes_crc (oracle/_ref: compiled by path from
+    /root/reference in the build container, travels as a prebuilt .so) fed with the GPU front end's bb/avg,
+    against the GPU's own preamble + slicer on the same streams: tags, bursts and message texts."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref/libairmodes_ref.so was not built (no /root/reference at build time)")
+    spc = int(rate / 2e6)
+    iq, _ = synth.synth_capture(rate, n, lam, seed=97)
+    ctx = _capi.Context(rate, 7.0, True, lib=lib)
+    bb, avg = ctx.frontend_work(iq)
+    rb, rt, rmsgs, keep = oracle.ref_preamble_slicer(bb, avg, spc, 7.0, rate)
+    nk = int(keep.sum())
+    bursts, tags = ctx.preamble_work(bb, avg)
+    assert nk == len(tags) > 20 and keep[:nk].all()
+    assert np.array_equal(rt["sample"][:nk], tags["sample"]) and np.array_equal(rt["frac"][:nk], tags["frac"])
+    assert np.array_equal(pc.u32(rb[:nk]), pc.u32(bursts))
+    pk = ctx.slicer_work(bursts, tags)
+    msgs = pc.messages(lib, pk)
+    assert msgs == rmsgs[:len(msgs)] and len(msgs) > 10
+    assert np.array_equal(ctx.process_iq(iq, flush=True), pk)
+    ctx.close()
