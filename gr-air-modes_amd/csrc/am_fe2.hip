@@ -404,9 +404,13 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     __syncthreads();
     FE2_STAMP(6);
 
+    const uint32_t jt0 = (uint32_t)(tile0 - a.out_abs0);   // array coordinate of the tile start
+    // bb out (coalesced, from X) as soon as it is complete in LDS: the writes drain under the reference
+    // level / detection / list phases instead of holding the finished workgroup's resources
+    if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T, EDGE>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
+
     // ---- P5: reference level (a4) + first-stage preamble test (a6) ------------------------------
     float avgv[R];
-    const uint32_t jt0 = (uint32_t)(tile0 - a.out_abs0);   // array coordinate of the tile start
     if (a.ablate & 2u) {
 #pragma unroll
         for (int i = 0; i < R; ++i) avgv[i] = bbv[i];
@@ -521,8 +525,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     }
 
     FE2_STAMP(10);
-    // ---- P6: bb out (coalesced), ordered candidate list ---------------------------------------------
-    if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T, EDGE>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
+    // ---- P6: ordered candidate list ------------------------------------------------------------------
     FE2_STAMP(11);
     uint32_t total = 0;
     uint32_t *seg = a.seg_pos + (size_t)tile * T;
