@@ -81,7 +81,7 @@ struct am_ctx {
 
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
-        visited, emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
+        emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch, dc_m1, dc_y;
 
     // results of the last scan
@@ -399,7 +399,6 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
     c->chain_Mp = Mp;
     if (M == 0) return AM_OK;
     const size_t stride = (size_t)M + 1;
-    ENSURE(c, c->visited, stride);
     ENSURE(c, c->emit, stride);
     ENSURE(c, c->jump, stride * sizeof(uint32_t));
     ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
@@ -424,15 +423,13 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     c->last_M = M;
     *final_cur = cur0;
     if (M == 0) return AM_OK;
-    HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
-                                    (uint8_t *)c->visited.p, (uint32_t *)c->scalars.p, c->stream, Mp));
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
-    HIPCHK(c, am_launch_chain_emit((uint8_t *)c->visited.p, (uint8_t *)c->valid.p, (uint32_t *)c->pos.p,
-                                   (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, M, emit_max, own_lo, own_hi,
-                                   (uint8_t *)c->emit.p, (uint32_t *)c->cblk_cnt.p, (uint32_t *)c->scalars.p,
-                                   emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
+    HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
+                                    (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
+                                    own_hi, (uint8_t *)c->emit.p, (uint32_t *)c->cblk_cnt.p, (uint32_t *)c->scalars.p,
+                                    emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
     HIPCHK(c, am_launch_scan_u32((uint32_t *)c->cblk_cnt.p, (uint32_t *)c->cblk_off.p, nb, c->stream));
     // Hits are at least 240*spc apart, so their number is bounded by the span of the candidates;
     // everything downstream is launched for that bound and reads the real count on the device.
@@ -615,7 +612,7 @@ void am_destroy(am_ctx *c)
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->blk_cnt, &c->blk_off,
-                     &c->pos, &c->e, &c->tgt, &c->valid, &c->visited, &c->emit, &c->jump, &c->emit_idx,
+                     &c->pos, &c->e, &c->tgt, &c->valid, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs, &c->exit_tab, &c->cscratch, &c->dc_m1, &c->dc_y};
     for (DevBuf *b : all) release(*b);

@@ -689,49 +689,6 @@ am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ t
     if (g == M) jump0[M] = M;
 }
 
-__global__ void __launch_bounds__(AM_DET_THREADS)
-am_k_chain_emit(const uint8_t *__restrict__ visited, const uint8_t *__restrict__ valid,
-                const uint32_t *__restrict__ pos, const uint32_t *__restrict__ e,
-                const uint32_t *__restrict__ tgt, uint32_t Mcap, uint32_t emit_max, uint32_t own_lo,
-                uint32_t own_hi, uint8_t *__restrict__ emit, uint32_t *__restrict__ blk_cnt, uint32_t *scalars,
-                int want_resume, const uint32_t *__restrict__ Mp)
-{
-    const uint32_t M = am_count(Mcap, Mp);
-    // emit flags + their per-2048 block counts (for the ordered compaction) in one pass.
-    // room rule (preamble_impl.cc:212): a valid hit too close to the end of the stream is not
-    // emitted (and nothing after it can be).  [own_lo, own_hi) restricts the output to the hits
-    // this GPU's time chunk owns (everything in single-GPU operation).
-    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
-    __shared__ uint32_t wmax[AM_DET_THREADS / AM_WAVE];
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    const int w = threadIdx.x / AM_WAVE;
-    const uint32_t base = blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
-    uint32_t cnt = 0, t = 0;
-    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
-        const uint32_t g = base + it * AM_WAVE + lane;
-        const bool in = g < M;
-        const bool vis = in && visited[g] != 0;
-        const bool em = vis && valid[g] && e[g] <= emit_max && pos[g] >= own_lo && pos[g] < own_hi;
-        if (in) emit[g] = em ? 1 : 0;
-        cnt += (uint32_t)__popcll(__ballot(em));
-        if (want_resume && vis) { const uint32_t tg = tgt[g]; t = tg > t ? tg : t; }
-    }
-    // where the scan resumes after everything visited here: the largest target (only needed when
-    // the stream continues).  Same-address atomics serialise (~11 ns each): one per workgroup.
-    for (int o = 32; o >= 1; o >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)t, o, AM_WAVE);
-        t = other > t ? other : t;
-    }
-    if (lane == 0) { wc[w] = cnt; wmax[w] = t; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0, m = 0;
-        for (int k = 0; k < AM_DET_THREADS / AM_WAVE; ++k) { tot += wc[k]; m = wmax[k] > m ? wmax[k] : m; }
-        blk_cnt[blockIdx.x] = tot;
-        if (want_resume && m) atomicMax(&scalars[0], m);
-    }
-}
-
 #define AM_CB 2048                  /* nodes per block */
 #define AM_CB_THREADS 256
 #define AM_CB_PER (AM_CB / AM_CB_THREADS)
@@ -908,29 +865,40 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
     }
 }
 
+// What the scan does with the candidates it visits (preamble_impl.cc:209-237).
+struct am_emit_args {
+    const uint8_t *valid;
+    const uint32_t *pos, *e, *tgt;
+    uint32_t emit_max;              // room rule (:212): a valid hit too close to the end of the stream is not
+                                    // emitted (and nothing after it can be)
+    uint32_t own_lo, own_hi;        // first-stage positions this GPU's time chunk owns (everything on one GPU)
+    uint8_t *emit;                  // out: per candidate, 1 = a hit to extract
+    uint32_t *blk_cnt;              // out: hits per block of AM_CB candidates (for the ordered compaction)
+    uint32_t *scalars;              // [0]: raised to the largest resume target of a visited candidate
+    int want_resume;
+};
+
 __global__ void __launch_bounds__(AM_CB_THREADS)
 am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ entry, uint32_t Mcap,
-               uint8_t *__restrict__ visited, const uint32_t *__restrict__ Mp)
+               am_emit_args ea, const uint32_t *__restrict__ Mp)
 {
     __shared__ uint16_t J[AM_CB_LEVELS][AM_CB];
     __shared__ uint8_t V[AM_CB];
+    __shared__ uint32_t wc[AM_CB_THREADS / AM_WAVE], wmax[AM_CB_THREADS / AM_WAVE];
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t base = blockIdx.x * AM_CB;
-    if (base >= M) {                                          // (capacity launch: nothing here)
-        if (base == 0 && threadIdx.x == 0) visited[0] = 0;
+    const uint32_t ent = (base < M) ? entry[blockIdx.x] : AM_CB_NONE;
+    if (ent == AM_CB_NONE) {                                  // uniform: the scan jumps over this block (or nothing here)
+        const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t g = base + threadIdx.x + k * AM_CB_THREADS;
+            if (g < end) ea.emit[g] = 0;
+        }
+        if (threadIdx.x == 0) ea.blk_cnt[blockIdx.x] = 0;
         return;
     }
     const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
     const uint32_t n = end - base;
-    const uint32_t ent = entry[blockIdx.x];
-    if (ent == AM_CB_NONE) {                                  // uniform: the scan jumps over this block
-        for (int k = 0; k < AM_CB_PER; ++k) {
-            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-            if (i < n) visited[base + i] = 0;
-        }
-        if (end == M && threadIdx.x == 0) visited[M] = 0;
-        return;
-    }
     const uint16_t OUT = (uint16_t)AM_CB;                    // "leaves the block"
     for (int k = 0; k < AM_CB_PER; ++k) {
         const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
@@ -956,11 +924,36 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         }
         __syncthreads();
     }
+    // emit flags + their count (for the ordered compaction), and where the scan resumes after
+    // everything visited here: the largest target (only needed when the stream continues).
+    // Same-address atomics serialise (~11 ns each): one per workgroup.
+    const int lane = threadIdx.x & (AM_WAVE - 1), w = threadIdx.x / AM_WAVE;
+    uint32_t cnt = 0, tmax = 0;
     for (int k = 0; k < AM_CB_PER; ++k) {
         const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-        if (i < n) visited[base + i] = V[i];
+        const uint32_t g = base + i;
+        const bool vis = i < n && V[i] != 0;
+        bool em = false;
+        if (vis) {
+            const uint32_t p = ea.pos[g];
+            em = ea.valid[g] && ea.e[g] <= ea.emit_max && p >= ea.own_lo && p < ea.own_hi;
+            if (ea.want_resume) { const uint32_t tg = ea.tgt[g]; tmax = tg > tmax ? tg : tmax; }
+        }
+        if (i < n) ea.emit[g] = em ? 1 : 0;
+        cnt += (uint32_t)__popcll(__ballot(em));
     }
-    if (end == M && threadIdx.x == 0) visited[M] = 0;
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)tmax, o, AM_WAVE);
+        tmax = other > tmax ? other : tmax;
+    }
+    if (lane == 0) { wc[w] = cnt; wmax[w] = tmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0, m = 0;
+        for (int k = 0; k < AM_CB_THREADS / AM_WAVE; ++k) { tot += wc[k]; m = wmax[k] > m ? wmax[k] : m; }
+        ea.blk_cnt[blockIdx.x] = tot;
+        if (ea.want_resume && m) atomicMax(&ea.scalars[0], m);
+    }
 }
 
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
@@ -1007,10 +1000,12 @@ hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uin
     return hipGetLastError();
 }
 
-// steps 2 + 3: visited[] for the scan that starts at position cur0
+// steps 2 + 3: which candidates the scan that starts at position cur0 visits, and what it does with them:
+// emit[] flags, hits per block of AM_CB candidates in blk_cnt[], scalars[0] = resume position
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
-                                 uint32_t *scratch, uint8_t *visited, uint32_t *scalars, hipStream_t s,
-                                 const uint32_t *Mp)
+                                 uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
+                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
+                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -1023,10 +1018,15 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     const size_t lds = ((size_t)L.nblk * L.headw + L.nblk + 2) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, scratch + L.off_head, M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp);
-    hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M,
-                       visited, Mp);
+    am_emit_args ea;
+    ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.emit_max = emit_max; ea.own_lo = own_lo;
+    ea.own_hi = own_hi; ea.emit = emit; ea.blk_cnt = blk_cnt; ea.scalars = scalars; ea.want_resume = want_resume;
+    hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M, ea,
+                       Mp);
     return hipGetLastError();
 }
+static_assert(AM_CB == AM_DET_PER_BLOCK, "blk_cnt[] of the chain and the flag compaction use the same blocks");
+unsigned am_chain_block(void) { return AM_CB; }
 
 // exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
@@ -1044,17 +1044,6 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
     const size_t lds = ((size_t)L.nblk * L.headw + 2) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
                        scratch + L.off_head, M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
-    return hipGetLastError();
-}
-
-hipError_t am_launch_chain_emit(const uint8_t *visited, const uint8_t *valid, const uint32_t *pos,
-                                const uint32_t *e, const uint32_t *tgt, uint32_t M, uint32_t emit_max,
-                                uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
-                                uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_chain_emit, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, visited,
-                       valid, pos, e, tgt, M, emit_max, own_lo, own_hi, emit, blk_cnt, scalars, want_resume, Mp);
     return hipGetLastError();
 }
 
