@@ -76,6 +76,7 @@ class Library(object):
         L.am_destroy.argtypes = [vp]
         L.am_set_rate.argtypes = [vp, f64]
         L.am_set_threshold.argtypes = [vp, f32]
+        L.am_set_rx_time.argtypes = [vp, u64, u64, f64]
         L.am_get_rate.restype = f64
         L.am_get_rate.argtypes = [vp]
         L.am_get_threshold.restype = f32
@@ -168,6 +169,11 @@ class Context(object):
 
     def set_threshold(self, thr_db):
         self._chk(self.lib.L.am_set_threshold(self._h, float(thr_db)))
+
+    def set_rx_time(self, offset, secs, frac):
+        """The "rx_time" stream tag of a live source (lib/preamble_impl.cc:165-170): from item `offset`
+        on, packets are stamped (secs, frac) + (item - offset) / rate."""
+        self._chk(self.lib.L.am_set_rx_time(self._h, int(offset), int(secs), float(frac)))
 
     def get_rate(self):
         return float(self.lib.L.am_get_rate(self._h))

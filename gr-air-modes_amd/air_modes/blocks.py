@@ -34,8 +34,12 @@ class preamble(object):
     def get_threshold(self):
         return self._ctx.get_threshold()
 
-    def work(self, in0, in1):
-        """Run the detector over whole streams; returns (bursts[n,240] float32, tags)."""
+    def work(self, in0, in1, rx_time=()):
+        """Run the detector over whole streams; returns (bursts[n,240] float32, tags).  rx_time: the
+        (offset, secs, frac) "rx_time" tags on input 0 (lib/preamble_impl.cc:165-170), ascending."""
+        self._ctx.reset()                      # every call is a stream of its own: item 0, no tags
+        for tag in rx_time:
+            self._ctx.set_rx_time(*tag)
         return self._ctx.preamble_work(in0, in1)
 
 

@@ -46,10 +46,18 @@ class rx_path(object):
         return self._ctx.get_threshold()
 
     # --- what the scheduler does for the reference: push samples through ---
-    def work(self, iq, flush=False):
+    def set_rx_time(self, offset, secs, frac):
+        """What an "rx_time" stream tag does in the reference (lib/preamble_impl.cc:165-170): item
+        `offset` of the stream was received at (secs, frac); later packets are stamped from it."""
+        self._ctx.set_rx_time(offset, secs, frac)
+
+    def work(self, iq, flush=False, rx_time=()):
         """Consume a chunk of the gr_complex stream (complex64 array or interleaved float32);
-        flush=True marks the end of the stream.  Returns the accepted packets (structured
-        array) after posting their messages to the queue."""
+        flush=True marks the end of the stream.  rx_time: the (offset, secs, frac) "rx_time" tags that
+        fall into this chunk, offsets counted over the whole stream.  Returns the accepted packets
+        (structured array) after posting their messages to the queue."""
+        for tag in rx_time:
+            self._ctx.set_rx_time(*tag)
         pk = self._ctx.process_iq(iq, flush=flush)
         return self._account(pk, (np.asarray(iq).size // (1 if np.iscomplexobj(iq) else 2)))
 

@@ -19,6 +19,7 @@ samples into the next chunk.  Per step:
 
 Packets of all ranks, concatenated in rank order, equal the single-GPU (and the reference's)
 packet list for the whole stream; the per-rank work does not grow with the number of ranks.
+"rx_time" tags (ctx.set_rx_time) carry stream-absolute offsets: give every rank's context the same tags.
 """
 import ctypes as C
 

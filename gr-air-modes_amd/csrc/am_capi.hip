@@ -71,6 +71,11 @@ struct am_ctx {
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     char err[256] = "";
 
+    // "rx_time" stream tags still able to stamp a future preamble, ascending offsets (am_set_rx_time);
+    // tt_dev mirrors them on the device for the extraction kernel
+    std::vector<am_time_tag> tt;
+    DevBuf tt_dev;
+
     // stream state (absolute sample indices)
     uint64_t total_in = 0;    // samples received so far
     uint64_t next_pos = 0;    // first position whose preamble test is still undecided
@@ -189,6 +194,7 @@ void reset_stream(am_ctx *c)
     c->carry_abs0 = 0;
     c->carry_n = 0;
     c->shard_ready = false;
+    c->tt.clear();            // item offsets restart with the stream
 }
 
 // positions beyond the end of the data read zeros: every bb/avg array carries this pad
@@ -455,7 +461,8 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                      (uint32_t *)c->emit_idx.p, c->stream, Mp));
     HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                 (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
-                                (float *)c->bursts.p, c->pin_tags, c->stream));
+                                (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(), (float *)c->bursts.p,
+                                c->pin_tags, c->stream));
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
     c->pin_scalars[2] = 0;
@@ -614,7 +621,7 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->exit_tab, &c->cscratch, &c->dc_m1, &c->dc_y};
+                     &c->recs, &c->exit_tab, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -637,6 +644,33 @@ int am_set_threshold(am_ctx *c, float threshold_db)
     if (!c) return AM_EINVAL;
     c->thr_db = threshold_db;
     c->thr_lin = powf(10.0f, (float)((double)threshold_db / 20.0));
+    return AM_OK;
+}
+
+// preamble_impl.cc:165-170 latches the newest "rx_time" tag of the stream; tag_to_timestamp (:100-137)
+// stamps every preamble relative to it.  Here the tags are handed over explicitly (no tagged stream at
+// a C boundary) and take effect exactly at their offset.
+int am_set_rx_time(am_ctx *c, uint64_t offset, uint64_t secs, double frac)
+{
+    if (!c) return AM_EINVAL;
+    if (!(frac == frac)) return fail(c, AM_EINVAL, "rx_time: fractional part is NaN");
+    if (!c->tt.empty() && offset < c->tt.back().offset)
+        return fail(c, AM_EINVAL, "rx_time: tag offsets must not go backwards");
+    // tags no future preamble can refer to: all but the newest one at or before the scan position
+    size_t keep_from = 0;
+    for (size_t i = 0; i < c->tt.size(); i++)
+        if (c->tt[i].offset <= c->chain_cur) keep_from = i;
+    if (keep_from) c->tt.erase(c->tt.begin(), c->tt.begin() + (long)keep_from);
+    const am_time_tag t = {offset, secs, frac};
+    if (!c->tt.empty() && c->tt.back().offset == offset) c->tt.back() = t;    // tstamp_tags.back(): the later one wins
+    else {
+        if (c->tt.size() >= AM_MAX_TIME_TAGS) return fail(c, AM_EINVAL, "rx_time: too many tags pending");
+        c->tt.push_back(t);
+    }
+    // the context is idle between calls: a plain copy, no ordering against the stream needed
+    HIPCHK(c, hipSetDevice(c->device));
+    ENSURE(c, c->tt_dev, AM_MAX_TIME_TAGS * sizeof(am_time_tag));
+    HIPCHK(c, hipMemcpy(c->tt_dev.p, c->tt.data(), c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice));
     return AM_OK;
 }
 

@@ -116,11 +116,20 @@ hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32
                                   uint32_t *out_idx, hipStream_t s, const uint32_t *Mp = nullptr);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
-/* n_ptr: device-side number of hits; n_max: upper bound used for the grid */
+/* "rx_time" stream tag (lib/preamble_impl.cc:165-170): from item `offset` on, time = (secs, frac) +
+ * (item - offset) / rate */
+struct am_time_tag {
+    uint64_t offset;
+    uint64_t secs;
+    double frac;
+};
+#define AM_MAX_TIME_TAGS 4096
+/* n_ptr: device-side number of hits; n_max: upper bound used for the grid; tt[0..ntt): device array of
+ * time tags in ascending offset order */
 hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
                              const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
-                             uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
-                             am_tag *tags, hipStream_t s);
+                             uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
+                             uint32_t ntt, float *bursts, am_tag *tags, hipStream_t s);
 /* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,

@@ -1119,13 +1119,14 @@ hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32
 // ------------------------------------------------------------------------------------------
 // Burst extraction + tag (a9): one wave per emitted preamble.
 //   out[c] = in[e + c*spc] - inavg[e]          preamble_impl.cc:219-221
-//   timestamp from the absolute item count     preamble_impl.cc:100-137 (file source: no rx_time)
+//   timestamp from the absolute item count     preamble_impl.cc:100-137, relative to the rx_time
+//   tag in force at that item (tt[0..ntt) ascending; none: offset 0, time 0 = a file source)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
              const uint32_t *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ pos,
              const uint32_t *__restrict__ eo, uint64_t base_abs, long long e_off, uint64_t rate,
-             float *__restrict__ bursts, am_tag *__restrict__ tags)
+             const am_time_tag *__restrict__ tt, uint32_t ntt, float *__restrict__ bursts, am_tag *__restrict__ tags)
 {
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
@@ -1140,8 +1141,17 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int 
         am_tag t;
         // item count as the preamble block numbers it: stream index + (history - 1)
         t.sample = base_abs + e + (uint64_t)(2 * spc - 1);
-        t.secs = t.sample / rate;                                   // :124
-        t.frac = (double)(t.sample % rate) / (double)rate;          // :125
+        uint64_t off = 0, whole = 0;                                // :103-108 no tag yet
+        double fr = 0.0;
+        uint32_t lo = 0, hi = ntt;                                  // last tag with offset <= sample
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tt[mid].offset <= t.sample) lo = mid + 1; else hi = mid;
+        }
+        if (lo) { off = tt[lo - 1].offset; whole = tt[lo - 1].secs; fr = tt[lo - 1].frac; }   // :110-111
+        const uint64_t d = t.sample - off;
+        t.secs = whole + d / rate;                                  // :124,127
+        t.frac = fr + (double)(d % rate) / (double)rate;            // :125,128
         if (t.frac > 1.0f) { t.frac -= 1.0f; t.secs += 1; }         // :129-132
         t.inavg = av;
         t.how_late = e - pos[g];
@@ -1151,12 +1161,12 @@ am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int 
 
 hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
                              const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
-                             uint64_t base_abs, long long e_off, uint64_t rate, float *bursts,
-                             am_tag *tags, hipStream_t s)
+                             uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
+                             uint32_t ntt, float *bursts, am_tag *tags, hipStream_t s)
 {
     if (n_max == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_ptr,
-                       pos, e, base_abs, e_off, rate, bursts, tags);
+                       pos, e, base_abs, e_off, rate, tt, ntt, bursts, tags);
     return hipGetLastError();
 }
 

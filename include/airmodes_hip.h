@@ -55,7 +55,8 @@ typedef struct am_packet {
     uint32_t reserved2;
     uint64_t sample;       /* preamble item count: stream index + 2*spc - 1                */
     uint64_t secs;         /* sample / rate                (tag_to_timestamp, :124)        */
-    double   frac;         /* (sample % rate) / rate       (tag_to_timestamp, :125)        */
+    double   frac;         /* (sample % rate) / rate       (tag_to_timestamp, :125); both   */
+                           /* relative to the rx_time tag in force (am_set_rx_time)         */
 } am_packet;
 
 /* One preamble hit: the "preamble_found" stream tag (preamble_impl.cc:224-232) whose value
@@ -96,6 +97,20 @@ void am_destroy(am_ctx *ctx);
  * am_set_rate also drops the carried stream state (window lengths change). */
 int    am_set_rate(am_ctx *ctx, double rate);
 int    am_set_threshold(am_ctx *ctx, float threshold_db);
+/* Replaces: the "rx_time" stream tag a live source (UHD, osmosdr) attaches to the sample stream and
+ *           preamble_impl::general_work latches (lib/preamble_impl.cc:165-170); tag_to_timestamp
+ *           (lib/preamble_impl.cc:100-137) then stamps each preamble with
+ *           (secs, frac) + (item - offset) / rate.
+ * offset is the tag's item offset in the input stream (tags pass the front-end blocks 1:1), counted
+ * from the first sample after am_create / am_reset / am_set_rate.  Call it before the am_process_iq
+ * (am_preamble_work, am_shard_scan) call whose samples the tag belongs to, with non-decreasing offsets
+ * (AM_EINVAL otherwise; a second tag at the same offset replaces the first, as .back() does).  The tag
+ * is in force for every preamble whose item count (am_packet.sample) is >= offset, until the next tag;
+ * before any tag the reference's default applies (offset 0, time 0: a file source).  In the reference a
+ * tag is latched as soon as the scheduler's current window contains it, i.e. up to a buffer early
+ * (the unsigned difference :124 then wraps for preambles in front of it); that scheduler-dependent
+ * early latch is not reproduced.  am_reset and am_set_rate drop the pending tags. */
+int    am_set_rx_time(am_ctx *ctx, uint64_t offset, uint64_t secs, double frac);
 double am_get_rate(const am_ctx *ctx);
 float  am_get_threshold(const am_ctx *ctx);
 int    am_get_pmf(const am_ctx *ctx);

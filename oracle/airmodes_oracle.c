@@ -458,6 +458,38 @@ uint64_t amo_demod(const float *iq, uint64_t n, double rate, float thr_db,
     return npk;
 }
 
+/* rx_time stream tags (preamble_impl.cc:165-170 picks the latest tag, tag_to_timestamp :100-137
+ * turns it into a time stamp).  Canonical rule: the tag in force for an item
+ * count k is the last one whose offset is <= k; with no such tag the reference's default applies
+ * (offset 0, time 0).  Which call's window first *sees* a tag depends on GNU Radio's scheduler in the
+ * reference (a tag up to one buffer ahead of the preamble may already be in force there, and the
+ * unsigned difference then wraps); this rule is the limit of small windows and is what the reference
+ * computes whenever no preamble lies in the same window in front of a tag. */
+void amo_timestamp(uint64_t k, uint64_t rate, const amo_time_tag *tt, uint64_t ntt, uint64_t *secs,
+                   double *frac)
+{
+    uint64_t off = 0, whole = 0;
+    double fr = 0.0;
+    for (uint64_t i = 0; i < ntt; i++)
+        if (tt[i].offset <= k) { off = tt[i].offset; whole = tt[i].secs; fr = tt[i].frac; }
+    const uint64_t d = k - off;
+    uint64_t s = whole + d / rate;                                  /* :124,127 */
+    double f = fr + (double)(d % rate) / (double)rate;              /* :125,128 */
+    if (f > 1.0f) { f -= 1.0f; s += 1; }                            /* :129-132 */
+    *secs = s;
+    *frac = f;
+}
+
+void amo_restamp_packets(amo_packet *p, uint64_t n, uint64_t rate, const amo_time_tag *tt, uint64_t ntt)
+{
+    for (uint64_t i = 0; i < n; i++) amo_timestamp(p[i].sample, rate, tt, ntt, &p[i].secs, &p[i].frac);
+}
+
+void amo_restamp_tags(amo_tag *t, uint64_t n, uint64_t rate, const amo_time_tag *tt, uint64_t ntt)
+{
+    for (uint64_t i = 0; i < n; i++) amo_timestamp(t[i].sample, rate, tt, ntt, &t[i].secs, &t[i].frac);
+}
+
 /* slicer_impl.cc:186-192.  The reference formats through a member
  * ostringstream whose precision is raised to 10 while printing the first
  * message's fractional timestamp and never lowered again, so the reference

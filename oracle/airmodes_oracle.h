@@ -97,6 +97,18 @@ int amo_dcblock(const float *iq, uint64_t n, int spc, float *out);
 uint64_t amo_demod2(const float *iq, uint64_t n, double rate, float thr_db, int use_pmf, int use_dcblock,
                     amo_packet *out, uint64_t cap, uint64_t *n_tags);
 
+/* rx_time stream tags (preamble_impl.cc:100-137,165-170): tags sorted by offset; the one in force for item
+ * count k is the last with offset <= k (none: offset 0, time 0).  The restamp helpers recompute
+ * secs/frac of packets / preamble tags from their .sample under a tag list. */
+typedef struct amo_time_tag {
+    uint64_t offset;       /* item count the time stamp belongs to            */
+    uint64_t secs;
+    double   frac;
+} amo_time_tag;
+void amo_timestamp(uint64_t k, uint64_t rate, const amo_time_tag *tt, uint64_t ntt, uint64_t *secs, double *frac);
+void amo_restamp_packets(amo_packet *p, uint64_t n, uint64_t rate, const amo_time_tag *tt, uint64_t ntt);
+void amo_restamp_tags(amo_tag *t, uint64_t n, uint64_t rate, const amo_time_tag *tt, uint64_t ntt);
+
 /* slicer_impl.cc:186-192 message text incl. the sticky-precision quirk:
  * first != 0 -> reference level printed with 6 significant digits, else 10. */
 int amo_format_message(const amo_packet *p, int first, char *buf, size_t cap);

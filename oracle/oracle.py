@@ -63,6 +63,10 @@ def lib():
         L.amo_demod.argtypes = [_f32p, C.c_uint64, C.c_double, C.c_float, C.c_int, C.c_void_p,
                                 C.c_uint64, C.POINTER(C.c_uint64)]
         L.amo_format_message.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]
+        L.amo_restamp_packets.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.amo_restamp_tags.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.amo_restamp_packets.restype = None
+        L.amo_restamp_tags.restype = None
         _lib = L
     return _lib
 
@@ -82,6 +86,9 @@ def ref():
             np.ctypeslib.ndpointer(np.uint64), np.ctypeslib.ndpointer(np.float64),
             np.ctypeslib.ndpointer(np.uint64), C.c_uint64, C.POINTER(C.c_uint64),
             C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        R.ref_preamble_slicer_tt.argtypes = R.ref_preamble_slicer.argtypes + [
+            C.c_uint64, np.ctypeslib.ndpointer(np.uint64), np.ctypeslib.ndpointer(np.uint64),
+            np.ctypeslib.ndpointer(np.float64)]
         _ref = R
     return _ref
 
@@ -119,7 +126,30 @@ def frontend(iq, spc, use_pmf=True, running_chunk=None):
     return bb, avg
 
 
-def preamble_scan(bb, avg, spc, thr_db, rate):
+TIME_TAG_DTYPE = np.dtype([("offset", "<u8"), ("secs", "<u8"), ("frac", "<f8")])
+
+
+def time_tags(rx_time):
+    """[(offset, secs, frac), ...] -> amo_time_tag array sorted by offset (stable: a later entry with the
+    same offset wins, as tstamp_tags.back() does in preamble_impl.cc:168-170)."""
+    tt = np.zeros(len(rx_time), TIME_TAG_DTYPE)
+    for i, (o, s_, f) in enumerate(rx_time):
+        tt[i] = (o, s_, f)
+    return tt[np.argsort(tt["offset"], kind="stable")]
+
+
+def restamp(records, rate, rx_time):
+    """Recompute secs/frac of packets (PACKET_DTYPE) or preamble tags (TAG_DTYPE) under rx_time tags."""
+    if rx_time is None or len(records) == 0:
+        return records
+    tt = time_tags(rx_time)
+    records = np.ascontiguousarray(records)
+    fn = lib().amo_restamp_packets if records.dtype == PACKET_DTYPE else lib().amo_restamp_tags
+    fn(records.ctypes.data, len(records), int(rate), tt.ctypes.data, len(tt))
+    return records
+
+
+def preamble_scan(bb, avg, spc, thr_db, rate, rx_time=None):
     n = bb.size
     cap = n // (240 * spc) + 2
     bursts = np.zeros((cap, 240), np.float32)
@@ -127,7 +157,7 @@ def preamble_scan(bb, avg, spc, thr_db, rate):
     hits = lib().amo_preamble_scan(np.ascontiguousarray(bb, np.float32), np.ascontiguousarray(avg, np.float32),
                                    n, spc, thr_db, int(rate), bursts.reshape(-1), tags.ctypes.data, cap)
     assert hits <= cap
-    return bursts[:hits], tags[:hits]
+    return bursts[:hits], restamp(tags[:hits], rate, rx_time)
 
 
 def slice_bursts(bursts, tags):
@@ -157,7 +187,7 @@ def dcblock(iq, spc):
     return out.view(np.complex64)
 
 
-def demod(iq, rate, thr_db=7.0, use_pmf=True, return_tags=False, use_dcblock=False):
+def demod(iq, rate, thr_db=7.0, use_pmf=True, return_tags=False, use_dcblock=False, rx_time=None):
     f = as_iq_f32(iq)
     n = f.size // 2
     spc = max(int(rate / 2e6), 1)
@@ -167,7 +197,8 @@ def demod(iq, rate, thr_db=7.0, use_pmf=True, return_tags=False, use_dcblock=Fal
     npk = lib().amo_demod2(f, n, float(rate), thr_db, int(use_pmf), int(use_dcblock), out.ctypes.data, cap,
                            C.byref(ntags))
     assert npk <= cap
-    return (out[:npk], int(ntags.value)) if return_tags else out[:npk]
+    pk = restamp(out[:npk], rate, rx_time)
+    return (pk, int(ntags.value)) if return_tags else pk
 
 
 def format_messages(packets, first=True):
@@ -182,9 +213,14 @@ def format_messages(packets, first=True):
     return msgs
 
 
-def ref_preamble_slicer(bb, avg, spc, thr_db, rate):
+def ref_preamble_slicer(bb, avg, spc, thr_db, rate, rx_time=None):
     """The reference's OWN preamble_impl + slicer_impl (+modes_crc) on the two float
-    streams; canonical end-of-stream rule applied here.  Returns (bursts, tags, msgs)."""
+    streams; canonical end-of-stream rule applied here.  Returns (bursts, tags, msgs, keep).
+    rx_time = [(offset, secs, frac), ...]: "rx_time" stream tags on the preamble block's input (the
+    driver ends scheduler windows at the tags, see ref_driver.cc; needs silence in front of each tag)."""
+    if rx_time is not None:
+        # the hits do not depend on the time tags: item counts come from an untagged run
+        b0, t0, _, keep0 = ref_preamble_slicer(bb, avg, spc, thr_db, rate)
     n = bb.size
     pad = 600 * spc
     cap = (n + pad) // (240 * spc) + 4
@@ -197,9 +233,15 @@ def ref_preamble_slicer(bb, avg, spc, thr_db, rate):
     msgs = C.create_string_buffer(mcap)
     mlen = C.c_uint64(0)
     nmsg = C.c_uint64(0)
-    rc = ref().ref_preamble_slicer(np.ascontiguousarray(bb, np.float32), np.ascontiguousarray(avg, np.float32),
-                                   n, float(rate), thr_db, pad, bursts.reshape(-1), secs, frac, item, cap,
-                                   C.byref(ntags), msgs, mcap, C.byref(mlen), C.byref(nmsg))
+    args = [np.ascontiguousarray(bb, np.float32), np.ascontiguousarray(avg, np.float32),
+            n, float(rate), thr_db, pad, bursts.reshape(-1), secs, frac, item, cap,
+            C.byref(ntags), msgs, mcap, C.byref(mlen), C.byref(nmsg)]
+    if rx_time is None:
+        rc = ref().ref_preamble_slicer(*args)
+    else:
+        tt = time_tags(rx_time)
+        rc = ref().ref_preamble_slicer_tt(*args, len(tt), np.ascontiguousarray(tt["offset"]),
+                                          np.ascontiguousarray(tt["secs"]), np.ascontiguousarray(tt["frac"]))
     if rc != 0:
         raise RuntimeError("ref_preamble_slicer rc=%d" % rc)
     nt = int(ntags.value)
@@ -208,9 +250,13 @@ def ref_preamble_slicer(bb, avg, spc, thr_db, rate):
     tags["secs"] = secs[:nt]
     tags["frac"] = frac[:nt]
     r = int(rate)
-    tags["sample"] = secs[:nt] * np.uint64(r) + np.rint(frac[:nt] * r).astype(np.uint64)
     text = msgs.raw[:mlen.value].decode().split("\n")[:-1]
     assert len(text) == nmsg.value
+    if rx_time is not None:
+        assert nt == len(t0) and np.array_equal(bursts[:nt], b0)
+        tags["sample"] = t0["sample"]
+        return bursts[:nt], tags, text, keep0
+    tags["sample"] = secs[:nt] * np.uint64(r) + np.rint(frac[:nt] * r).astype(np.uint64)
     # canonical end-of-stream rule: hits need 240*spc items of room
     K = n + 2 * spc - 1
     ninputs = K - K % spc - spc

@@ -36,13 +36,29 @@ uint32_t ref_crc24(const uint8_t *data, int nbytes)
 // pad_items zeros are appended so that the end-of-buffer rule never fires inside the
 // real data; the caller applies the canonical end-of-stream rule.
 // Returns 0 on success.
-int ref_preamble_slicer(const float *in, const float *inavg, uint64_t n, float rate,
-                        float thr_db, uint64_t pad_items, float *bursts, uint64_t *tag_secs,
-                        double *tag_frac, uint64_t *tag_item, uint64_t cap_tags,
-                        uint64_t *n_tags, char *msgs, uint64_t msgs_cap, uint64_t *msgs_len,
-                        uint64_t *n_msgs)
+//
+// rx_time tags (n_tt entries, ascending item offsets in the preamble block's own item count): the
+// reference latches the newest tag inside the window of the current general_work() call
+// (preamble_impl.cc:165-170), so WHEN a tag takes effect depends on the scheduler's windows.  This
+// driver ends every window at the next tag's offset, so that a tag is in force exactly from its
+// offset on; the few items in front of a tag that the block cannot scan in such a window (it keeps
+// one chip of margin, :150) are skipped, which is only legitimate when they are silent -- the driver
+// checks that and returns -3 otherwise.  Test streams therefore keep a silent gap in front of tags.
+int ref_preamble_slicer_tt(const float *in, const float *inavg, uint64_t n, float rate,
+                           float thr_db, uint64_t pad_items, float *bursts, uint64_t *tag_secs,
+                           double *tag_frac, uint64_t *tag_item, uint64_t cap_tags,
+                           uint64_t *n_tags, char *msgs, uint64_t msgs_cap, uint64_t *msgs_len,
+                           uint64_t *n_msgs, uint64_t n_tt, const uint64_t *tt_offset,
+                           const uint64_t *tt_secs, const double *tt_frac)
 {
     gr::air_modes::preamble::sptr pre = gr::air_modes::preamble::make(rate, thr_db);
+    for (uint64_t t = 0; t < n_tt; t++) {
+        gr::tag_t g;
+        g.offset = tt_offset[t];
+        g.key = pmt::string_to_symbol("rx_time");
+        g.value = pmt::make_tuple(pmt::from_uint64(tt_secs[t]), pmt::from_double(tt_frac[t]));
+        pre->stub_in_tags.push_back(g);
+    }
     const unsigned hist = pre->history();
     const uint64_t K = n + (hist - 1) + pad_items;
     std::vector<float> a(K + 64, 0.0f), b(K + 64, 0.0f);
@@ -56,7 +72,11 @@ int ref_preamble_slicer(const float *in, const float *inavg, uint64_t n, float r
     uint64_t r = 0;
     for (;;) {
         if (K <= r) break;
-        gr_vector_int nin(2, (int)std::min<uint64_t>(K - r, 0x7fffffff));
+        uint64_t win = K - r;
+        bool cut = false;                   // window ends at the next rx_time tag
+        for (uint64_t t = 0; t < n_tt; t++)
+            if (tt_offset[t] > r && tt_offset[t] - r < win) { win = tt_offset[t] - r; cut = true; }
+        gr_vector_int nin(2, (int)std::min<uint64_t>(win, 0x7fffffff));
         gr_vector_const_void_star ins(2);
         ins[0] = a.data() + r;
         ins[1] = b.data() + r;
@@ -68,7 +88,13 @@ int ref_preamble_slicer(const float *in, const float *inavg, uint64_t n, float r
         int produced = pre->general_work(240, nin, ins, outs);
         if (produced > 0) stream.insert(stream.end(), out, out + produced);
         for (size_t t = ntag0; t < pre->stub_out_tags.size(); t++) tags.push_back(pre->stub_out_tags[t]);
-        if (produced == 0 && pre->stub_consumed == 0) break;
+        if (produced == 0 && pre->stub_consumed == 0) {
+            if (!cut) break;
+            for (uint64_t k = r; k < r + win + 16; k++)      // skipping is only sound over silence
+                if (a[k] != 0.0f || b[k] != 0.0f) return -3;
+            r += win;
+            continue;
+        }
         r += (uint64_t)pre->stub_consumed;
     }
 
@@ -100,6 +126,16 @@ int ref_preamble_slicer(const float *in, const float *inavg, uint64_t n, float r
     *msgs_len = w;
     *n_msgs = q->stub_msgs.size();
     return 0;
+}
+
+int ref_preamble_slicer(const float *in, const float *inavg, uint64_t n, float rate,
+                        float thr_db, uint64_t pad_items, float *bursts, uint64_t *tag_secs,
+                        double *tag_frac, uint64_t *tag_item, uint64_t cap_tags,
+                        uint64_t *n_tags, char *msgs, uint64_t msgs_cap, uint64_t *msgs_len,
+                        uint64_t *n_msgs)
+{
+    return ref_preamble_slicer_tt(in, inavg, n, rate, thr_db, pad_items, bursts, tag_secs, tag_frac, tag_item,
+                                  cap_tags, n_tags, msgs, msgs_cap, msgs_len, n_msgs, 0, nullptr, nullptr, nullptr);
 }
 
 } // extern "C"

@@ -119,6 +119,98 @@ def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None, ctxs=None, dcb
     return len(got)
 
 
+def rx_time_golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "rxtime_*.npz")))
+
+
+def load_rx_time_golden(path):
+    z = np.load(path)
+    rx = [(int(o), int(s_), float(f)) for o, s_, f in zip(z["rx_offset"], z["rx_secs"], z["rx_frac"])]
+    return dict(iq=z["iq"], rate=float(z["rate"]), thr=float(z["thr_db"]), rx=rx, ref_sample=z["ref_tag_sample"],
+                ref_secs=z["ref_tag_secs"], ref_frac=z["ref_tag_frac"], ref_msgs=[str(m) for m in z["ref_msgs"]])
+
+
+def check_rx_time_golden(lib, path):
+    """Product path under "rx_time" tags vs what the REFERENCE's own preamble_impl.cc (tag_to_timestamp)
+    and slicer_impl.cc produced (tests/golden/rxtime_*.npz, tools/gen_golden.py rx_time)."""
+    g = load_rx_time_golden(path)
+    spc = int(g["rate"] / 2e6)
+    ctx = _capi.Context(g["rate"], g["thr"], True, lib=lib)
+    bb, avg = ctx.frontend_work(g["iq"])
+    for tag in g["rx"]:
+        ctx.set_rx_time(*tag)
+    _, tags = ctx.preamble_work(bb, avg)
+    assert np.array_equal(tags["sample"], g["ref_sample"])
+    assert np.array_equal(tags["secs"], g["ref_secs"]) and np.array_equal(tags["frac"], g["ref_frac"])
+    ctx.reset()
+    n = len(g["iq"])
+    parts = []
+    for a, b in [(0, n // 2), (n // 2, n)]:
+        for tag in g["rx"]:
+            if a <= tag[0] < b:
+                ctx.set_rx_time(*tag)
+        parts.append(ctx.process_iq(g["iq"][a:b], flush=(b == n)))
+    assert messages(lib, np.concatenate(parts)) == g["ref_msgs"]
+    ctx.close()
+
+
+def check_rx_time(lib, rate, n, lam, seed, thr=7.0, pmf=True, G=3):
+    """"rx_time" stream tags (lib/preamble_impl.cc:100-137,165-170): a tag at the stream start, one that
+    makes the fractional part roll over, two on the same item (the later wins), one on the very last
+    items; block level, streaming (tags handed over with the chunk they fall into, and all in advance)
+    and time-sharded.  Returns the number of distinct whole seconds seen (the tags must matter)."""
+    spc = int(rate / 2e6)
+    iq, _ = synth.synth_capture(rate, n, lam, seed)
+    rx = [(0, 1600000000, 0.125), (n // 3 + 5, 1600000007, 0.9999995), (2 * n // 3, 3, 0.5),
+          (2 * n // 3, 1700000000, 0.75), (n - 100 * spc, 9, 0.0)]
+    want = oracle.demod(iq, rate, thr, pmf, rx_time=rx)
+    plain = oracle.demod(iq, rate, thr, pmf)
+    assert np.array_equal(want["sample"], plain["sample"]) and not np.array_equal(want["secs"], plain["secs"])
+    # block level
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    obb, oavg = oracle.frontend(iq, spc, pmf)
+    for tag in rx:
+        ctx.set_rx_time(*tag)
+    bursts, tags = ctx.preamble_work(obb, oavg)
+    ob, ot = oracle.preamble_scan(obb, oavg, spc, thr, rate, rx_time=rx)
+    assert np.array_equal(tags, ot), "tags differ"
+    ctx.reset()                                              # drops the tags with the stream state
+    assert np.array_equal(ctx.process_iq(iq, flush=True), plain)
+    # streaming: each tag arrives with its chunk
+    ctx.reset()
+    edges = [0, n // 5, n // 3 + 5, n // 2, 2 * n // 3 + 7, n]
+    parts = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        for tag in rx:
+            if a <= tag[0] < b:
+                ctx.set_rx_time(*tag)
+        parts.append(ctx.process_iq(iq[a:b], flush=(b == n)))
+    assert np.array_equal(np.concatenate(parts), want), "streaming with rx_time differs"
+    # streaming: all tags known in advance, other chunking
+    ctx.reset()
+    for tag in rx:
+        ctx.set_rx_time(*tag)
+    try:                                                     # offsets must not go backwards
+        ctx.set_rx_time(5, 1, 0.0)
+        raise AssertionError("backwards rx_time accepted")
+    except _capi.AirModesError:
+        pass
+    got = np.concatenate([ctx.process_iq(iq[:n // 7]), ctx.process_iq(iq[n // 7:], flush=True)])
+    assert np.array_equal(got, want)
+    assert messages(lib, got) == oracle.format_messages(want)
+    assert np.array_equal(ctx.process_iq(iq, flush=True), plain)      # the end of a stream drops its tags
+    ctx.close()
+    # time-sharded: every rank's context holds the same tags
+    ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
+    for c in ctxs:
+        for tag in rx:
+            c.set_rx_time(*tag)
+    check_sharded(lib, rate, iq, G, thr, pmf, want=want, ctxs=ctxs)
+    for c in ctxs:
+        c.close()
+    return len(np.unique(want["secs"]))
+
+
 def edge_inputs(rate, seed=5):
     """Edge cases: empty, shorter than one burst, exactly at the room limit, all zeros,
     huge / tiny / non-finite samples."""

@@ -193,3 +193,14 @@ def test_candidate_count_accessor(emu_lib):
     pk = ctx.process_iq(iq, flush=True)
     assert ctx.last_num_candidates() >= ctx.last_num_tags() >= len(pk) > 0
     ctx.close()
+
+
+@pytest.mark.parametrize("path", pc.rx_time_golden_cases(), ids=os.path.basename)
+def test_rx_time_reference_golden(emu_lib, path):
+    pc.check_rx_time_golden(emu_lib, path)
+
+
+@pytest.mark.parametrize("rate,n", [(2e6, 150000), (8e6, 300000), (64e6, 700000)])
+def test_rx_time_tags(emu_lib, rate, n):
+    """am_set_rx_time: block level, streaming (tags arriving with their chunk / in advance), sharded."""
+    assert pc.check_rx_time(emu_lib, rate, n, 3000.0, 91) >= 3

@@ -199,3 +199,15 @@ def test_live_reference_cpp(lib, rate, n, lam):
     assert msgs == rmsgs[:len(msgs)] and len(msgs) > 10
     assert np.array_equal(ctx.process_iq(iq, flush=True), pk)
     ctx.close()
+
+
+@pytest.mark.parametrize("path", pc.rx_time_golden_cases(), ids=os.path.basename)
+def test_rx_time_reference_golden(lib, path):
+    """"rx_time" stream tags: packets stamped by the GPU path vs the reference's own tag_to_timestamp."""
+    pc.check_rx_time_golden(lib, path)
+
+
+@pytest.mark.parametrize("rate,n", [(2e6, 1000000), (20e6, 2000000), (64e6, 6400000)])
+def test_rx_time_tags(lib, rate, n):
+    """am_set_rx_time: block level, streaming (tags arriving with their chunk / in advance), sharded."""
+    assert pc.check_rx_time(lib, rate, n, 3000.0, 91, G=4) >= 3

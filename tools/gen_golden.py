@@ -77,5 +77,46 @@ def main():
     print("crc_kat.json: %d vectors" % len(kat))
 
 
+# "rx_time" stream tags: (name, rate, n, lambda/s, seed); the capture is silenced in front of every tag
+# so that the reference's scheduler-dependent early latch cannot matter (oracle/ref_driver.cc)
+RX_TIME_CASES = [("rxtime_4msps", 4e6, 90000, 6000.0, 111), ("rxtime_20msps", 20e6, 140000, 14000.0, 112)]
+
+
+def rx_time_tags(n, spc):
+    return [(0, 1600000000, 0.125), (n // 3 + 5, 1600000007, 0.9999995), (2 * n // 3, 3, 0.5),
+            (2 * n // 3, 1700000000, 0.75)]
+
+
+def gen_rx_time():
+    for name, rate, n, lam, seed in RX_TIME_CASES:
+        spc = int(rate / 2e6)
+        iq, _ = synth.synth_capture(rate, n, lam, seed, snr_db=(12.0, 35.0))
+        rx = rx_time_tags(n, spc)
+        for off, _, _ in rx[1:]:
+            iq[off - 900 * spc:off + 32] = 0
+        bb, avg = oracle.frontend(iq, spc, True)
+        rb, rt, rmsgs, keep = oracle.ref_preamble_slicer(bb, avg, spc, 7.0, rate, rx_time=rx)
+        nk = int(keep.sum())
+        assert keep[:nk].all()
+        # messages of hits past the end-of-stream rule come last, if any; count the kept ones
+        _, _, plain_msgs, _ = oracle.ref_preamble_slicer(bb, avg, spc, 7.0, rate)
+        opk = oracle.demod(iq, rate, 7.0, True, rx_time=rx)
+        rmsgs = rmsgs[:len(opk)]
+        assert oracle.format_messages(opk) == rmsgs, "oracle and reference disagree"
+        assert len(set(m.split()[3] for m in rmsgs)) >= 3, "tags must matter"
+        np.savez_compressed(
+            os.path.join(OUT, name + ".npz"), iq=iq, rate=np.float64(rate), thr_db=np.float32(7.0),
+            use_pmf=np.int32(1), rx_offset=np.array([t[0] for t in rx], np.uint64),
+            rx_secs=np.array([t[1] for t in rx], np.uint64), rx_frac=np.array([t[2] for t in rx], np.float64),
+            ref_tag_sample=rt["sample"][:nk], ref_tag_secs=rt["secs"][:nk], ref_tag_frac=rt["frac"][:nk],
+            ref_msgs=np.array(rmsgs))
+        print("%s: %d samples, %d reference tags, %d reference messages" % (name, n, nk, len(rmsgs)))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["rx_time"]:
+        oracle.build()
+        gen_rx_time()          # only the rx_time fixtures (the others stay byte-identical in git)
+    else:
+        main()
+        gen_rx_time()
