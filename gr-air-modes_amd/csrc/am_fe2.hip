@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #if defined(__clang__)
@@ -136,6 +137,69 @@ __device__ __forceinline__ void fe2_store_tile(const float *X, int lhp, float *d
         if (a.clk && (tid == 0 || tid == 5 * AM_WAVE))                                          \
             a.clk[(size_t)tile * 32 + (tid ? 16 : 0) + (k)] = (long long)clock64();             \
     } while (0)
+
+// First-stage test with EXEC-narrowing compares (gfx9 v_cmpx: EXEC &= condition), eight samples per
+// block: three VALU instructions and one scalar move per sample.  The compiler's own form of the same
+// predicate keeps every partial result as a lane mask in scalar registers and spends ~9 scalar
+// instructions per sample on combining them -- the scalar unit, not the vector ALU, then bounds the phase.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FE2_NO_CMPX)
+#define FE2_CMPX 1
+// bit SH+k of cm |= (x[k] > thr[k]) & !(x[k+1] > x[k])        preamble_impl.cc:174-175
+template <int SH>
+__device__ __forceinline__ void fe2_peak8(uint32_t &cm, const float *x, float x8, const float *thr)
+{
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x0], %[t0]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x1], %[x0]\n\t"
+        "v_or_b32_e32 %[cm], %[b0], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x1], %[t1]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x2], %[x1]\n\t"
+        "v_or_b32_e32 %[cm], %[b1], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x2], %[t2]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x3], %[x2]\n\t"
+        "v_or_b32_e32 %[cm], %[b2], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x3], %[t3]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x4], %[x3]\n\t"
+        "v_or_b32_e32 %[cm], %[b3], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x4], %[t4]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x5], %[x4]\n\t"
+        "v_or_b32_e32 %[cm], %[b4], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x5], %[t5]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x6], %[x5]\n\t"
+        "v_or_b32_e32 %[cm], %[b5], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x6], %[t6]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x7], %[x6]\n\t"
+        "v_or_b32_e32 %[cm], %[b6], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_gt_f32_e32 vcc, %[x7], %[t7]\n\t" "v_cmpx_ngt_f32_e32 vcc, %[x8], %[x7]\n\t"
+        "v_or_b32_e32 %[cm], %[b7], %[cm]\n\t" "s_mov_b64 exec, %[sv]"
+        : [cm] "+v"(cm), [sv] "=&s"(sv)
+        : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]),
+          [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x8), [t0] "v"(thr[0]), [t1] "v"(thr[1]), [t2] "v"(thr[2]),
+          [t3] "v"(thr[3]), [t4] "v"(thr[4]), [t5] "v"(thr[5]), [t6] "v"(thr[6]), [t7] "v"(thr[7]),
+          [b0] "n"(1u << (SH + 0)), [b1] "n"(1u << (SH + 1)), [b2] "n"(1u << (SH + 2)), [b3] "n"(1u << (SH + 3)),
+          [b4] "n"(1u << (SH + 4)), [b5] "n"(1u << (SH + 5)), [b6] "n"(1u << (SH + 6)), [b7] "n"(1u << (SH + 7))
+        : "vcc");
+}
+// bit SH+k of cm &= !(w[k] < thr[k])                            preamble_impl.cc:177-179 (w = weakest later pulse)
+template <int SH>
+__device__ __forceinline__ void fe2_weak8(uint32_t &cm, const float *w, const float *thr)
+{
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w0], %[t0]\n\t" "v_and_b32_e32 %[cm], %[b0], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w1], %[t1]\n\t" "v_and_b32_e32 %[cm], %[b1], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w2], %[t2]\n\t" "v_and_b32_e32 %[cm], %[b2], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w3], %[t3]\n\t" "v_and_b32_e32 %[cm], %[b3], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w4], %[t4]\n\t" "v_and_b32_e32 %[cm], %[b4], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w5], %[t5]\n\t" "v_and_b32_e32 %[cm], %[b5], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w6], %[t6]\n\t" "v_and_b32_e32 %[cm], %[b6], %[cm]\n\t" "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_lt_f32_e32 vcc, %[w7], %[t7]\n\t" "v_and_b32_e32 %[cm], %[b7], %[cm]\n\t" "s_mov_b64 exec, %[sv]"
+        : [cm] "+v"(cm), [sv] "=&s"(sv)
+        : [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[4]), [w5] "v"(w[5]),
+          [w6] "v"(w[6]), [w7] "v"(w[7]), [t0] "v"(thr[0]), [t1] "v"(thr[1]), [t2] "v"(thr[2]), [t3] "v"(thr[3]),
+          [t4] "v"(thr[4]), [t5] "v"(thr[5]), [t6] "v"(thr[6]), [t7] "v"(thr[7]),
+          [b0] "n"(~(1u << (SH + 0))), [b1] "n"(~(1u << (SH + 1))), [b2] "n"(~(1u << (SH + 2))),
+          [b3] "n"(~(1u << (SH + 3))), [b4] "n"(~(1u << (SH + 4))), [b5] "n"(~(1u << (SH + 5))),
+          [b6] "n"(~(1u << (SH + 6))), [b7] "n"(~(1u << (SH + 7)))
+        : "vcc");
+}
+#endif
 
 struct am_fe2_args {
     const float *iq;
@@ -459,6 +523,36 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
         constexpr int CH = (R % 16 == 0) ? 16 : R;           // samples per pass (scalar register budget)
         static_assert(R % CH == 0, "passes tile the run");
         const float nxt = X[fe2_pidx(run_base + R)];
+#if defined(FE2_CMPX)
+        if constexpr (!EDGE && (CH % 8 == 0)) {       // interior tiles: EXEC-narrowing compares (fe2_peak8)
+            static_assert(CH <= 16 && R <= 2 * CH, "at most two passes of at most two blocks of eight");
+            auto pass = [&](auto hc) __attribute__((always_inline)) {
+                constexpr int H = decltype(hc)::value;
+                float thr[CH];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) thr[i] = avgv[H + i] * a.thr_lin;        // preamble_impl.cc:173
+                uint32_t part = 0u;
+                fe2_peak8<H>(part, &bbv[H], (H + 8 < R) ? bbv[(H + 8 < R) ? H + 8 : 0] : nxt, &thr[0]);
+                if constexpr (CH > 8)
+                    fe2_peak8<H + 8>(part, &bbv[H + 8], (H + 16 < R) ? bbv[(H + 16 < R) ? H + 16 : 0] : nxt, &thr[8]);
+                // later pulses (:177-179), only where some lane still has a survivor (see below)
+                if (__ballot(part != 0u) != 0ull) {
+                    constexpr bool AL = SHIFT_AL && (CH % 4 == 0), IG = (SPC % CH == 0) && (32 % CH == 0);
+                    float t2[CH], t7[CH], t9[CH];
+                    fe2_lds_load<CH, AL, IG>(X, run_base + 2 * SPC + H, t2);
+                    fe2_lds_load<CH, AL, IG>(X, run_base + 7 * SPC + H, t7);
+                    fe2_lds_load<CH, AL, IG>(X, run_base + 9 * SPC + H, t9);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) t2[i] = fminf(fminf(t2[i], t7[i]), t9[i]);
+                    fe2_weak8<H>(part, &t2[0], &thr[0]);
+                    if constexpr (CH > 8) fe2_weak8<H + 8>(part, &t2[8], &thr[8]);
+                }
+                cm |= part;
+            };
+            pass(std::integral_constant<int, 0>{});
+            if constexpr (R > CH) pass(std::integral_constant<int, CH>{});
+        } else
+#endif
 #pragma unroll
         for (int h = 0; h < R; h += CH) {
             bool c[CH];
