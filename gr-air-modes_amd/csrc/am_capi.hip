@@ -90,8 +90,9 @@ struct am_ctx {
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch, dc_m1, dc_y;
 
     // results of the last scan
-    std::vector<am_packet> h_packets;   // every sliced burst, reserved[0] = accepted
-    std::vector<am_tag> h_tags;
+    std::vector<am_packet> h_packets;   // am_slicer_work: every sliced burst, reserved[0] = accepted
+    std::vector<am_tag> h_tags;         // block-level scans (am_preamble_work): one tag per hit
+    uint32_t n_hits = 0;                // preamble hits of the last scan
     std::vector<float> h_bursts;
     std::vector<am_packet> pending;     // accepted packets not yet handed to the caller
     std::vector<am_shard_exit> h_exit;  // exit table of the resident chunk
@@ -416,7 +417,8 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
 
 // Greedy chain, part 2: mark the candidates the scan visits when it starts at cur0, then extract
 // and slice the hits (e <= emit_max, first-stage position in [own_lo, own_hi)).
-// Fills h_packets / h_tags (+ h_bursts).
+// keep_bursts (block-level scan): fills h_tags + h_bursts.  Otherwise (streaming / sharded scan) the tags
+// stay on the device and the accepted packets go straight from pinned memory to `pending`.
 int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, uint64_t base_abs,
                  bool keep_bursts, uint32_t *final_cur, uint32_t max_hits, uint32_t own_lo = 0,
                  uint32_t own_hi = 0xFFFFFFFFu, long long e_off = 0)
@@ -426,6 +428,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     c->h_packets.clear();
     c->h_tags.clear();
     c->h_bursts.clear();
+    c->n_hits = 0;
     c->last_M = M;
     *final_cur = cur0;
     if (M == 0) return AM_OK;
@@ -459,14 +462,21 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     }
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
                                      (uint32_t *)c->emit_idx.p, c->stream, Mp));
+    // the slicer reads the tags back: device memory unless the caller wants them (a read from pinned host
+    // memory is a PCIe round trip inside the kernel)
+    am_tag *tags = c->pin_tags;
+    if (!keep_bursts) {
+        ENSURE(c, c->tags, (size_t)n_max * sizeof(am_tag));
+        tags = (am_tag *)c->tags.p;
+    }
     HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                 (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
                                 (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(), (float *)c->bursts.p,
-                                c->pin_tags, c->stream));
+                                tags, c->stream));
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
     c->pin_scalars[2] = 0;
-    HIPCHK(c, am_launch_slice((float *)c->bursts.p, c->pin_tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
+    HIPCHK(c, am_launch_slice((float *)c->bursts.p, tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
                               c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan
     const uint32_t seq = ++c->ticket_seq;
@@ -483,9 +493,17 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     const uint32_t n_emit = c->pin_scalars[0];
     *final_cur = c->pin_scalars[1];
     if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
-    c->h_packets.assign(c->pin_packets, c->pin_packets + n_emit);
+    c->n_hits = n_emit;
+    if (!keep_bursts) {
+        for (uint32_t i = 0; i < n_emit; i++) {
+            if (!c->pin_packets[i].reserved[0]) continue;      // rejected: only this flag was written
+            c->pending.push_back(c->pin_packets[i]);
+            c->pending.back().reserved[0] = 0;
+        }
+        return AM_OK;
+    }
     c->h_tags.assign(c->pin_tags, c->pin_tags + n_emit);
-    if (keep_bursts && n_emit) {
+    if (n_emit) {
         c->h_bursts.resize((size_t)n_emit * AM_BURST);
         HIPCHK(c, hipMemcpyAsync(c->h_bursts.data(), c->bursts.p, (size_t)n_emit * AM_BURST * sizeof(float),
                                  hipMemcpyDeviceToHost, c->stream));
@@ -500,6 +518,7 @@ int run_chain_and_slice(am_ctx *c, const float *bb, const float *, uint32_t M, u
     c->h_packets.clear();
     c->h_tags.clear();
     c->h_bursts.clear();
+    c->n_hits = 0;
     c->last_M = M;
     *final_cur = cur0;
     int rc = chain_prepare(c, M, false, c->spec_now ? c->Mdev : nullptr);
@@ -786,8 +805,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         }
         if (rc != AM_OK) return rc;
         c->spec_density = (j1 > j0) ? (double)c->last_M / (double)(j1 - j0) : 0.0;
-        c->last_tags = c->h_packets.size();
-        collect_accepted(c);
+        c->last_tags = c->n_hits;
         if (out_abs0 + fin > c->chain_cur) c->chain_cur = out_abs0 + fin;
         c->next_pos = P1;
     }
@@ -1128,8 +1146,7 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
     int rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits);
     if (rc != AM_OK) return rc;
-    c->last_tags = c->h_packets.size();
-    collect_accepted(c);
+    c->last_tags = c->n_hits;
     return hand_out(c, out, cap, n_out);
 }
 

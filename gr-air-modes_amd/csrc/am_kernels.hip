@@ -1262,6 +1262,11 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
         p.crc = part;
         p.ref = ref;
         p.reserved2 = 0;
+        if (!ok) {
+            // never handed out: only the flag travels (the packet array is usually pinned host memory)
+            packets[i].reserved[0] = 0;
+            return;
+        }
         const am_tag t = tags[i];
         p.sample = t.sample;
         p.secs = t.secs;
