@@ -772,6 +772,12 @@ __device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint32_t
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AM_KEEP_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define AM_KEEP_VGPR(x) ((void)0)
+#endif
+
 __global__ void __launch_bounds__(1024)
 am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
                const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
@@ -806,6 +812,10 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
             ent[kb] = (uint16_t)ki;
             if (ki >= headw) { g = __builtin_nontemporal_load(&exitnode[g]); continue; }   // root / long head
             uint32_t slot = (kb << hs) + ki, nx;
+            // The slot stays in a vector register: everything here is uniform (one lane), and the compiler
+            // would otherwise move each loaded link to the scalar unit (v_readfirstlane + scalar address
+            // arithmetic + v_mov back) -- all of it on the load-to-load dependency chain of the walk.
+            AM_KEEP_VGPR(slot);
             while ((nx = lnk[slot]) < AM_CB_OUT) {           // the fast loop: one hop per block
                 slot = nx;
                 ent[slot >> hs] = (uint16_t)(slot & hm);
