@@ -446,7 +446,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     const uint32_t n_max = max_hits < M ? max_hits : M;
     const uint32_t *n_ptr = (const uint32_t *)c->cblk_off.p + nb;
     ENSURE(c, c->emit_idx, (size_t)n_max * sizeof(uint32_t));
-    ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
+    if (keep_bursts) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
         if (c->pin_packets) (void)hipHostFree(c->pin_packets);
         if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -462,22 +462,17 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     }
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
                                      (uint32_t *)c->emit_idx.p, c->stream, Mp));
-    // the slicer reads the tags back: device memory unless the caller wants them (a read from pinned host
-    // memory is a PCIe round trip inside the kernel)
-    am_tag *tags = c->pin_tags;
-    if (!keep_bursts) {
-        ENSURE(c, c->tags, (size_t)n_max * sizeof(am_tag));
-        tags = (am_tag *)c->tags.p;
-    }
-    HIPCHK(c, am_launch_extract(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
-                                (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
-                                (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(), (float *)c->bursts.p,
-                                tags, c->stream));
+    // extraction + slicing in one launch; the bursts and their tags leave the kernel only for the block-level
+    // caller (am_preamble_work), the accepted packets always land in pinned host memory
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
     c->pin_scalars[2] = 0;
-    HIPCHK(c, am_launch_slice((float *)c->bursts.p, tags, n_ptr, n_max, (uint32_t *)c->crc_pow.p,
-                              c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
+    HIPCHK(c, am_launch_extract_slice(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
+                                      (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
+                                      (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(),
+                                      keep_bursts ? (float *)c->bursts.p : nullptr,
+                                      keep_bursts ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p, c->pin_packets,
+                                      (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan
     const uint32_t seq = ++c->ticket_seq;
     HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream));

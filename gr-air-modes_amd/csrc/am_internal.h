@@ -124,12 +124,15 @@ struct am_time_tag {
     double frac;
 };
 #define AM_MAX_TIME_TAGS 4096
-/* n_ptr: device-side number of hits; n_max: upper bound used for the grid; tt[0..ntt): device array of
- * time tags in ascending offset order */
-hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
-                             const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
-                             uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
-                             uint32_t ntt, float *bursts, am_tag *tags, hipStream_t s);
+/* extraction + slicing of the emitted preambles in one launch.  n_ptr: device-side number of hits; n_max:
+ * upper bound used for the grid; tt[0..ntt): device array of time tags in ascending offset order;
+ * bursts_out / tags_out may be null */
+hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
+                                   const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
+                                   uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
+                                   uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,
+                                   am_packet *packets, const uint32_t *scalars, uint32_t *host_out, hipStream_t s,
+                                   const uint32_t *Mp = nullptr);
 /* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,

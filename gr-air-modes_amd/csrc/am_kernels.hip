@@ -1127,57 +1127,33 @@ hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32
 }
 
 // ------------------------------------------------------------------------------------------
-// Burst extraction + tag (a9): one wave per emitted preamble.
+// Burst extraction + tag (a9): one wave per emitted preamble (am_k_extract_slice, after the slicer below).
 //   out[c] = in[e + c*spc] - inavg[e]          preamble_impl.cc:219-221
 //   timestamp from the absolute item count     preamble_impl.cc:100-137, relative to the rx_time
 //   tag in force at that item (tt[0..ntt) ascending; none: offset 0, time 0 = a file source)
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-am_k_extract(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
-             const uint32_t *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ pos,
-             const uint32_t *__restrict__ eo, uint64_t base_abs, long long e_off, uint64_t rate,
-             const am_time_tag *__restrict__ tt, uint32_t ntt, float *__restrict__ bursts, am_tag *__restrict__ tags)
+// the "preamble_found" tag of item count `sample` (= stream index + history - 1, as the preamble block
+// numbers its items): time stamp relative to the rx_time tag in force    preamble_impl.cc:100-137
+__device__ __forceinline__ am_tag am_make_tag(uint64_t sample, uint64_t rate, const am_time_tag *__restrict__ tt,
+                                          uint32_t ntt)
 {
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
-    if (i >= *n_ptr) return;                              // device-side hit count (no host round trip)
-    const uint32_t g = emit_idx[i];
-    const uint32_t e = eo[g];
-    const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
-    const float av = inavg[g];                              // reference level at the shifted start
-    for (int c = lane; c < AM_BURST; c += AM_WAVE)
-        bursts[(size_t)i * AM_BURST + c] = bb[ei + (size_t)(c * spc)] - av;
-    if (lane == 0) {
-        am_tag t;
-        // item count as the preamble block numbers it: stream index + (history - 1)
-        t.sample = base_abs + e + (uint64_t)(2 * spc - 1);
-        uint64_t off = 0, whole = 0;                                // :103-108 no tag yet
-        double fr = 0.0;
-        uint32_t lo = 0, hi = ntt;                                  // last tag with offset <= sample
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (tt[mid].offset <= t.sample) lo = mid + 1; else hi = mid;
-        }
-        if (lo) { off = tt[lo - 1].offset; whole = tt[lo - 1].secs; fr = tt[lo - 1].frac; }   // :110-111
-        const uint64_t d = t.sample - off;
-        t.secs = whole + d / rate;                                  // :124,127
-        t.frac = fr + (double)(d % rate) / (double)rate;            // :125,128
-        if (t.frac > 1.0f) { t.frac -= 1.0f; t.secs += 1; }         // :129-132
-        t.inavg = av;
-        t.how_late = e - pos[g];
-        tags[i] = t;
+    am_tag t;
+    t.sample = sample;
+    uint64_t off = 0, whole = 0;                                // :103-108 no tag yet
+    double fr = 0.0;
+    uint32_t lo = 0, hi = ntt;                                  // last tag with offset <= sample
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tt[mid].offset <= t.sample) lo = mid + 1; else hi = mid;
     }
-}
-
-hipError_t am_launch_extract(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
-                             const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
-                             uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
-                             uint32_t ntt, float *bursts, am_tag *tags, hipStream_t s)
-{
-    if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_extract, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_ptr,
-                       pos, e, base_abs, e_off, rate, tt, ntt, bursts, tags);
-    return hipGetLastError();
+    if (lo) { off = tt[lo - 1].offset; whole = tt[lo - 1].secs; fr = tt[lo - 1].frac; }   // :110-111
+    const uint64_t d = t.sample - off;
+    t.secs = whole + d / rate;                                  // :124,127
+    t.frac = fr + (double)(d % rate) / (double)rate;            // :125,128
+    if (t.frac > 1.0f) { t.frac -= 1.0f; t.secs += 1; }         // :129-132
+    t.inavg = 0.0f;
+    t.how_late = 0;
+    return t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1210,21 +1186,10 @@ __device__ __forceinline__ uint32_t am_bitrev8(uint32_t v)
     return v;
 }
 
-__global__ void __launch_bounds__(256)
-am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, const uint32_t *__restrict__ n_ptr,
-           const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets,
-           const uint32_t *__restrict__ scalars, uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
+// one wave slices burst b (240 soft chips, global memory or LDS); lane 0 files the packet under index i
+__device__ __forceinline__ void am_slice_wave(const float *b, const am_tag &t, uint32_t i, int lane,
+                                              const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets)
 {
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
-    // hit count and scan resume position go straight to pinned host memory (no extra copies)
-    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) {
-        host_out[0] = *n_ptr;
-        host_out[1] = scalars[0];
-        host_out[2] = Mp ? *Mp : 0u;                          // actual candidate count (speculative launches)
-    }
-    if (i >= *n_ptr) return;                              // wave-uniform; device-side burst count
-    const float *b = bursts + (size_t)i * AM_BURST;
     float s = b[0] + b[2];                                // slicer_impl.cc:128-131
     s = s + b[7];
     s = s + b[9];
@@ -1277,12 +1242,82 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
             packets[i].reserved[0] = 0;
             return;
         }
-        const am_tag t = tags[i];
         p.sample = t.sample;
         p.secs = t.secs;
         p.frac = t.frac;
         packets[i] = p;
     }
+}
+
+__global__ void __launch_bounds__(256)
+am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, const uint32_t *__restrict__ n_ptr,
+           const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets,
+           const uint32_t *__restrict__ scalars, uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
+{
+    const int lane = threadIdx.x & (AM_WAVE - 1);
+    const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + threadIdx.x / AM_WAVE;
+    // hit count and scan resume position go straight to pinned host memory (no extra copies)
+    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        host_out[0] = *n_ptr;
+        host_out[1] = scalars[0];
+        host_out[2] = Mp ? *Mp : 0u;                          // actual candidate count (speculative launches)
+    }
+    if (i >= *n_ptr) return;                              // wave-uniform; device-side burst count
+    const am_tag t = tags[i];                             // (lane 0 uses it)
+    am_slice_wave(bursts + (size_t)i * AM_BURST, t, i, lane, crc_pow, packets);
+}
+
+// Extraction and slicing in one launch (the scan paths: every extracted burst is sliced right away).  One
+// wave per hit: the 240 soft chips go through LDS instead of a bursts[] round trip through memory; bursts_out
+// and tags_out are written only when the caller wants them (block-level API), packets as am_k_slice does.
+__global__ void __launch_bounds__(256)
+am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
+                   const uint32_t *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr,
+                   const uint32_t *__restrict__ pos, const uint32_t *__restrict__ eo, uint64_t base_abs,
+                   long long e_off, uint64_t rate, const am_time_tag *__restrict__ tt, uint32_t ntt,
+                   float *__restrict__ bursts_out, am_tag *__restrict__ tags_out,
+                   const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets,
+                   const uint32_t *__restrict__ scalars, uint32_t *__restrict__ host_out,
+                   const uint32_t *__restrict__ Mp)
+{
+    __shared__ float sb[256 / AM_WAVE][AM_BURST];
+    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
+    const uint32_t i = blockIdx.x * (blockDim.x / AM_WAVE) + wv;
+    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        host_out[0] = *n_ptr;
+        host_out[1] = scalars[0];
+        host_out[2] = Mp ? *Mp : 0u;                          // actual candidate count (speculative launches)
+    }
+    if (i >= *n_ptr) return;                              // wave-uniform; device-side hit count
+    const uint32_t g = emit_idx[i];
+    const uint32_t e = eo[g];
+    const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
+    const float av = inavg[g];                              // reference level at the shifted start
+    for (int c = lane; c < AM_BURST; c += AM_WAVE) {
+        const float v = bb[ei + (size_t)(c * spc)] - av;    // preamble_impl.cc:219-221
+        sb[wv][c] = v;
+        if (bursts_out) bursts_out[(size_t)i * AM_BURST + c] = v;
+    }
+    am_tag t = am_make_tag(base_abs + e + (uint64_t)(2 * spc - 1), rate, tt, ntt);
+    t.inavg = av;
+    t.how_late = e - pos[g];
+    if (tags_out && lane == 0) tags_out[i] = t;
+    __builtin_amdgcn_wave_barrier();                       // the wave's own LDS writes, in order, before its reads
+    am_slice_wave(sb[wv], t, i, lane, crc_pow, packets);
+}
+
+hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
+                                   const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
+                                   uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
+                                   uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,
+                                   am_packet *packets, const uint32_t *scalars, uint32_t *host_out, hipStream_t s,
+                                   const uint32_t *Mp)
+{
+    if (n_max == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_extract_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_ptr,
+                       pos, e, base_abs, e_off, rate, tt, ntt, bursts_out, tags_out, crc_pow, packets, scalars,
+                       host_out, Mp);
+    return hipGetLastError();
 }
 
 // Completion ticket: the last launch of a scan.  The host polls the pinned word instead of asking the
