@@ -992,10 +992,17 @@ static am_chain_layout am_chain_layout_of(uint32_t M)
 }
 size_t am_chain_scratch_bytes(uint32_t M) { return am_chain_layout_of(M).words * sizeof(uint32_t); }
 
-static hipError_t am_chain_walk_lds(const void *kernel)
+// the walk kernels may need more than the default 64 KB of dynamic LDS: raised once per device and kernel
+// (`done` is the caller's per-kernel table; a process may hold contexts on several devices)
+static hipError_t am_chain_walk_lds(const void *kernel, bool (&done)[64])
 {
-    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)((AM_CB_HEADCAP + 1) * sizeof(uint32_t)));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((AM_CB_HEADCAP + 1) * sizeof(uint32_t)));
+    if (rc == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+    return rc;
 }
 
 // step 1 (independent of where the scan starts): successor array + per-block exits
@@ -1019,12 +1026,9 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_walk));
-        if (rc != hipSuccess) return rc;
-        attr_set = true;
-    }
+    static bool attr_set[64] = {};
+    if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_walk), attr_set); rc != hipSuccess)
+        return rc;
     const size_t lds = ((size_t)L.nblk * L.headw + L.nblk + 2) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, scratch + L.off_head, M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp);
@@ -1045,12 +1049,10 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 {
     if (n == 0 || M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_exit_table));
-        if (rc != hipSuccess) return rc;
-        attr_set = true;
-    }
+    static bool attr_set[64] = {};
+    if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_exit_table), attr_set);
+        rc != hipSuccess)
+        return rc;
     const size_t lds = ((size_t)L.nblk * L.headw + 2) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
                        scratch + L.off_head, M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
