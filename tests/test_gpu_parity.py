@@ -214,14 +214,14 @@ def test_rx_time_tags(lib, rate, n):
 
 
 def test_chain_walk_beyond_64k_of_lds(lib):
-    """More than 2^19 first-stage candidates in ONE scan (low threshold, dense traffic): the block-to-block
-    walk of the greedy chain then keeps more than 64 KB of head links in LDS, i.e. it depends on the raised
-    dynamic-LDS limit of its kernel."""
-    rate, n, thr = 8e6, 24000000, 2.0
+    """Between 256 and 288 blocks of 2048 first-stage candidates in ONE scan (low threshold, dense traffic):
+    the block-to-block walk of the greedy chain then keeps 128 head links per block = more than 64 KB in LDS,
+    i.e. it depends on the raised dynamic-LDS limit of its kernel (beyond 288 blocks the heads get shorter)."""
+    rate, n, thr = 8e6, 22000000, 2.0
     iq, _ = synth.synth_capture(rate, n, 40000.0, seed=123)
     ctx = _capi.Context(rate, thr, True, lib=lib)
     pk = ctx.process_iq(iq, flush=True)
-    assert ctx.last_num_candidates() > 540000, ctx.last_num_candidates()
+    assert 256 * 2048 < ctx.last_num_candidates() <= 288 * 2048, ctx.last_num_candidates()
     want = oracle.demod(iq, rate, thr, True)
     assert np.array_equal(pk, want) and len(want) > 2000
     pc.check_sharded(lib, rate, iq, 2, thr=thr, want=want)
