@@ -105,3 +105,40 @@ def test_rx_path_surface_via_emulation(emu_lib):
     sl = air_modes.slicer(q2, lib=emu_lib)
     pk = sl.work(bursts, tags)
     assert q2.count() == len(pk) == len(got)
+
+
+def test_rx_time_through_the_host_mirror(emu_lib):
+    """rx_path.work(..., rx_time=[(offset, secs, frac)]) and preamble.work(..., rx_time=...): what a live
+    source's "rx_time" stream tags do to the message timestamps (lib/preamble_impl.cc:100-137,165-170)."""
+    import air_modes
+    import oracle
+    import synth
+    rate = 4e6
+    iq, _ = synth.synth_capture(rate, 160000, 2500.0, seed=14)
+    rx_tags = [(0, 1700000000, 0.5), (90000, 1700000123, 0.25)]
+    q = air_modes.msg_queue()
+    rx = air_modes.rx_path(rate, 7.0, q, use_pmf=True, lib=emu_lib)
+    rx.work(iq[:50000], rx_time=rx_tags[:1])
+    rx.work(iq[50000:120000], rx_time=rx_tags[1:])
+    rx.work(iq[120000:], flush=True)
+    got = []
+    while not q.empty_p():
+        got.append(q.delete_head().to_string())
+    want = oracle.format_messages(oracle.demod(iq, rate, rx_time=rx_tags))
+    assert got == want and len(got) > 5
+    assert {m.split()[3] for m in got} >= {"1700000000", "1700000123"}
+    # a second stream through the same object starts without tags again (flush ended the first one)
+    rx.work(iq, flush=True)
+    again = []
+    while not q.empty_p():
+        again.append(q.delete_head().to_string())
+    plain = oracle.format_messages(oracle.demod(iq, rate), first=False)
+    assert again == plain
+    # block level
+    pre = air_modes.preamble(rate, 7.0, lib=emu_lib)
+    bb, avg = oracle.frontend(iq, 2, True)
+    _, tags = pre.work(bb, avg, rx_time=rx_tags)
+    _, otags = oracle.preamble_scan(bb, avg, 2, 7.0, rate, rx_time=rx_tags)
+    assert np.array_equal(tags, otags)
+    _, tags0 = pre.work(bb, avg)
+    assert np.array_equal(tags0, oracle.preamble_scan(bb, avg, 2, 7.0, rate)[1])
