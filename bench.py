@@ -109,7 +109,7 @@ def main():
                     results[w] = c.process_iq_device(d_iq.data_ptr(), n, flush=True)
                 else:
                     results[w] = step()
-                fe[w].append(c.last_timing()[1])
+                fe[w].append(c.last_dom_ms())
         if inflight == 1:
             worker(0)
         else:

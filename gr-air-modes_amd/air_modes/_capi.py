@@ -194,9 +194,16 @@ class Context(object):
         return int(self.lib.L.am_last_num_candidates(self._h))
 
     def last_timing(self):
+        """(whole call, dominant kernel) device milliseconds of the last call."""
         a, b = C.c_float(0), C.c_float(0)
         self._chk(self.lib.L.am_last_timing(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_dom_ms(self):
+        """Dominant-kernel milliseconds only (never waits for the call's trailing event)."""
+        b = C.c_float(0)
+        self._chk(self.lib.L.am_last_timing(self._h, None, C.byref(b)))
+        return b.value
 
     def _fetch(self, need):
         out = np.zeros(need, PACKET_DTYPE)

@@ -67,6 +67,12 @@ struct am_ctx {
     unsigned ht_n = 0;
     uint32_t ticket_seq = 0;      // completion tickets (wait_for_ticket)
     bool dom_timed = false;       // ev[3] / ev[1] bracket the dominant kernel of this call
+    // Every event record is a packet the in-order queue executes (a few microseconds each, measured in the
+    // kernel trace).  ev[0] opens a call, ev[3] / ev[1] bracket the dominant kernel (ev[3] directly in front
+    // of it: sharing ev[0] saved a packet but put the host's launch preparation into the kernel's time);
+    // ev[2], the end of the device work, goes AFTER the completion ticket, i.e. off the path the host
+    // waits on, and the whole-call time is formed on request (am_last_timing).
+    bool total_pending = false;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
     char err[256] = "";
@@ -473,9 +479,10 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                       keep_bursts ? (float *)c->bursts.p : nullptr,
                                       keep_bursts ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p, c->pin_packets,
                                       (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan
     const uint32_t seq = ++c->ticket_seq;
     HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan (behind the ticket)
+    c->total_pending = true;
     const double TS = am_now_us();
     HIPCHK(c, wait_for_ticket(c, seq));
     c->ht[5] += am_now_us() - TS;
@@ -717,6 +724,7 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     const uint64_t LH = L + S;
     if (c->carry_n + n > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "chunk larger than 2^31 samples");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    c->total_pending = false;
     c->dom_timed = false;
     c->tail_synced = false;
 
@@ -829,9 +837,12 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         // buffer must not be reused by the caller before the device is done with it
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->total_pending = false;
     }
     const double T5 = am_now_us();
-    (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
+    // (after a scan ev[2] sits behind the completion ticket and may still be in flight: am_last_timing waits
+    // for it when somebody asks for the whole-call time)
+    if (!c->total_pending) (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
     c->last_dom_ms = 0.0f;
     if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
     const int hrc = hand_out(c, out, cap, n_out);
@@ -1015,6 +1026,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     if (nsrc > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "chunk larger than 2^31 samples");
     if (nsrc && !iq) return fail(c, AM_EINVAL, "null iq");
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    c->total_pending = false;
     c->dom_timed = false;
     const float *src = iq;
     if (!(flags & AM_F_DEVICE_IN) && nsrc) {
@@ -1081,6 +1093,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         if (Mp) HIPCHK(c, hipMemcpyAsync(&actual, Mp, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->total_pending = false;
         if (!Mp || actual <= M) { c->last_M = actual; break; }
         // more candidates than the capacity this scan was launched for: once more with the exact count
         if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: shard capacity %u < %u candidates, scan redone\n", M, actual);
@@ -1147,10 +1160,19 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
 
 const char *am_last_error(const am_ctx *c) { return c ? c->err : g_create_err; }
 
-int am_last_timing(const am_ctx *c, float *total_ms, float *dom_ms)
+int am_last_timing(am_ctx *c, float *total_ms, float *dom_ms)
 {
     if (!c) return AM_EINVAL;
-    if (total_ms) *total_ms = c->last_total_ms;
+    if (total_ms) {
+        if (c->total_pending) {
+            // the end-of-work event of the last scan was queued behind its completion ticket
+            (void)hipSetDevice(c->device);
+            if (hipEventSynchronize(c->ev[2]) == hipSuccess)
+                (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
+            c->total_pending = false;
+        }
+        *total_ms = c->last_total_ms;
+    }
     if (dom_ms) *dom_ms = c->last_dom_ms;
     return AM_OK;
 }

@@ -207,8 +207,10 @@ const char *am_last_error(const am_ctx *ctx);
 
 /* timing of the last am_process_iq / am_shard_scan call, measured with HIP events on the
  * context's own stream: device milliseconds for the whole call and for the dominant
- * (front-end + detection) kernel.  Used by bench.py for the roofline line. */
-int am_last_timing(const am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
+ * (front-end + detection) kernel.  Used by bench.py for the roofline line.  Either pointer may be
+ * NULL; asking for total_ms may wait a few microseconds for the call's last event (it is queued
+ * behind the completion signal the call itself waits for), dominant_kernel_ms never waits. */
+int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
 
 /* Diagnostic: number of first-stage preamble candidates (positions passing preamble_impl.cc:172-179)
  * the last scan refined and chained.  Negative error code on a null context. */
