@@ -142,3 +142,17 @@ def test_rx_time_through_the_host_mirror(emu_lib):
     assert np.array_equal(tags, otags)
     _, tags0 = pre.work(bb, avg)
     assert np.array_equal(tags0, oracle.preamble_scan(bb, avg, 2, 7.0, rate)[1])
+
+
+def test_timing_accessors(emu_lib):
+    """am_last_timing with either pointer NULL (bench.py reads the dominant-kernel time only: that never
+    waits for the call's trailing event)."""
+    import synth
+    from air_modes import _capi
+    ctx = _capi.Context(4e6, 7.0, True, lib=emu_lib)
+    iq, _ = synth.synth_capture(4e6, 60000, 2500.0, seed=15)
+    ctx.process_iq(iq, flush=True)
+    assert ctx.last_dom_ms() >= 0.0
+    total, dom = ctx.last_timing()
+    assert total >= 0.0 and dom >= 0.0
+    ctx.close()
