@@ -93,7 +93,7 @@ struct am_ctx {
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
-        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, exit_tab, cscratch, dc_m1, dc_y;
+        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y;
 
     // results of the last scan
     std::vector<am_packet> h_packets;   // am_slicer_work: every sliced burst, reserved[0] = accepted
@@ -101,7 +101,6 @@ struct am_ctx {
     uint32_t n_hits = 0;                // preamble hits of the last scan
     std::vector<float> h_bursts;
     std::vector<am_packet> pending;     // accepted packets not yet handed to the caller
-    std::vector<am_shard_exit> h_exit;  // exit table of the resident chunk
     uint64_t last_tags = 0;
     uint32_t last_M = 0;
     uint32_t chain_M = 0;               // records (or capacity) chain_prepare ran for
@@ -116,6 +115,8 @@ struct am_ctx {
     am_tag *pin_tags = nullptr;
     uint32_t *pin_scalars = nullptr;
     uint32_t pin_cap = 0;
+    am_shard_exit *pin_exit = nullptr;  // exit table of a time chunk, written by its kernel directly
+    uint32_t pin_exit_cap = 0;
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_total_ms = 0.0f, last_dom_ms = 0.0f;
@@ -642,11 +643,12 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->exit_tab, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};
+                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
     if (c->pin_scalars) (void)hipHostFree(c->pin_scalars);
+    if (c->pin_exit) (void)hipHostFree(c->pin_exit);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1080,20 +1082,32 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         if (rc != AM_OK) return rc;
         n_dev = (uint32_t)std::min<uint64_t>(M, lead + 1);
         uint32_t actual = M;
+        if (!c->pin_scalars) {
+            HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
+            memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));
+        }
         if (n_dev) {
-            ENSURE(c, c->exit_tab, (size_t)n_dev * sizeof(am_shard_exit));
+            // the table goes straight to pinned host memory; the host then reads it up to its last entry
+            if (c->pin_exit_cap < n_dev) {
+                if (c->pin_exit) (void)hipHostFree(c->pin_exit);
+                c->pin_exit = nullptr; c->pin_exit_cap = 0;
+                HIPCHK(c, hipHostMalloc((void **)&c->pin_exit, ((size_t)n_dev + 64) * sizeof(am_shard_exit),
+                                        hipHostMallocDefault));
+                c->pin_exit_cap = n_dev + 64;
+            }
             HIPCHK(c, am_launch_chain_exit_table((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, n_dev,
                                                  (uint32_t)std::min<uint64_t>(lead_end - out_abs0, 0xFFFFFFFFull),
-                                                 (uint32_t *)c->cscratch.p, out_abs0, (am_shard_exit *)c->exit_tab.p,
-                                                 c->stream, Mp));
-            c->h_exit.resize(n_dev);
-            HIPCHK(c, hipMemcpyAsync(c->h_exit.data(), c->exit_tab.p, (size_t)n_dev * sizeof(am_shard_exit),
-                                     hipMemcpyDeviceToHost, c->stream));
+                                                 (uint32_t *)c->cscratch.p, out_abs0, c->pin_exit, c->stream, Mp));
         }
-        if (Mp) HIPCHK(c, hipMemcpyAsync(&actual, Mp, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        // one completion ticket (with the device-side candidate count of a capacity launch) instead of
+        // copies through the runtime and a stream synchronisation
+        c->pin_scalars[3] = M;
+        const uint32_t seq = ++c->ticket_seq;
+        HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, Mp, c->pin_scalars + 3));
         HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->total_pending = false;
+        c->total_pending = true;
+        HIPCHK(c, wait_for_ticket(c, seq));
+        actual = c->pin_scalars[3];
         if (!Mp || actual <= M) { c->last_M = actual; break; }
         // more candidates than the capacity this scan was launched for: once more with the exact count
         if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: shard capacity %u < %u candidates, scan redone\n", M, actual);
@@ -1101,20 +1115,19 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         if (rc != AM_OK) return rc;
     }
     c->spec_density = (P1 > P0) ? (double)c->last_M / (double)(P1 - P0) : 0.0;
-    (void)hipEventElapsedTime(&c->last_total_ms, c->ev[0], c->ev[2]);
     c->last_dom_ms = 0.0f;
     if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
     uint64_t nt = 0;
     for (uint32_t i = 0; i < n_dev; i++) {
         nt = i + 1;
-        if (c->h_exit[i].pos >= lead_end) break;                // first candidate past the lead-in: last entry
+        if (c->pin_exit[i].pos >= lead_end) break;              // first candidate past the lead-in: last entry
     }
     c->shard_ready = true;
     if (n_table) *n_table = nt;
     if (nt > cap) return fail(c, AM_ECAPACITY, "exit table too small");
     if (nt) {
         if (!table) return fail(c, AM_EINVAL, "null table");
-        memcpy(table, c->h_exit.data(), (size_t)nt * sizeof(am_shard_exit));
+        memcpy(table, c->pin_exit, (size_t)nt * sizeof(am_shard_exit));
     }
     return AM_OK;
 }

@@ -55,7 +55,8 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
                           uint8_t *valid, hipStream_t s, const uint32_t *Mp = nullptr);
-hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s);
+hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s, const uint32_t *count_src = nullptr,
+                            uint32_t *count_dst = nullptr);
 
 /* ---- optional DC blocker in front of the path (am_dcblock.hip) ---------------------------- */
 #define AM_DC_CHIPS 100              /* rx_path.py:40  dc_blocker_cc(100*spc, False) */

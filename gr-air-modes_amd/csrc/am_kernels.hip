@@ -849,15 +849,18 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         am_shard_exit t;
         if (i >= M) {                                        // (capacity launch) end marker: "no candidate here"
-            t.pos = ~(uint64_t)0;
-            t.exit = 0;
-            table[i] = t;
+            if (i == M) {                                    // (the reader stops at the first one)
+                t.pos = ~(uint64_t)0;
+                t.exit = 0;
+                table[i] = t;
+            }
             continue;
         }
+        // the table ends with the first candidate at or past lead_end: later entries are never read
+        if (i != 0 && pos[i - 1u] >= lead_end) continue;
         t.pos = base_abs + pos[i];
         t.exit = 0;
-        // the table ends with the first candidate at or past lead_end: later entries are never read
-        if (i == 0 || pos[i - 1u] < lead_end) {
+        {
             uint32_t g = i, ent = i;                         // ent: entry node of the last block the orbit touches
             while (g < M) {
                 ent = g;
@@ -1324,13 +1327,16 @@ hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc,
 
 // Completion ticket: the last launch of a scan.  The host polls the pinned word instead of asking the
 // runtime (whose completion path costs tens of microseconds per scan).
-__global__ void am_k_ticket(uint32_t *host_word, uint32_t seq)
+// (count_src / count_dst: a device-side count to hand to the host along with the ticket, or null)
+__global__ void am_k_ticket(uint32_t *host_word, uint32_t seq, const uint32_t *count_src, uint32_t *count_dst)
 {
+    if (count_src) *count_dst = *count_src;
     __hip_atomic_store(host_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s)
+hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s, const uint32_t *count_src,
+                            uint32_t *count_dst)
 {
-    hipLaunchKernelGGL(am_k_ticket, dim3(1), dim3(1), 0, s, host_word, seq);
+    hipLaunchKernelGGL(am_k_ticket, dim3(1), dim3(1), 0, s, host_word, seq, count_src, count_dst);
     return hipGetLastError();
 }
 
