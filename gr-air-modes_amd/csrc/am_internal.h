@@ -107,12 +107,10 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
                                  uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp = nullptr);
-unsigned am_chain_block(void);      /* candidates per blk_cnt[] entry (== AM_DET_PER_BLOCK) */
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
                                       hipStream_t s, const uint32_t *Mp = nullptr);
-hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s);
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
                                   uint32_t *out_idx, hipStream_t s, const uint32_t *Mp = nullptr);
 

@@ -1043,7 +1043,6 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     return hipGetLastError();
 }
 static_assert(AM_CB == AM_DET_PER_BLOCK, "blk_cnt[] of the chain and the flag compaction use the same blocks");
-unsigned am_chain_block(void) { return AM_CB; }
 
 // exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
@@ -1063,30 +1062,8 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Ordered compaction of a byte-flag array: per-block counts -> scan -> scatter.
+// Ordered compaction of a byte-flag array: per-block counts (am_k_cblk_mark) -> scan -> scatter.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(AM_DET_THREADS)
-am_k_flag_count(const uint8_t *__restrict__ flags, uint32_t M, uint32_t *__restrict__ blk_cnt)
-{
-    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    const int w = threadIdx.x / AM_WAVE;
-    const uint32_t base = blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
-    uint32_t cnt = 0;
-    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
-        const uint32_t g = base + it * AM_WAVE + lane;
-        const bool c = g < M && flags[g] != 0;
-        cnt += (uint32_t)__popcll(__ballot(c));
-    }
-    if (lane == 0) wc[w] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int k = 0; k < AM_DET_THREADS / AM_WAVE; ++k) t += wc[k];
-        blk_cnt[blockIdx.x] = t;
-    }
-}
-
 __global__ void __launch_bounds__(AM_DET_THREADS)
 am_k_flag_scatter(const uint8_t *__restrict__ flags, uint32_t Mcap, const uint32_t *__restrict__ blk_off,
                   uint32_t *__restrict__ out_idx, const uint32_t *__restrict__ Mp)
@@ -1115,13 +1092,6 @@ am_k_flag_scatter(const uint8_t *__restrict__ flags, uint32_t Mcap, const uint32
     }
 }
 
-hipError_t am_launch_flag_count(const uint8_t *flags, uint32_t M, uint32_t *blk_cnt, hipStream_t s)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_flag_count, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, flags, M,
-                       blk_cnt);
-    return hipGetLastError();
-}
 hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
                                   uint32_t *out_idx, hipStream_t s, const uint32_t *Mp)
 {
