@@ -13,7 +13,8 @@ samples into the next chunk.  Per step:
                      chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan
                      could enter the chunk at (those in its first 241*spc samples), where the
                      scan would leave the chunk;
-  3. table exchange  one all_gather of the fixed-size exit tables (16 bytes per entry, KBs);
+  3. table exchange  one all_gather of fixed-size exit tables (16 bytes per entry; a short message of 512
+                     entries, and the full 241*spc-entry one only if some rank's table does not fit);
                      every rank composes them (am_shard_entry) -> scan entry of its own chunk;
   4. resolve         am_shard_resolve(entry): mark the chain from that entry, extract + slice.
 
@@ -32,7 +33,7 @@ class ShardedReceiver(object):
     """`chunk` is this rank's 2*n float32 I,Q samples (a view into the halo'd device buffer:
     write the samples there once, no per-step copy); step() runs one pass."""
 
-    def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None):
+    def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None, small_table=512):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -45,6 +46,10 @@ class ShardedReceiver(object):
         self.a0, self.a1 = self.rank * self.n, (self.rank + 1) * self.n
         spc = max(int(ctx.get_rate() / 2e6), 1)
         self.tab_cap = 241 * spc + 4                      # a lead-in cannot hold more candidates than positions
+        # the tables are exchanged in a short fixed-size message; only when some rank's table does not fit
+        # (every rank sees every count) the full-size message follows
+        self.small_cap = max(1, min(int(small_table), self.tab_cap))
+        self.full_exchanges = 0                           # steps that needed the full-size message
         self._alloc(device if device is not None else "cpu")
         self.chunk = self._buf[self.left * 2:(self.left + self.n) * 2]
 
@@ -54,10 +59,22 @@ class ShardedReceiver(object):
         self._buf = t.zeros((hl + n + hr) * 2, dtype=t.float32, device=dev)
         self._slab = t.empty((hl + hr) * 2, dtype=t.float32, device=dev)
         self._slabs = [t.empty_like(self._slab) for _ in range(self.world)]
-        # exit table message: [count, pos0, exit0, pos1, exit1, ...] as int64
+        # exit table message: [count, pos0, exit0, pos1, exit1, ...] as int64, in two sizes
         self._msg = t.zeros(1 + 2 * self.tab_cap, dtype=t.int64, device=dev)
         self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
+        self._msg_s = t.zeros(1 + 2 * self.small_cap, dtype=t.int64, device=dev)
+        self._msgs_s = [t.empty_like(self._msg_s) for _ in range(self.world)]
         self._host_tab = np.zeros(self.tab_cap, _capi.EXIT_DTYPE)
+
+    def _exchange(self, m, cap, msg_dev, msgs_dev):
+        """all_gather of [count | first min(count, cap) table entries]; returns the gathered rows (host)."""
+        k = min(m, cap)
+        msg = np.zeros(1 + 2 * cap, np.int64)
+        msg[0] = m
+        msg[1:1 + 2 * k] = self._host_tab[:k].view(np.int64)
+        msg_dev.copy_(self.torch.from_numpy(msg))
+        self.dist.all_gather(msgs_dev, msg_dev, group=self.group)
+        return self.torch.stack(msgs_dev).cpu().numpy()
 
     def step(self):
         """One pass over the samples currently in `chunk`.  Returns this rank's accepted packets."""
@@ -86,12 +103,10 @@ class ShardedReceiver(object):
         self.ctx._chk(rc)
         m = int(got.value)
         if world > 1:
-            msg = np.zeros(1 + 2 * self.tab_cap, np.int64)
-            msg[0] = m
-            msg[1:1 + 2 * m] = self._host_tab[:m].view(np.int64)
-            self._msg.copy_(t.from_numpy(msg))
-            dist.all_gather(self._msgs, self._msg, group=self.group)
-            allm = t.stack(self._msgs).cpu().numpy()
+            allm = self._exchange(m, self.small_cap, self._msg_s, self._msgs_s)
+            if int(allm[:, 0].max()) > self.small_cap:       # the same decision on every rank
+                self.full_exchanges += 1
+                allm = self._exchange(m, self.tab_cap, self._msg, self._msgs)
             tables = [allm[r, 1:1 + 2 * int(allm[r, 0])].copy().view(_capi.EXIT_DTYPE) for r in range(world)]
             entry = _capi.shard_entries(self.ctx.lib, tables, [r * n for r in range(world)])
             cur_in = int(entry[rank])
