@@ -37,6 +37,9 @@
 #ifndef FE2_WPS
 #define FE2_WPS 3                          /* launch bound: waves per SIMD */
 #endif
+#ifndef FE2_NO_PREFIX_CSE
+#define FE2_NO_PREFIX_CSE 0                 /* 1: P5 recomputes the in-chip prefix sums (register diet, see P5) */
+#endif
 #define FE2_RH_CHIPS 9                       /* the first-stage test looks 9 chips (+ 1 sample) ahead */
 #define FE2_LH_CHIPS (AM_CHIPS_AVG + 1)      /* 48-chip block + one chip                 */
 #define FE2_HALO_THREADS (AM_CHIPS_AVG + FE2_RH_CHIPS)
@@ -474,6 +477,14 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T, EDGE>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
 
     // ---- P5: reference level (a4) + first-stage preamble test (a6) ------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && FE2_NO_PREFIX_CSE
+    // The in-chip prefix sums below repeat the left-to-right chain of the chip totals (P3).  Left alone,
+    // the compiler keeps all R partial sums of that chain alive across three barriers (168 VGPRs at
+    // 64 Msps; 72 spilled registers when the build is limited to 128) to save R additions here; making
+    // the values opaque ends those live ranges (143 VGPRs; 6 spilled dwords at 128).
+#pragma unroll
+    for (int i = 0; i < R; ++i) asm volatile("" : "+v"(bbv[i]));
+#endif
     float avgv[R];
     if (a.ablate & 2u) {
 #pragma unroll
