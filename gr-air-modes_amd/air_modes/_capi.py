@@ -102,6 +102,8 @@ class Library(object):
         L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
         L.am_last_num_candidates.restype = C.c_longlong
         L.am_last_num_candidates.argtypes = [vp]
+        L.am_last_frontend.restype = C.c_int
+        L.am_last_frontend.argtypes = [vp]
         self.L = L
         if L.am_abi_version() != 1:
             raise OSError("ABI version mismatch in %s" % path)
@@ -192,6 +194,10 @@ class Context(object):
 
     def last_num_candidates(self):
         return int(self.lib.L.am_last_num_candidates(self._h))
+
+    def last_frontend(self):
+        """3 = streaming kernel, 2 = tile kernel, 1 = rate-generic kernels, 0 = no scan yet (diagnostic)."""
+        return int(self.lib.L.am_last_frontend(self._h))
 
     def last_timing(self):
         """(whole call, dominant kernel) device milliseconds of the last call."""

@@ -75,6 +75,13 @@ struct am_ctx {
     bool total_pending = false;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
+    bool allow_fe3 = true;        // AIRMODES_FE=2 keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
+    // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
+    // extraction recomputes from these samples (they must stay valid until the scan's hits are sliced)
+    bool bb_sparse = false;
+    int last_fe = 0;              // which front end the last scan ran (am_last_frontend)
+    const float *scan_src = nullptr;
+    uint64_t scan_src_abs0 = 0, scan_src_abs1 = 0;
     char err[256] = "";
 
     // "rx_time" stream tags still able to stamp a future preamble, ascending offsets (am_set_rx_time);
@@ -92,7 +99,7 @@ struct am_ctx {
 
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
-        emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy,
+        emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y;
 
     // results of the last scan
@@ -295,7 +302,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
     c->ref_endj = end_j;
     uint32_t M = 0;
     const uint32_t *Mp = nullptr;
-    if (spec_cap && mode == 2) {
+    if (spec_cap && mode >= 2) {
         M = spec_cap;                                        // capacity; the kernels clip to *Mp
         Mp = (const uint32_t *)c->blk_off.p + nseg;
         c->spec_now = true;
@@ -311,7 +318,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
         ENSURE(c, c->valid, (size_t)M + 1);
-        if (mode == 2) {
+        if (mode >= 2) {
             // split refinement: positions -> energies once per reachable position -> per-candidate test
             const uint32_t nb = (M + 2047u) / 2048u;
             const uint64_t ebound = std::min<uint64_t>((uint64_t)M * (uint64_t)(c->spc + 1), (uint64_t)M + 0xFFFFFFFFull);
@@ -320,8 +327,12 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             ENSURE(c, c->blk_tot2, ((size_t)nb + 1) * sizeof(uint32_t));
             ENSURE(c, c->blk_base2, ((size_t)nb + 2) * sizeof(uint32_t));
             ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
-            HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
-                                           c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
+            if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
+                HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_off.p, nseg, M, c->spc,
+                                                am_fe3_lag(), (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
+            else
+                HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
+                                               c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             HIPCHK(c, am_launch_exscan_blocks((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
                                               (uint32_t *)c->blk_tot2.p, M, c->stream, Mp));
             HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_tot2.p, (uint32_t *)c->blk_base2.p, nb, c->stream));
@@ -346,6 +357,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
 int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, uint32_t j1, uint32_t *M_out)
 {
     *M_out = 0;
+    c->bb_sparse = false;
     if (j1 <= j0) return AM_OK;
     const uint32_t nblk = (uint32_t)(((uint64_t)(j1 - j0) + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
     ENSURE(c, c->cand_seg, (size_t)nblk * AM_DET_PER_BLOCK * sizeof(uint32_t));
@@ -365,14 +377,43 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     *M_out = 0;
     c->spec_now = false;
     c->Mdev = nullptr;
+    c->bb_sparse = false;
     const unsigned T2 = c->force_generic ? 0u : am_fe2_tile(c->spc);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    c->last_fe = T2 == 0 ? 1 : 2;
     if (T2 == 0) {
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         return run_candidates(c, bb, avg, j0, j1, M_out);
+    }
+    c->scan_src = src; c->scan_src_abs0 = src_abs0; c->scan_src_abs1 = src_abs1;
+    if (!avg && c->allow_fe3 && am_fe3_supported(c->spc)) {
+        // streaming kernel: candidate bitmap + per-(step, wave) counts; bb and the reference level only around candidates
+        const unsigned ns = am_fe3_steps((long long)out_n);
+        ENSURE(c, c->bits, ((size_t)ns * 96 + 64) * sizeof(uint32_t));
+        ENSURE(c, c->blk_cnt, ((size_t)ns * 2 + 8) * sizeof(uint32_t));
+        ENSURE(c, c->blk_off, ((size_t)ns * 2 + 9) * sizeof(uint32_t));
+        ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
+        unsigned nsteps = 0;
+        HIPCHK(c, am_launch_fe3(src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
+                                (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
+                                (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
+                                (uint32_t *)c->blk_cnt.p, &nsteps, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->dom_timed = true;
+        c->bb_sparse = true;
+        c->last_fe = 3;
+        const uint64_t endj3 = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
+        uint32_t cap3 = 0;
+        if (may_speculate && c->allow_spec && c->spec_density > 0.0) {
+            const double npos = (double)(j1 - j0);
+            const double want = c->spec_density * npos * 1.25 + c->spec_floor;
+            cap3 = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
+        }
+        return run_refine(c, bb, (const float *)c->avg.p, nsteps * 2, 0, 3, M_out,
+                          (uint32_t)std::min<uint64_t>(endj3, 0xFFFFFFFFull), cap3);
     }
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
     const size_t nslots = (size_t)ntiles * T2;
@@ -474,6 +515,15 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
     c->pin_scalars[2] = 0;
+    if (c->bb_sparse && !keep_bursts)
+        // bb exists only around the candidates: the 240 soft chips of a hit are recomputed from the scan's samples
+        HIPCHK(c, am_launch_extract_slice_iq(c->scan_src, (long long)c->scan_src_abs0, (long long)c->scan_src_abs1,
+                                             c->use_pmf, (float)(1.0 / (double)c->spc), (const float *)c->inavg.p, c->spc,
+                                             (uint32_t *)c->emit_idx.p, n_ptr, n_max, (uint32_t *)c->pos.p,
+                                             (uint32_t *)c->e.p, base_abs, c->rate_i, (const am_time_tag *)c->tt_dev.p,
+                                             (uint32_t)c->tt.size(), nullptr, nullptr, (uint32_t *)c->crc_pow.p,
+                                             c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
+    else
     HIPCHK(c, am_launch_extract_slice(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                       (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
                                       (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(),
@@ -608,6 +658,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         {
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
+            const char *fe = getenv("AIRMODES_FE");
+            c->allow_fe3 = !(fe && fe[0] == '2');
             const char *sp = getenv("AIRMODES_NO_SPEC");
             c->allow_spec = !(sp && sp[0] == '1');
             if (const char *sf = getenv("AIRMODES_SPEC_FLOOR")) c->spec_floor = atof(sf);
@@ -640,7 +692,7 @@ void am_destroy(am_ctx *c)
                 c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
-                     &c->energy, &c->blk_cnt, &c->blk_off,
+                     &c->energy, &c->bits, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};
@@ -1189,6 +1241,8 @@ int am_last_timing(am_ctx *c, float *total_ms, float *dom_ms)
     if (dom_ms) *dom_ms = c->last_dom_ms;
     return AM_OK;
 }
+
+int am_last_frontend(const am_ctx *c) { return c ? c->last_fe : AM_EINVAL; }
 
 long long am_last_num_candidates(const am_ctx *c)
 {

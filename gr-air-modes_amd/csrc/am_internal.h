@@ -41,6 +41,20 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
                          float sL, float thr_lin, uint32_t *seg_pos, float *avg_sparse, uint32_t *blk_cnt,
                          unsigned *ntiles, unsigned *tile_len, hipStream_t s);
+/* streaming fused front end (am_fe3.hip; 32 samples per chip): persistent workgroups, LDS-DMA staging, sparse
+ * outputs.  Candidates leave as a bitmap: bit b of word w = array coordinate w*32 + b - am_fe3_lag(); seg_cnt holds
+ * the number of candidates per (step, wave): wave 0 = words 0..63 of a step's 96, wave 1 = words 64..95. */
+int am_fe3_supported(int spc);
+unsigned am_fe3_tile(void);                 /* positions per step (3072) */
+unsigned am_fe3_lag(void);                  /* 288 */
+unsigned am_fe3_steps(long long out_n);
+hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
+                         float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
+                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, unsigned *nsteps, hipStream_t s);
+/* flat candidate positions + dcount from the bitmap; blk_off = exclusive scan of seg_cnt (2 segments per step) */
+hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *blk_off, uint32_t nseg, uint32_t M, int spc,
+                                 uint32_t lag, uint32_t *pos, uint32_t *dcount, hipStream_t s,
+                                 const uint32_t *Mp = nullptr);
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
@@ -132,6 +146,14 @@ hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc,
                                    uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,
                                    am_packet *packets, const uint32_t *scalars, uint32_t *host_out, hipStream_t s,
                                    const uint32_t *Mp = nullptr);
+/* the same when bb exists only around the candidates: the burst is recomputed from IQ (iq[0] = absolute sample src_abs0) */
+hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
+                                      const float *inavg, int spc, const uint32_t *emit_idx, const uint32_t *n_ptr,
+                                      uint32_t n_max, const uint32_t *pos, const uint32_t *e, uint64_t base_abs,
+                                      uint64_t rate, const am_time_tag *tt, uint32_t ntt, float *bursts_out,
+                                      am_tag *tags_out, const uint32_t *crc_pow, am_packet *packets,
+                                      const uint32_t *scalars, uint32_t *host_out, hipStream_t s,
+                                      const uint32_t *Mp = nullptr);
 /* packets[i].reserved[0] = 1 when the reference would post the message, else 0 */
 hipError_t am_launch_slice(const float *bursts, const am_tag *tags, const uint32_t *n_ptr, uint32_t n_max,
                            const uint32_t *crc_pow, am_packet *packets, const uint32_t *scalars,

@@ -440,6 +440,65 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
     }
 }
 
+// Flat candidate positions from the streaming front end's bitmap (am_fe3.hip): one wave per (step, wave) segment.
+// Word w, bit b = array coordinate 32*w + b - lag.  dcount needs the distance to the candidate before, capped
+// at spc + 1 <= 64: the two words in front of a word are all the history it can need.
+__global__ void __launch_bounds__(AM_WAVE)
+am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ blk_off, uint32_t nseg, uint32_t Mcap,
+                 int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
+                 const uint32_t *__restrict__ Mp)
+{
+    const uint32_t M = am_count(Mcap, Mp);
+    const uint32_t seg = blockIdx.x;
+    const uint32_t off = blk_off[seg], cnt = blk_off[seg + 1u] - off;
+    if (cnt == 0 || off >= M) return;                        // uniform
+    const int lane = threadIdx.x;
+    const uint32_t half = seg & 1u;
+    const uint32_t nw = half ? 32u : 64u;                    // words of this segment
+    const size_t w = (size_t)(seg >> 1) * 96u + half * 64u + (uint32_t)lane;
+    uint32_t word = 0, p1 = 0, p2 = 0;
+    if ((uint32_t)lane < nw) {
+        word = bits[w];
+        if (word) {
+            p1 = w >= 1 ? bits[w - 1] : 0u;
+            p2 = w >= 2 ? bits[w - 2] : 0u;
+        }
+    }
+    const uint32_t c = (uint32_t)__popcll((unsigned long long)word);
+    uint32_t incl = c;
+    for (int d = 1; d < AM_WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
+        if (lane >= d) incl += up;
+    }
+    uint32_t g = off + incl - c;
+    const unsigned long long hist = ((unsigned long long)p1 << 32) | p2;     // the 64 positions before this word
+    int prev_b = -1;
+    while (word) {
+        if (g >= M) break;
+        const int b = __ffsll((long long)word) - 1;
+        uint32_t gap;                                        // distance to the candidate before (hist bit 63 = the position just before bit 0)
+        if (prev_b >= 0) gap = (uint32_t)(b - prev_b);
+        else if (hist) gap = (uint32_t)b + 1u + (uint32_t)__clzll((long long)hist);
+        else gap = 0xFFFFu;
+        uint32_t d = (uint32_t)spc + 1u;
+        d = gap < d ? gap : d;
+        pos[g] = (uint32_t)(w * 32u) + (uint32_t)b - lag;
+        dcount[g] = d;
+        ++g;
+        prev_b = b;
+        word &= word - 1u;
+    }
+}
+
+hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *blk_off, uint32_t nseg, uint32_t M, int spc,
+                                 uint32_t lag, uint32_t *pos, uint32_t *dcount, hipStream_t s, const uint32_t *Mp)
+{
+    if (M == 0 || nseg == 0) return hipSuccess;
+    if (spc + 1 > 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(am_k_gather_bits, dim3(nseg), dim3(AM_WAVE), 0, s, bits, blk_off, nseg, M, spc, lag, pos, dcount, Mp);
+    return hipGetLastError();
+}
+
 // block-local exclusive scan (2048 elements per workgroup) + block totals
 __global__ void __launch_bounds__(256)
 am_k_exscan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out_local, uint32_t *__restrict__ blk_tot,
@@ -1292,6 +1351,105 @@ hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc,
     hipLaunchKernelGGL(am_k_extract_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_ptr,
                        pos, e, base_abs, e_off, rate, tt, ntt, bursts_out, tags_out, crc_pow, packets, scalars,
                        host_out, Mp);
+    return hipGetLastError();
+}
+
+// Extraction + slicing when bb exists only around the candidates (streaming front end): the 240 chip-spaced
+// samples of a hit are recomputed from IQ in the canonical order: sample n of chip q (offset i) is
+//   bb[n] = fl( (suf + pre) * s1 ),  pre = m[q*spc] + ... + m[n] left->right,
+//                                    suf = m[q*spc-1] + ... + m[n-spc+1] right->left (absent for i = spc-1),
+// m = |iq|^2, zero outside the stream; bb itself reads zero beyond the end of the stream.  One workgroup per hit:
+// the 240*spc samples the burst spans are staged as |.|^2 in LDS (coalesced 8-byte loads), lane c forms sample c.
+__global__ void __launch_bounds__(256)
+am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
+                      const float *__restrict__ inavg, int spc, const uint32_t *__restrict__ emit_idx,
+                      const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ pos,
+                      const uint32_t *__restrict__ eo, uint64_t base_abs, uint64_t rate,
+                      const am_time_tag *__restrict__ tt, uint32_t ntt, float *__restrict__ bursts_out,
+                      am_tag *__restrict__ tags_out, const uint32_t *__restrict__ crc_pow,
+                      am_packet *__restrict__ packets, const uint32_t *__restrict__ scalars,
+                      uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
+{
+    HIP_DYNAMIC_SHARED(float, W);                             // [240*spc padded 1 per 32] then the burst [240]
+    const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1);
+    const uint32_t i = blockIdx.x;
+    if (host_out && blockIdx.x == 0 && threadIdx.x == 0) {
+        host_out[0] = *n_ptr;
+        host_out[1] = scalars[0];
+        host_out[2] = Mp ? *Mp : 0u;
+    }
+    if (i >= *n_ptr) return;                                  // uniform; device-side hit count
+    const uint32_t g = emit_idx[i];
+    const uint32_t e = eo[g];
+    const float av = inavg[g];
+    const long long ae = (long long)base_abs + (long long)e;  // absolute index of the burst's first sample
+    const bool pmf = use_pmf && spc > 1;
+    const int nwin = AM_BURST * spc;
+    float *sb = W + nwin + (nwin >> 5) + 8;
+    const float2 *iq2 = reinterpret_cast<const float2 *>(iq);
+    const long long wlo = ae - (spc - 1);
+    if (pmf) {
+        for (int k = tid; k < nwin; k += 256) {
+            const long long n = wlo + k;
+            float mv = 0.0f;
+            if (n >= src_abs0 && n < src_abs1) {
+                const float2 t = iq2[n - src_abs0];
+                const float r = t.x * t.x, q = t.y * t.y;
+                mv = r + q;
+            }
+            W[k + (k >> 5)] = mv;
+        }
+        __syncthreads();
+    }
+    if (tid < AM_BURST) {
+        const long long n = ae + (long long)tid * spc;
+        float v = 0.0f;
+        if (n < src_abs1) {
+            if (!pmf) {
+                if (n >= src_abs0) {
+                    const float2 t = iq2[n - src_abs0];
+                    const float r = t.x * t.x, q = t.y * t.y;
+                    v = r + q;
+                }
+            } else {
+                const int ii = (int)(n % spc);                // offset inside the chip (chips start at multiples of spc)
+                const int kn = (int)(n - wlo);                // window index of sample n
+                float pre = 0.0f;
+                for (int k = kn - ii; k <= kn; ++k) pre = pre + W[k + (k >> 5)];
+                if (ii == spc - 1) v = pre * s1;
+                else {
+                    float suf = 0.0f;
+                    for (int k = kn - ii - 1; k >= kn - spc + 1; --k) suf = suf + W[k + (k >> 5)];
+                    v = (suf + pre) * s1;
+                }
+            }
+        }
+        v = v - av;                                           // preamble_impl.cc:219-221
+        sb[tid] = v;
+        if (bursts_out) bursts_out[(size_t)i * AM_BURST + tid] = v;
+    }
+    am_tag t = am_make_tag(base_abs + e + (uint64_t)(2 * spc - 1), rate, tt, ntt);
+    t.inavg = av;
+    t.how_late = e - pos[g];
+    if (tags_out && tid == 0) tags_out[i] = t;
+    __syncthreads();
+    if (tid < AM_WAVE) am_slice_wave(sb, t, i, lane, crc_pow, packets);
+}
+
+hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
+                                      const float *inavg, int spc, const uint32_t *emit_idx, const uint32_t *n_ptr,
+                                      uint32_t n_max, const uint32_t *pos, const uint32_t *e, uint64_t base_abs,
+                                      uint64_t rate, const am_time_tag *tt, uint32_t ntt, float *bursts_out,
+                                      am_tag *tags_out, const uint32_t *crc_pow, am_packet *packets,
+                                      const uint32_t *scalars, uint32_t *host_out, hipStream_t s, const uint32_t *Mp)
+{
+    if (n_max == 0) return hipSuccess;
+    const int nwin = AM_BURST * spc;
+    const size_t lds = ((size_t)nwin + (nwin >> 5) + 8 + AM_BURST) * sizeof(float);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;        // (rates served by the streaming front end are far below)
+    hipLaunchKernelGGL(am_k_extract_slice_iq, dim3(n_max), dim3(256), lds, s, iq, src_abs0, src_abs1, use_pmf, s1, inavg,
+                       spc, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow, packets,
+                       scalars, host_out, Mp);
     return hipGetLastError();
 }
 

@@ -216,6 +216,11 @@ int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
  * the last scan refined and chained.  Negative error code on a null context. */
 long long am_last_num_candidates(const am_ctx *ctx);
 
+/* Diagnostic: which front-end kernel the last scan ran -- 3 = streaming kernel (am_k_fe3: LDS-DMA staging,
+ * sparse bb), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan yet.  Results do
+ * not depend on it (the environment variable AIRMODES_FE=2 keeps the tile kernel; tests compare both). */
+int am_last_frontend(const am_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif
