@@ -35,6 +35,26 @@
 
 #include "am_fe_cmpx.h"
 
+// Two builds of the load path (FE3_DMA; measured side by side on MI355X):
+//   0 (default): plain coalesced 16-byte loads, |.|^2 written straight into the ring slots of the new chips.  26 KB
+//      of LDS per workgroup -> six workgroups (12 waves) per CU; a workgroup waits for its own loads, the other five
+//      keep the CU busy.
+//   1: raw IQ by LDS-DMA into a 24 KB staging buffer, one step ahead of the arithmetic (no wait, no VGPRs), but only
+//      three workgroups (6 waves) per CU: the dependent chains of this arithmetic then leave the SIMDs idle.
+#ifndef FE3_DMA
+#define FE3_DMA 0
+#endif
+#if FE3_DMA
+#define FE3_WPS 2                         /* launch bound, waves per SIMD */
+#define FE3_WG_PER_CU 3
+#else
+#define FE3_WPS 3
+#define FE3_WG_PER_CU 6
+#endif
+// tuning builds only (tools/build_variants.sh): FE3_ABLATE bit mask removes parts of the kernel -- results INVALID
+#ifndef FE3_ABLATE
+#define FE3_ABLATE 0
+#endif
 #define FE3_SPC 32
 #define FE3_S 96                          /* chips per step: two 48-chip blocks                        */
 #define FE3_NT 128                        /* 96 chip threads + 32 helpers (block scans, DMA issue)     */
@@ -59,7 +79,7 @@ struct am_fe3_args {
     unsigned steps_per_wg;
     // steps whose raw samples are all present and 16-byte aligned arrive by DMA: [raw_lo, raw_hi); steps whose
     // tested positions are all wanted need no range mask: [test_lo, test_hi)   (host: fe3_ranges)
-    long long raw_lo, raw_hi, test_lo, test_hi;
+    int raw_lo, raw_hi, test_lo, test_hi;
     int use_pmf;
     float s1, sL, thr_lin;
     long long *prof;                      // profiling builds: [grid * 2 waves][12] cycles per phase, else null
@@ -133,10 +153,10 @@ struct fe3_smem {
     float *X;                 // [FE3_CR * FE3_XS] bb ring
     float *TOT, *RTOT, *PT, *ST;   // [FE3_CR] per-chip sums (left->right, right->left) and their in-block scans
     float *SB0;               // [2][32] in-chip suffix sums of |.|^2 of a step's last chip (by step parity)
-    float *SB1;               // [32] the same for chip 63 (last lane of wave 0)
+    float *SB1;               // [32] DMA build: the same for chip 63 (last lane of wave 0); else |.|^2 of chip 63
     uint32_t *MASK;           // [2][4] chips with candidates, by step parity
 };
-#define FE3_LDS_BYTES (FE3_RAWB + FE3_CR * FE3_XS * 4 + 4 * FE3_CR * 4 + 3 * 32 * 4 + 8 * 4)
+#define FE3_LDS_BYTES ((FE3_DMA ? FE3_RAWB : 0) + FE3_CR * FE3_XS * 4 + 4 * FE3_CR * 4 + 3 * 32 * 4 + 8 * 4)
 
 // what a thread keeps across steps
 struct fe3_thread {
@@ -182,24 +202,74 @@ __device__ __forceinline__ void fe3_fill_raw_guarded(const am_fe3_args &a, const
     }
 }
 
+#if !FE3_DMA
+// |iq|^2 of one step straight into the ring slots of its chips (they hold chips nobody needs any more): piece
+// p = tid + 128 j (16 bytes = samples 2k, 2k+1 of chip p >> 4, k = p & 15 = tid & 15) -> X[slot][2k .. 2k+1].
+// Coalesced loads (consecutive lanes, consecutive pieces), 8-byte LDS stores (16 lanes = one chip's 128 bytes).
+// chip 63's values are stored a second time (M63): the other wave needs them after chip 63's slot holds bb.
+template <bool GUARD>
+__device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_smem &L, long long A0, int slot0, int tid)
+{
+    const int c0 = tid >> 4, k = tid & 15;
+    if constexpr (GUARD) {
+        // stream edges / unaligned input: one piece at a time, zeros outside the stream (rare: kept small)
+        const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
+#pragma unroll 1
+        for (int j = 0; j < 12; ++j) {
+            const long long n = A0 + 2 * (long long)(tid + FE3_NT * j);
+            float2 u0, u1;
+            u0.x = 0.0f; u0.y = 0.0f; u1 = u0;
+            if (n >= a.src_abs0 && n < a.src_abs1) u0 = iq2[n - a.src_abs0];
+            if (n + 1 >= a.src_abs0 && n + 1 < a.src_abs1) u1 = iq2[n + 1 - a.src_abs0];
+            const float r0 = u0.x * u0.x, i0 = u0.y * u0.y, r1 = u1.x * u1.x, i1 = u1.y * u1.y;
+            float2 mm;
+            mm.x = r0 + i0;
+            mm.y = r1 + i1;
+            const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
+            *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
+            if (j == 7 && c0 == 7) *reinterpret_cast<float2 *>(L.SB1 + 2 * k) = mm;
+        }
+        return;
+    }
+    // wave-uniform 64-bit base + 32-bit lane offset
+    const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
+    const unsigned off = (unsigned)tid * 16u;
+    float4 v[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) v[j] = *reinterpret_cast<const float4 *>(gb + (off + (unsigned)j * (FE3_NT * 16u)));
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const float r0 = v[j].x * v[j].x, i0 = v[j].y * v[j].y, r1 = v[j].z * v[j].z, i1 = v[j].w * v[j].w;
+        float2 mm;
+        mm.x = r0 + i0;                                               // a1: fl(fl(I*I) + fl(Q*Q))
+        mm.y = r1 + i1;
+        const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
+        *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
+        if (j == 7 && c0 == 7) *reinterpret_cast<float2 *>(L.SB1 + 2 * k) = mm;   // chip 63
+    }
+}
+#endif
+
 // One step.
 //   step     global step index (may be -1: history before the first wanted block)
 //   test     false for a workgroup's first step (it only rebuilds the rings from the previous segment's tail)
 //   slot0    ring slot of this step's chip 0
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
 __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const fe3_thread &T,
-                                         const unsigned raw_lds, const long long step, const bool test, const int slot0,
+                                         const unsigned raw_lds, const int step, const bool test, const int slot0,
                                          const int par, const bool issue_next, const bool edge, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
     const bool chip_thread = tid < FE3_S;
-    const long long A0 = a.out_abs0 + step * FE3_T;                 // absolute index of the step's first sample
+    const long long A0 = a.out_abs0 + (long long)step * FE3_T;      // absolute index of the step's first sample
     const int slotA = fe3_wrap_up(slot0 + tid);                       // (only meaningful for chip threads)
     const bool do_pmf = a.use_pmf != 0;
 
-    // ---- phase A1: |iq|^2 of the own chip (piece k sits at raw_addr ^ (k << 4)), in-chip suffix sums ----------
+    // ---- phase A1: |iq|^2 of the own chip, in-chip suffix sums ---------------------------------------------------
     float m[SPC];
+#if FE3_DMA
+    // raw IQ from the staging buffer (piece k sits at raw_addr ^ (k << 4))
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const float4 v = *reinterpret_cast<const float4 *>(L.raw + (T.raw_addr ^ (unsigned)(k << 4)));
@@ -207,14 +277,25 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         m[2 * k] = r0 + i0;                                           // a1: fl(fl(I*I) + fl(Q*Q))
         m[2 * k + 1] = r1 + i1;
     }
+#else
+    {
+        const float4 *mp = reinterpret_cast<const float4 *>(L.X + slotA * FE3_XS);
+#pragma unroll
+        for (int k = 0; k < SPC / 4; ++k) {
+            const float4 t = mp[k];
+            m[4 * k] = t.x; m[4 * k + 1] = t.y; m[4 * k + 2] = t.z; m[4 * k + 3] = t.w;
+        }
+    }
+#endif
     // suffix sums of the own chip (what the NEXT chip's filter needs): sx[i] = m[31] + ... + m[i], right->left
     float sx[SPC];
     if (do_pmf) {
         float acc = 0.0f;
 #pragma unroll
         for (int i = SPC - 1; i >= 0; --i) { acc = acc + m[i]; sx[i] = acc; }
-        // the step's last chip hands its sums to the next step's first chip, chip 63 to chip 64 (other wave)
-        if (tid == FE3_S - 1 || tid == AM_WAVE - 1) {
+        // the step's last chip hands its sums to the next step's first chip (DMA build: and chip 63 to chip 64,
+        // other wave; the plain-load build staged chip 63's |.|^2 for that)
+        if (tid == FE3_S - 1 || (FE3_DMA && tid == AM_WAVE - 1)) {
             float4 *dst = reinterpret_cast<float4 *>((tid == FE3_S - 1) ? (L.SB0 + par * 32) : L.SB1);
 #pragma unroll
             for (int k = 0; k < SPC / 4; ++k) {
@@ -225,11 +306,13 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         }
     }
     FE3_STAMP(1);
+#if FE3_DMA
     fe3_barrier();                                                    // B2: staging buffer read by everyone
     FE3_STAMP(2);
     if (issue_next)
         fe3_issue_dma(reinterpret_cast<const unsigned char *>(a.iq) + (size_t)((A0 + FE3_T) - a.src_abs0) * 8, L, T,
                       raw_lds, wv, lane);
+#endif
     float bb[SPC];
     if (do_pmf) {
         // suffix sums of the chip before: lane-1, except lane 0 of a wave (from LDS; every lane reads: a broadcast)
@@ -241,6 +324,13 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                 const float4 t = src[k];
                 pv[4 * k] = t.x; pv[4 * k + 1] = t.y; pv[4 * k + 2] = t.z; pv[4 * k + 3] = t.w;
             }
+#if !FE3_DMA
+            if (wv != 0) {                                            // (uniform) |.|^2 of chip 63 -> its suffix sums
+                float acc2 = 0.0f;
+#pragma unroll
+                for (int i = SPC - 1; i >= 0; --i) { acc2 = acc2 + pv[i]; pv[i] = acc2; }
+            }
+#endif
         }
         float acc = 0.0f;
 #pragma unroll
@@ -284,7 +374,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
 
     // ---- in-block scans of the two new blocks (4 helper lanes: block x direction), canonical sequential order.
     // Blocks start at multiples of 16 slots, so groups of four consecutive chips never straddle the ring's end.
-    if (tid >= FE3_S && tid < FE3_S + 4) {
+    if (!(FE3_ABLATE & 8) && tid >= FE3_S && tid < FE3_S + 4) {
         const int blk = (tid - FE3_S) >> 1;
         const int s0 = fe3_wrap_up(slot0 + blk * AM_CHIPS_AVG);
         float t[AM_CHIPS_AVG];
@@ -361,7 +451,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         }
     }
     // array coordinate of x[0]
-    const long long jrun = step * FE3_T + (long long)tid * SPC - (long long)FE3_LAG * SPC;
+    const long long jrun = (long long)step * FE3_T + (long long)(tid * SPC - FE3_LAG * SPC);
     uint32_t cm = 0u;
     {
         constexpr int CH = 16;
@@ -377,7 +467,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             fe2_peak8<H + 8>(part, &x[H + 8], (H + 16 < SPC) ? x[(H + 16 < SPC) ? H + 16 : 0] : nxt, &thr[8]);
             // the three later pulses must not be below the threshold (:177-179): one test on the smallest
             // (v_min3 ignores a NaN operand exactly as `NaN < thr` is false); only where some lane has a survivor
-            if (__ballot(part != 0u) != 0ull) {
+            if (!(FE3_ABLATE & 2) && __ballot(part != 0u) != 0ull) {
                 float t2[CH], t7[CH], t9[CH];
 #pragma unroll
                 for (int k = 0; k < CH / 4; ++k) {
@@ -395,8 +485,10 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             }
             cm |= part;
         };
+        if (!(FE3_ABLATE & 4)) {
         pass(std::integral_constant<int, 0>{});
         pass(std::integral_constant<int, CH>{});
+        }
 #else
         // (host build of the same source for the CPU-fiber tests: the predicate as plain C++)
 #pragma unroll
@@ -452,7 +544,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     fe3_barrier();                                                    // B5: chip masks of this step
     FE3_STAMP(8);
     // ---- sparse outputs: bb for the 17 chips from a candidate's chip on, avg for 2 -----------------------------------
-    if (chip_thread) {
+    if (chip_thread && !(FE3_ABLATE & 1)) {
         // bit i of `win` = chip (tid - 31 + i) has a candidate, chips before this step come from the previous mask
         const uint32_t *cur = L.MASK + par * 4, *prv = L.MASK + (par ^ 1) * 4;
         const int w = tid >> 5, sh = tid & 31;
@@ -496,12 +588,12 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     }
 }
 
-__global__ void __launch_bounds__(FE3_NT, 2) am_k_fe3(am_fe3_args a)
+__global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem);
     fe3_smem L;
     L.raw = smem;
-    L.X = reinterpret_cast<float *>(smem + FE3_RAWB);
+    L.X = reinterpret_cast<float *>(smem + (FE3_DMA ? FE3_RAWB : 0));
     L.TOT = L.X + FE3_CR * FE3_XS;
     L.RTOT = L.TOT + FE3_CR;
     L.PT = L.RTOT + FE3_CR;
@@ -515,9 +607,9 @@ __global__ void __launch_bounds__(FE3_NT, 2) am_k_fe3(am_fe3_args a)
     const unsigned raw_lds = 0;
 #endif
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
-    const long long sb = (long long)blockIdx.x * a.steps_per_wg;
-    if (sb >= (long long)a.nsteps) return;
-    const long long se = (sb + a.steps_per_wg < (long long)a.nsteps) ? sb + a.steps_per_wg : (long long)a.nsteps;
+    const int sb = (int)(blockIdx.x * a.steps_per_wg);
+    if (sb >= (int)a.nsteps) return;
+    const int se = (sb + (int)a.steps_per_wg < (int)a.nsteps) ? sb + (int)a.steps_per_wg : (int)a.nsteps;
 
     fe3_thread T;
     {
@@ -535,12 +627,19 @@ __global__ void __launch_bounds__(FE3_NT, 2) am_k_fe3(am_fe3_args a)
     // segment count as "had candidates" so that the first 17 chips' bb is always written
     for (int i = tid; i < FE3_CR * FE3_XS + 4 * FE3_CR + 96; i += FE3_NT) L.X[i] = 0.0f;
     if (tid < 8) L.MASK[tid] = 0xFFFFFFFFu;
+#if !FE3_DMA
+    fe3_barrier();                                                    // (the first step stages into the ring right away)
+#endif
 
-    long long step = sb - 1;                                          // the step before the segment rebuilds the rings
+    int step = sb - 1;                                                // the step before the segment rebuilds the rings
     bool fast = step >= a.raw_lo && step < a.raw_hi;
+#if FE3_DMA
     if (fast)
-        fe3_issue_dma(reinterpret_cast<const unsigned char *>(a.iq) + (size_t)((a.out_abs0 + step * FE3_T) - a.src_abs0) * 8,
+        fe3_issue_dma(reinterpret_cast<const unsigned char *>(a.iq) + (size_t)((a.out_abs0 + (long long)step * FE3_T) - a.src_abs0) * 8,
                       L, T, raw_lds, wv, lane);
+#else
+    (void)raw_lds; (void)lane; (void)wv;
+#endif
     int slot0 = 0, par = 0;
     fe3_prof PR;
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -552,11 +651,16 @@ __global__ void __launch_bounds__(FE3_NT, 2) am_k_fe3(am_fe3_args a)
         const bool next_fast = (step + 1 < se) && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
         const bool edge = !fast || (test && !(step >= a.test_lo && step < a.test_hi));
         FE3_STAMP(9);
+#if FE3_DMA
         if (fast) fe3_dma_wait();
         else {
             fe3_barrier();                                            // (the staging buffer may still be read)
-            fe3_fill_raw_guarded(a, L, a.out_abs0 + step * FE3_T, tid);
+            fe3_fill_raw_guarded(a, L, a.out_abs0 + (long long)step * FE3_T, tid);
         }
+#else
+        if (fast) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+        else fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+#endif
         FE3_STAMP(10);
         fe3_barrier();                                                // B1: raw of this step landed (all waves); LDS reuse
         FE3_STAMP(0);
@@ -589,7 +693,7 @@ static int fe3_wgs_for_device()
         hipDeviceProp_t prop;
         const int ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                             ? prop.multiProcessorCount : 256;
-        cached[dev] = 3 * ncu;                                        // three resident workgroups per CU (LDS)
+        cached[dev] = FE3_WG_PER_CU * ncu;                            // resident workgroups (LDS)
     }
     return cached[dev];
 }
@@ -608,13 +712,14 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     // steps served by DMA: samples [out_abs0 + k T, + T) inside [src_abs0, src_abs1), source 16-byte aligned (the
     // parity of the offset is the same for every step: T is even)
     const bool aligned = ((reinterpret_cast<uintptr_t>(iq) + (uintptr_t)(out_abs0 - src_abs0) * 8u) & 15u) == 0;
-    a.raw_lo = fe3_ceil_div(src_abs0 - out_abs0, FE3_T);
-    a.raw_hi = aligned ? fe3_floor_div(src_abs1 - out_abs0, FE3_T) : a.raw_lo;
+    auto clampi = [](long long v) { return (int)(v < -4 ? -4 : (v > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : v)); };
+    a.raw_lo = clampi(fe3_ceil_div(src_abs0 - out_abs0, FE3_T));
+    a.raw_hi = aligned ? clampi(fe3_floor_div(src_abs1 - out_abs0, FE3_T)) : a.raw_lo;
     // steps whose tested positions [k T - 288, k T + T - 288) all lie in [j0, min(j1, out_n))
     const long long lag = (long long)FE3_LAG * FE3_SPC;
     const long long jhi = (long long)j1 < out_n ? (long long)j1 : out_n;
-    a.test_lo = fe3_ceil_div((long long)j0 + lag, FE3_T);
-    a.test_hi = fe3_floor_div(jhi + lag, FE3_T);
+    a.test_lo = clampi(fe3_ceil_div((long long)j0 + lag, FE3_T));
+    a.test_hi = clampi(fe3_floor_div(jhi + lag, FE3_T));
     // persistent workgroups: as many as are resident at once, each with a contiguous run of steps; short inputs
     // get at least 4 steps per workgroup (the ring rebuild costs one)
     const unsigned resident = (unsigned)fe3_wgs_for_device();
