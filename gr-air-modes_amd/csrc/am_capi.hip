@@ -99,7 +99,7 @@ struct am_ctx {
 
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
-        emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits,
+        emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y;
 
     // results of the last scan
@@ -297,18 +297,29 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
     c->spec_now = false;
     c->Mdev = nullptr;
     if (nseg == 0) return AM_OK;
-    HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg, c->stream));
+    const uint32_t *count_ptr = (const uint32_t *)c->blk_off.p + nseg;       // device-side total
+    if (mode == 3) {
+        // many short segments (two per step of the streaming kernel): two-level scan, 2048 counts per workgroup
+        const uint32_t nbs = (nseg + 2047u) / 2048u;
+        ENSURE(c, c->seg_tot, ((size_t)nbs + 1) * sizeof(uint32_t));
+        ENSURE(c, c->seg_base, ((size_t)nbs + 2) * sizeof(uint32_t));
+        HIPCHK(c, am_launch_exscan_blocks((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, (uint32_t *)c->seg_tot.p,
+                                          nseg, c->stream));
+        HIPCHK(c, am_launch_scan_u32((uint32_t *)c->seg_tot.p, (uint32_t *)c->seg_base.p, nbs, c->stream));
+        count_ptr = (const uint32_t *)c->seg_base.p + nbs;
+    } else
+        HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg, c->stream));
     c->ref_bb = bb; c->ref_avg = avg; c->ref_nseg = nseg; c->ref_stride = seg_stride; c->ref_mode = mode;
     c->ref_endj = end_j;
     uint32_t M = 0;
     const uint32_t *Mp = nullptr;
     if (spec_cap && mode >= 2) {
         M = spec_cap;                                        // capacity; the kernels clip to *Mp
-        Mp = (const uint32_t *)c->blk_off.p + nseg;
+        Mp = count_ptr;
         c->spec_now = true;
         c->Mdev = Mp;
     } else {
-        HIPCHK(c, hipMemcpyAsync(&M, (uint32_t *)c->blk_off.p + nseg, sizeof(uint32_t), hipMemcpyDeviceToHost,
+        HIPCHK(c, hipMemcpyAsync(&M, count_ptr, sizeof(uint32_t), hipMemcpyDeviceToHost,
                                  c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -328,8 +339,9 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             ENSURE(c, c->blk_base2, ((size_t)nb + 2) * sizeof(uint32_t));
             ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
             if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
-                HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_off.p, nseg, M, c->spc,
-                                                am_fe3_lag(), (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
+                HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p,
+                                                (uint32_t *)c->seg_base.p, nseg, M, c->spc, am_fe3_lag(),
+                                                (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             else
                 HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
                                                c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
@@ -692,7 +704,7 @@ void am_destroy(am_ctx *c)
                 c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
-                     &c->energy, &c->bits, &c->blk_cnt, &c->blk_off,
+                     &c->energy, &c->bits, &c->seg_tot, &c->seg_base, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->emit, &c->jump, &c->emit_idx,
                      &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};

@@ -35,35 +35,27 @@
 
 #include "am_fe_cmpx.h"
 
-// Two builds of the load path (FE3_DMA; measured side by side on MI355X):
-//   0 (default): plain coalesced 16-byte loads, |.|^2 written straight into the ring slots of the new chips.  26 KB
-//      of LDS per workgroup -> six workgroups (12 waves) per CU; a workgroup waits for its own loads, the other five
-//      keep the CU busy.
-//   1: raw IQ by LDS-DMA into a 24 KB staging buffer, one step ahead of the arithmetic (no wait, no VGPRs), but only
-//      three workgroups (6 waves) per CU: the dependent chains of this arithmetic then leave the SIMDs idle.
-#ifndef FE3_DMA
-#define FE3_DMA 0
-#endif
-#if FE3_DMA
-#define FE3_WPS 2                         /* launch bound, waves per SIMD */
-#define FE3_WG_PER_CU 3
-#else
-#define FE3_WPS 3
-#define FE3_WG_PER_CU 6
-#endif
 // tuning builds only (tools/build_variants.sh): FE3_ABLATE bit mask removes parts of the kernel -- results INVALID
 #ifndef FE3_ABLATE
 #define FE3_ABLATE 0
 #endif
+#ifndef FE3_LOAD_EARLY
+#define FE3_LOAD_EARLY 1
+#endif
+#ifndef FE3_WPS
+#define FE3_WPS 2                         /* launch bound, waves per SIMD (<= 256 VGPRs; at 168 the prefetched loads spill) */
+#endif
+#ifndef FE3_WG_PER_CU
+#define FE3_WG_PER_CU 4                   /* resident workgroups per CU (8 waves of <= 256 VGPRs)      */
+#endif
 #define FE3_SPC 32
-#define FE3_S 96                          /* chips per step: two 48-chip blocks                        */
-#define FE3_NT 128                        /* 96 chip threads + 32 helpers (block scans, DMA issue)     */
+#define FE3_S 96                          /* chips per step: two 48-chip blocks, one per wave          */
+#define FE3_NT 128                        /* two waves: lanes 0..47 = the block's chips, all 128 threads stage the loads */
 #define FE3_T (FE3_S * FE3_SPC)           /* samples per step                                          */
 #define FE3_LAG 9                         /* phase B runs this many chips behind phase A               */
-#define FE3_CR 160                        /* ring capacity in chips: 96 new + 9 lag + 48 back + slack   */
+#define FE3_CR 154                        /* ring capacity in chips: 96 new + 9 lag + 48 back + 1           */
 #define FE3_XS 36                         /* floats per ring chip: 32 + 4 pad (16-byte reads of consecutive chips hit all banks) */
-#define FE3_RAWB (FE3_T * 8)              /* raw bytes per step                                        */
-#define FE3_BBW 17                        /* chips of bb kept after a candidate's chip (am_k_cand reads up to pos + 16*spc) */
+#define FE3_BBW 17                        /* chips of bb kept from a candidate's chip on (am_k_cand reads up to pos + 16*spc) */
 
 struct am_fe3_args {
     const float *iq;
@@ -74,11 +66,11 @@ struct am_fe3_args {
     float *avg_sparse;                    // reference-level runs around candidates
     uint32_t j0, j1;                      // positions whose preamble test is wanted
     uint32_t *bits;                       // [nsteps * 96] candidate words: bit b of word w = position w*32 + b - 288
-    uint32_t *seg_cnt;                    // [nsteps * 2] candidates per (step, wave)
+    uint32_t *seg_cnt;                    // [nsteps * 2] candidates per (step, wave); wave w = words 48w .. 48w+47
     unsigned nsteps;                      // steps (= bitmap tiles) of the whole launch
     unsigned steps_per_wg;
-    // steps whose raw samples are all present and 16-byte aligned arrive by DMA: [raw_lo, raw_hi); steps whose
-    // tested positions are all wanted need no range mask: [test_lo, test_hi)   (host: fe3_ranges)
+    // steps whose raw samples are all present and 16-byte aligned are loaded without guards: [raw_lo, raw_hi);
+    // steps whose tested positions are all wanted need no range mask: [test_lo, test_hi)
     int raw_lo, raw_hi, test_lo, test_hi;
     int use_pmf;
     float s1, sL, thr_lin;
@@ -90,7 +82,7 @@ struct am_fe3_args {
 __device__ __forceinline__ int fe3_wrap_up(int s) { return s >= FE3_CR ? s - FE3_CR : s; }     // s in [0, 2*CR)
 __device__ __forceinline__ int fe3_wrap_dn(int s) { return s < 0 ? s + FE3_CR : s; }           // s in [-CR, CR)
 
-// everything this workgroup wrote to LDS is visible to it after this; asynchronous LDS-DMA stays in flight
+// everything this workgroup wrote to LDS is visible to it after this (global loads / stores stay in flight)
 __device__ __forceinline__ void fe3_barrier()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -100,41 +92,27 @@ __device__ __forceinline__ void fe3_barrier()
 #endif
 }
 
-// 16 bytes from global memory (gbase + voff + IMM) to LDS address (lds_base + IMM + lane * 16), asynchronously
-// (counted by vmcnt): the instruction's immediate offset applies to BOTH addresses.  gbase and lds_base are
-// wave-uniform (scalar registers), voff is the lane's byte offset.
-template <int IMM>
-__device__ __forceinline__ void fe3_dma16(const unsigned char *gbase, unsigned voff, unsigned lds_base,
-                                          unsigned char *lds_generic, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lds_generic; (void)lane;
-    // (s_nop 4: the scalar base may come straight from an SALU instruction the compiler placed in front of this
-    // statement -- it does not know that a memory instruction reads it here)
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3 nt"
-                 : : "v"(voff), "s"(gbase), "s"(lds_base), "n"(IMM) : "memory");
-#else
-    (void)lds_base;
-    memcpy(lds_generic + IMM + (size_t)lane * 16, gbase + voff + IMM, 16);
-#endif
-}
-__device__ __forceinline__ void fe3_dma_wait()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
-
-// value of lane-1 (lane 0 of a wave keeps `old`): DPP wave_shr:1 on gfx9
-__device__ __forceinline__ float fe3_from_prev_lane(float v, float old, int lane)
+// value of lane-1 (lane 0 of a wave gets `first`) / of lane+1 (lane 63 gets `last`): DPP wave_shr:1 / wave_shl:1 on gfx9
+__device__ __forceinline__ float fe3_from_prev_lane(float v, float first, int lane)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)lane;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v),
                                                                  0x138, 0xf, 0xf, false));
 #else
     const float s = __shfl_up(v, 1, AM_WAVE);
-    return lane == 0 ? old : s;
+    return lane == 0 ? first : s;
+#endif
+}
+__device__ __forceinline__ float fe3_from_next_lane(float v, float last, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, v),
+                                                                 0x130, 0xf, 0xf, false));
+#else
+    const float s = __shfl_down(v, 1, AM_WAVE);
+    return lane == AM_WAVE - 1 ? last : s;
 #endif
 }
 
@@ -149,64 +127,45 @@ struct fe3_prof { };
 #endif
 
 struct fe3_smem {
-    unsigned char *raw;       // [FE3_RAWB] DMA target, 16-byte pieces permuted per chip
-    float *X;                 // [FE3_CR * FE3_XS] bb ring
-    float *TOT, *RTOT, *PT, *ST;   // [FE3_CR] per-chip sums (left->right, right->left) and their in-block scans
+    float *X;                 // [FE3_CR * FE3_XS] ring: |.|^2 of a step's chips while it is staged, then bb
+    float *RTOT, *PT, *ST;    // [FE3_CR] per chip: right->left sum of its bb; in-block exclusive prefix / suffix of the chip totals
     float *SB0;               // [2][32] in-chip suffix sums of |.|^2 of a step's last chip (by step parity)
-    float *SB1;               // [32] DMA build: the same for chip 63 (last lane of wave 0); else |.|^2 of chip 63
-    uint32_t *MASK;           // [2][4] chips with candidates, by step parity
+    float *M47;               // [32] |.|^2 of chip 47 (the chip before wave 1's first)
+    uint32_t *CARRY;          // [2] chips at the start of the next step whose bb must be written (bit mask, by step parity)
+    uint32_t *TAB;            // [2][64] per wave: lane of the r-th chip whose bb / reference level is written
+    float *AVS;               // [2][4 * FE3_XS] per wave: four chips of reference level on their way out
 };
-#define FE3_LDS_BYTES ((FE3_DMA ? FE3_RAWB : 0) + FE3_CR * FE3_XS * 4 + 4 * FE3_CR * 4 + 3 * 32 * 4 + 8 * 4)
+#define FE3_LDS_BYTES (FE3_CR * FE3_XS * 4 + 3 * 32 * 4 + 2 * 4 * FE3_XS * 4 + 3 * FE3_CR * 4 + 2 * 4 + 2 * 64 * 4)
 
-// what a thread keeps across steps
-struct fe3_thread {
-    unsigned raw_addr;        // byte offset of the own chip's staging row, already XORed with its swizzle
-    unsigned dma_off[4];      // lane part of the DMA source offsets (wave-instruction j uses [j & 3])
-};
+struct fe3_raw { float4 v[12]; };      // a thread's 12 pieces of a step's raw IQ (piece tid + 128 j)
 
-// raw IQ of one step (first sample at byte address g0, wave-uniform) -> staging buffer: 24 KB = 24 wave-instructions
-// of 1 KB, 12 per wave.  LDS piece p = 16 * chip + kk receives the chip's piece kk ^ (chip & 15): thread t then
-// reads its 16 pieces with 16 consecutive lanes on 16 different bank groups.
-__device__ __forceinline__ void fe3_issue_dma(const unsigned char *g0, const fe3_smem &L, const fe3_thread &T,
-                                              unsigned raw_lds, int wv, int lane)
+// unguarded loads of a step (wave-uniform 64-bit base + 32-bit lane offset): issued early, consumed by fe3_store_step
+__device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0, int tid, fe3_raw &r)
 {
-    wv = __builtin_amdgcn_readfirstlane(wv);                          // (bases go through scalar registers)
-    const unsigned char *gw = g0 + (size_t)wv * 12288;                // this wave's 12 KB
-    const unsigned lw = raw_lds + (unsigned)wv * 12288u;
-    unsigned char *lg = L.raw + (size_t)wv * 12288;
-#define FE3_DMA4(G)                                                                              \
-    fe3_dma16<0>(gw + (G) * 4096, T.dma_off[0], lw + (G) * 4096u, lg + (G) * 4096, lane);        \
-    fe3_dma16<1024>(gw + (G) * 4096, T.dma_off[1], lw + (G) * 4096u, lg + (G) * 4096, lane);     \
-    fe3_dma16<2048>(gw + (G) * 4096, T.dma_off[2], lw + (G) * 4096u, lg + (G) * 4096, lane);     \
-    fe3_dma16<3072>(gw + (G) * 4096, T.dma_off[3], lw + (G) * 4096u, lg + (G) * 4096, lane);
-    FE3_DMA4(0)
-    FE3_DMA4(1)
-    FE3_DMA4(2)
-#undef FE3_DMA4
+    const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
+    const unsigned off = (unsigned)tid * 16u;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) r.v[j] = *reinterpret_cast<const float4 *>(gb + (off + (unsigned)j * (FE3_NT * 16u)));
 }
-
-// A step whose raw samples did not arrive by DMA (stream edges, unaligned input): the staging buffer is filled
-// with guarded loads, zeros outside the stream, in the same permuted layout.
-__device__ __forceinline__ void fe3_fill_raw_guarded(const am_fe3_args &a, const fe3_smem &L, long long A0, int tid)
+__device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int tid, const fe3_raw &r)
 {
-    const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
-    for (int p = tid; p < FE3_T / 2; p += FE3_NT) {
-        const int t = p >> 4, kk = p & 15;
-        const int k = kk ^ (t & 15);
-        const long long n = A0 + (long long)t * FE3_SPC + 2 * k;
-        float4 v;
-        v.x = 0.0f; v.y = 0.0f; v.z = 0.0f; v.w = 0.0f;
-        if (n >= a.src_abs0 && n < a.src_abs1) { const float2 u = iq2[n - a.src_abs0]; v.x = u.x; v.y = u.y; }
-        if (n + 1 >= a.src_abs0 && n + 1 < a.src_abs1) { const float2 u = iq2[n + 1 - a.src_abs0]; v.z = u.x; v.w = u.y; }
-        *reinterpret_cast<float4 *>(L.raw + (size_t)p * 16) = v;
+    const int c0 = tid >> 4, k = tid & 15;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const float r0 = r.v[j].x * r.v[j].x, i0 = r.v[j].y * r.v[j].y, r1 = r.v[j].z * r.v[j].z, i1 = r.v[j].w * r.v[j].w;
+        float2 mm;
+        mm.x = r0 + i0;                                               // a1: fl(fl(I*I) + fl(Q*Q))
+        mm.y = r1 + i1;
+        const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
+        *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
+        if (j == 5 && c0 == 7) *reinterpret_cast<float2 *>(L.M47 + 2 * k) = mm;   // chip 47 = pieces 752 .. 767
     }
 }
 
-#if !FE3_DMA
 // |iq|^2 of one step straight into the ring slots of its chips (they hold chips nobody needs any more): piece
 // p = tid + 128 j (16 bytes = samples 2k, 2k+1 of chip p >> 4, k = p & 15 = tid & 15) -> X[slot][2k .. 2k+1].
 // Coalesced loads (consecutive lanes, consecutive pieces), 8-byte LDS stores (16 lanes = one chip's 128 bytes).
-// chip 63's values are stored a second time (M63): the other wave needs them after chip 63's slot holds bb.
+// chip 47's values are stored a second time (M47): wave 1 needs them after chip 47's slot holds bb.
 template <bool GUARD>
 __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_smem &L, long long A0, int slot0, int tid)
 {
@@ -227,218 +186,166 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
             mm.y = r1 + i1;
             const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
             *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
-            if (j == 7 && c0 == 7) *reinterpret_cast<float2 *>(L.SB1 + 2 * k) = mm;
+            if (j == 5 && c0 == 7) *reinterpret_cast<float2 *>(L.M47 + 2 * k) = mm;
         }
         return;
     }
-    // wave-uniform 64-bit base + 32-bit lane offset
-    const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
-    const unsigned off = (unsigned)tid * 16u;
-    float4 v[12];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) v[j] = *reinterpret_cast<const float4 *>(gb + (off + (unsigned)j * (FE3_NT * 16u)));
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const float r0 = v[j].x * v[j].x, i0 = v[j].y * v[j].y, r1 = v[j].z * v[j].z, i1 = v[j].w * v[j].w;
-        float2 mm;
-        mm.x = r0 + i0;                                               // a1: fl(fl(I*I) + fl(Q*Q))
-        mm.y = r1 + i1;
-        const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
-        *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
-        if (j == 7 && c0 == 7) *reinterpret_cast<float2 *>(L.SB1 + 2 * k) = mm;   // chip 63
-    }
+    fe3_raw v;
+    fe3_load_step(a, A0, tid, v);
+    fe3_store_step(L, slot0, tid, v);
 }
-#endif
 
-// One step.
+// One step (its |.|^2 is staged).
 //   step     global step index (may be -1: history before the first wanted block)
 //   test     false for a workgroup's first step (it only rebuilds the rings from the previous segment's tail)
 //   slot0    ring slot of this step's chip 0
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
-__device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const fe3_thread &T,
-                                         const unsigned raw_lds, const int step, const bool test, const int slot0,
-                                         const int par, const bool issue_next, const bool edge, fe3_prof &PR)
+__device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const int step, const bool test,
+                                         const int slot0, const int par, const bool edge, const bool load_next,
+                                         fe3_raw &nextraw, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
-    const bool chip_thread = tid < FE3_S;
+    const bool chip_thread = lane < AM_CHIPS_AVG;
+    const int t = wv * AM_CHIPS_AVG + (chip_thread ? lane : AM_CHIPS_AVG - 1);   // chip of the step (spare lanes shadow the last one, never write)
     const long long A0 = a.out_abs0 + (long long)step * FE3_T;      // absolute index of the step's first sample
-    const int slotA = fe3_wrap_up(slot0 + tid);                       // (only meaningful for chip threads)
+    const int slotA = fe3_wrap_up(slot0 + t);
     const bool do_pmf = a.use_pmf != 0;
 
-    // ---- phase A1: |iq|^2 of the own chip, in-chip suffix sums ---------------------------------------------------
-    float m[SPC];
-#if FE3_DMA
-    // raw IQ from the staging buffer (piece k sits at raw_addr ^ (k << 4))
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float4 v = *reinterpret_cast<const float4 *>(L.raw + (T.raw_addr ^ (unsigned)(k << 4)));
-        const float r0 = v.x * v.x, i0 = v.y * v.y, r1 = v.z * v.z, i1 = v.w * v.w;
-        m[2 * k] = r0 + i0;                                           // a1: fl(fl(I*I) + fl(Q*Q))
-        m[2 * k + 1] = r1 + i1;
-    }
-#else
+    // ---- phase A: pulse matched filter of the own chip, chip totals, in-block scans -------------------------------
+    float bb[SPC];
     {
+        float m[SPC];
         const float4 *mp = reinterpret_cast<const float4 *>(L.X + slotA * FE3_XS);
 #pragma unroll
         for (int k = 0; k < SPC / 4; ++k) {
-            const float4 t = mp[k];
-            m[4 * k] = t.x; m[4 * k + 1] = t.y; m[4 * k + 2] = t.z; m[4 * k + 3] = t.w;
+            const float4 u = mp[k];
+            m[4 * k] = u.x; m[4 * k + 1] = u.y; m[4 * k + 2] = u.z; m[4 * k + 3] = u.w;
         }
-    }
-#endif
-    // suffix sums of the own chip (what the NEXT chip's filter needs): sx[i] = m[31] + ... + m[i], right->left
-    float sx[SPC];
-    if (do_pmf) {
-        float acc = 0.0f;
+        if (do_pmf) {
+            // suffix sums of the own chip (what the NEXT chip's filter needs): sx[i] = m[31] + ... + m[i], right->left
+            float sx[SPC];
+            float acc = 0.0f;
 #pragma unroll
-        for (int i = SPC - 1; i >= 0; --i) { acc = acc + m[i]; sx[i] = acc; }
-        // the step's last chip hands its sums to the next step's first chip (DMA build: and chip 63 to chip 64,
-        // other wave; the plain-load build staged chip 63's |.|^2 for that)
-        if (tid == FE3_S - 1 || (FE3_DMA && tid == AM_WAVE - 1)) {
-            float4 *dst = reinterpret_cast<float4 *>((tid == FE3_S - 1) ? (L.SB0 + par * 32) : L.SB1);
+            for (int i = SPC - 1; i >= 0; --i) { acc = acc + m[i]; sx[i] = acc; }
+            // the step's last chip hands its sums to the next step's first chip
+            if (tid == AM_WAVE + AM_CHIPS_AVG - 1) {
+                float4 *dst = reinterpret_cast<float4 *>(L.SB0 + par * 32);
 #pragma unroll
-            for (int k = 0; k < SPC / 4; ++k) {
-                float4 t;
-                t.x = sx[4 * k]; t.y = sx[4 * k + 1]; t.z = sx[4 * k + 2]; t.w = sx[4 * k + 3];
-                dst[k] = t;
+                for (int k = 0; k < SPC / 4; ++k) {
+                    float4 u;
+                    u.x = sx[4 * k]; u.y = sx[4 * k + 1]; u.z = sx[4 * k + 2]; u.w = sx[4 * k + 3];
+                    dst[k] = u;
+                }
             }
-        }
-    }
-    FE3_STAMP(1);
-#if FE3_DMA
-    fe3_barrier();                                                    // B2: staging buffer read by everyone
-    FE3_STAMP(2);
-    if (issue_next)
-        fe3_issue_dma(reinterpret_cast<const unsigned char *>(a.iq) + (size_t)((A0 + FE3_T) - a.src_abs0) * 8, L, T,
-                      raw_lds, wv, lane);
-#endif
-    float bb[SPC];
-    if (do_pmf) {
-        // suffix sums of the chip before: lane-1, except lane 0 of a wave (from LDS; every lane reads: a broadcast)
-        float pv[SPC];
-        {
-            const float4 *src = reinterpret_cast<const float4 *>((wv == 0) ? (L.SB0 + (par ^ 1) * 32) : L.SB1);
+            // suffix sums of the chip before: lane-1; lane 0 of wave 0: the previous step's last chip (LDS), lane 0 of
+            // wave 1: chip 47, recomputed from its staged |.|^2 (every lane reads them: a broadcast)
+            float pv[SPC];
+            {
+                const float4 *src = reinterpret_cast<const float4 *>((wv == 0) ? (L.SB0 + (par ^ 1) * 32) : L.M47);
 #pragma unroll
-            for (int k = 0; k < SPC / 4; ++k) {
-                const float4 t = src[k];
-                pv[4 * k] = t.x; pv[4 * k + 1] = t.y; pv[4 * k + 2] = t.z; pv[4 * k + 3] = t.w;
+                for (int k = 0; k < SPC / 4; ++k) {
+                    const float4 u = src[k];
+                    pv[4 * k] = u.x; pv[4 * k + 1] = u.y; pv[4 * k + 2] = u.z; pv[4 * k + 3] = u.w;
+                }
+                if (wv != 0) {                                        // (uniform)
+                    float acc2 = 0.0f;
+#pragma unroll
+                    for (int i = SPC - 1; i >= 0; --i) { acc2 = acc2 + pv[i]; pv[i] = acc2; }
+                }
             }
-#if !FE3_DMA
-            if (wv != 0) {                                            // (uniform) |.|^2 of chip 63 -> its suffix sums
-                float acc2 = 0.0f;
+            acc = 0.0f;
 #pragma unroll
-                for (int i = SPC - 1; i >= 0; --i) { acc2 = acc2 + pv[i]; pv[i] = acc2; }
+            for (int i = 0; i < SPC; ++i) {
+                acc = acc + m[i];                                     // in-chip prefix, left->right
+                if (i == SPC - 1) bb[i] = acc * a.s1;                 // the window is the chip
+                else bb[i] = (fe3_from_prev_lane(sx[i + 1], pv[i + 1], lane) + acc) * a.s1;
             }
-#endif
-        }
-        float acc = 0.0f;
+        } else {
 #pragma unroll
-        for (int i = 0; i < SPC; ++i) {
-            acc = acc + m[i];                                         // in-chip prefix, left->right
-            if (i == SPC - 1) bb[i] = acc * a.s1;                     // the window is the chip
-            else bb[i] = (fe3_from_prev_lane(sx[i + 1], pv[i + 1], lane) + acc) * a.s1;
+            for (int i = 0; i < SPC; ++i) bb[i] = m[i];
         }
-    } else {
-#pragma unroll
-        for (int i = 0; i < SPC; ++i) bb[i] = m[i];
     }
     if (edge) {
         // positions beyond the end of the stream read as zero (the preamble view pads with zeros)
-        long long left = a.src_abs1 - (A0 + (long long)tid * SPC);      // samples of this chip inside the stream
+        const long long left = a.src_abs1 - (A0 + (long long)t * SPC);    // samples of this chip inside the stream
         const int nin = left >= SPC ? SPC : (left <= 0 ? 0 : (int)left);
 #pragma unroll
         for (int i = 0; i < SPC; ++i)
             if (i >= nin) bb[i] = 0.0f;
     }
-    // ---- phase A2: chip totals in both directions, bb -> ring ------------------------------------------------
-    if (chip_thread) {
+    {
+        // chip totals in both directions (canonical level-1 sums); spare lanes contribute zeros to the scans
         float f = 0.0f, b = 0.0f;
 #pragma unroll
         for (int i = 0; i < SPC; ++i) f = f + bb[i];
 #pragma unroll
         for (int i = SPC - 1; i >= 0; --i) b = b + bb[i];
-        L.TOT[slotA] = f;
-        L.RTOT[slotA] = b;
-        float4 *xp = reinterpret_cast<float4 *>(L.X + slotA * FE3_XS);
+        if (!chip_thread) f = 0.0f;
+        // exclusive prefix / suffix of the 48 chip totals of this wave's block, strictly sequential (canonical
+        // order): x <- x(lane-1) + f repeated 47 times leaves lane j with ((f0 + f1) + ...) + fj (a lane's value is
+        // final after j rounds and is recomputed identically afterwards); the same right->left from lane 47
+        float xs = f, ys = f;
+        if (!(FE3_ABLATE & 8)) {
 #pragma unroll
-        for (int k = 0; k < SPC / 4; ++k) {
-            float4 t;
-            t.x = bb[4 * k]; t.y = bb[4 * k + 1]; t.z = bb[4 * k + 2]; t.w = bb[4 * k + 3];
-            xp[k] = t;
+            for (int r = 0; r < AM_CHIPS_AVG - 1; ++r) {
+                xs = fe3_from_prev_lane(xs, 0.0f, lane) + f;
+                ys = fe3_from_next_lane(ys, 0.0f, lane) + f;
+            }
+        }
+        const float pt = fe3_from_prev_lane(xs, 0.0f, lane);
+        const float st = fe3_from_next_lane(ys, 0.0f, lane);
+        if (chip_thread) {
+            L.RTOT[slotA] = b;
+            L.PT[slotA] = pt;
+            L.ST[slotA] = st;
+            float4 *xp = reinterpret_cast<float4 *>(L.X + slotA * FE3_XS);
+#pragma unroll
+            for (int k = 0; k < SPC / 4; ++k) {
+                float4 u;
+                u.x = bb[4 * k]; u.y = bb[4 * k + 1]; u.z = bb[4 * k + 2]; u.w = bb[4 * k + 3];
+                xp[k] = u;
+            }
         }
     }
-    FE3_STAMP(3);
-    fe3_barrier();                                                    // B3: ring and totals of this step complete
-    FE3_STAMP(4);
-
-    // ---- in-block scans of the two new blocks (4 helper lanes: block x direction), canonical sequential order.
-    // Blocks start at multiples of 16 slots, so groups of four consecutive chips never straddle the ring's end.
-    if (!(FE3_ABLATE & 8) && tid >= FE3_S && tid < FE3_S + 4) {
-        const int blk = (tid - FE3_S) >> 1;
-        const int s0 = fe3_wrap_up(slot0 + blk * AM_CHIPS_AVG);
-        float t[AM_CHIPS_AVG];
-#pragma unroll
-        for (int g = 0; g < AM_CHIPS_AVG / 4; ++g) {
-            const float4 v = *reinterpret_cast<const float4 *>(L.TOT + fe3_wrap_up(s0 + 4 * g));
-            t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
-        }
-        float acc = 0.0f;
-        float *dst = L.PT;
-        if (tid & 1) {
-            dst = L.ST;
-#pragma unroll
-            for (int j = AM_CHIPS_AVG - 1; j >= 0; --j) { const float v = t[j]; t[j] = acc; acc = acc + v; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < AM_CHIPS_AVG; ++j) { const float v = t[j]; t[j] = acc; acc = acc + v; }
-        }
-#pragma unroll
-        for (int g = 0; g < AM_CHIPS_AVG / 4; ++g) {
-            float4 v;
-            v.x = t[4 * g]; v.y = t[4 * g + 1]; v.z = t[4 * g + 2]; v.w = t[4 * g + 3];
-            *reinterpret_cast<float4 *>(dst + fe3_wrap_up(s0 + 4 * g)) = v;
-        }
-    }
+    FE3_STAMP(1);
+    fe3_barrier();                                                    // B3: ring, totals and scans of this step complete
+    FE3_STAMP(2);
     if (!test) {                                                      // (uniform) ring rebuild only
-        fe3_barrier();                                                // B4
+        if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
         return;
     }
-    // phase B works on chip q = (this thread's phase-A chip) - 9
+
+    // ---- phase B on chip q = (this thread's phase-A chip) - 9: reference level (a4) + first-stage test (a6) --------
     const int slotB = fe3_wrap_dn(slotA - FE3_LAG);
     const int slotS = fe3_wrap_dn(slotB - AM_CHIPS_AVG);              // the chip 48 chips back
-    float x[SPC], scv[SPC];
+    float x[SPC], avgv[SPC];
     float nxt;
     {
+        float scv[SPC];
         const float4 *xp = reinterpret_cast<const float4 *>(L.X + slotB * FE3_XS);
         const float4 *sp = reinterpret_cast<const float4 *>(L.X + slotS * FE3_XS);
 #pragma unroll
         for (int k = 0; k < SPC / 4; ++k) {
-            const float4 t = xp[k];
-            x[4 * k] = t.x; x[4 * k + 1] = t.y; x[4 * k + 2] = t.z; x[4 * k + 3] = t.w;
+            const float4 u = xp[k];
+            x[4 * k] = u.x; x[4 * k + 1] = u.y; x[4 * k + 2] = u.z; x[4 * k + 3] = u.w;
         }
 #pragma unroll
         for (int k = 0; k < SPC / 4; ++k) {
-            const float4 t = sp[k];
-            scv[4 * k] = t.x; scv[4 * k + 1] = t.y; scv[4 * k + 2] = t.z; scv[4 * k + 3] = t.w;
+            const float4 u = sp[k];
+            scv[4 * k] = u.x; scv[4 * k + 1] = u.y; scv[4 * k + 2] = u.z; scv[4 * k + 3] = u.w;
         }
         nxt = L.X[fe3_wrap_up(slotB + 1) * FE3_XS];
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = SPC - 1; i >= 0; --i) { acc = acc + scv[i]; scv[i] = acc; }   // in-chip suffix sums, 48 chips back
-    }
-    FE3_STAMP(5);
-    fe3_barrier();                                                    // B4: PT / ST of the new blocks
-    FE3_STAMP(6);
-
-    // ---- phase B: reference level (a4) + first-stage test (a6) ------------------------------------------------
-    const int jb = (tid + AM_CHIPS_AVG - FE3_LAG) % AM_CHIPS_AVG;     // chip index inside its 48-chip block
-    float avgv[SPC];
-    {
         const int slotS1 = fe3_wrap_up(slotS + 1);
         const float pt = L.PT[slotB];
         const float st_a = L.ST[slotS];
         const float suf_last = L.RTOT[slotS1] + L.ST[slotS1];
+        const int jb = (t + AM_CHIPS_AVG - FE3_LAG) % AM_CHIPS_AVG;   // chip index inside its 48-chip block
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = SPC - 1; i >= 0; --i) { acc = acc + scv[i]; scv[i] = acc; }   // in-chip suffix sums, 48 chips back
+        }
         float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < SPC; ++i) {
@@ -451,7 +358,8 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         }
     }
     // array coordinate of x[0]
-    const long long jrun = (long long)step * FE3_T + (long long)(tid * SPC - FE3_LAG * SPC);
+    const long long jstep = (long long)step * FE3_T - (long long)(FE3_LAG * SPC);
+    const long long jrun = jstep + (long long)(t * SPC);
     uint32_t cm = 0u;
     {
         constexpr int CH = 16;
@@ -486,8 +394,8 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             cm |= part;
         };
         if (!(FE3_ABLATE & 4)) {
-        pass(std::integral_constant<int, 0>{});
-        pass(std::integral_constant<int, CH>{});
+            pass(std::integral_constant<int, 0>{});
+            pass(std::integral_constant<int, CH>{});
         }
 #else
         // (host build of the same source for the CPU-fiber tests: the predicate as plain C++)
@@ -528,150 +436,166 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         cm &= keep;
     }
     if (!chip_thread) cm = 0u;
-    // candidate word, per-wave count, chips with candidates
-    if (chip_thread) a.bits[(size_t)step * FE3_S + tid] = cm;
-    {
-        uint32_t cnt = (uint32_t)__popcll((unsigned long long)cm);
-        for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, AM_WAVE);
-        const unsigned long long hm = __ballot(cm != 0u);
-        if (lane == 0) {
-            a.seg_cnt[(size_t)step * 2 + wv] = cnt;
-            L.MASK[par * 4 + wv * 2] = (uint32_t)hm;
-            if (wv == 0) L.MASK[par * 4 + 1] = (uint32_t)(hm >> 32);
+    // candidate word, per-wave count
+    if (chip_thread) a.bits[(size_t)step * FE3_S + t] = cm;
+    uint32_t cnt = (uint32_t)__popcll((unsigned long long)cm);
+    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, AM_WAVE);
+    if (lane == 0) a.seg_cnt[(size_t)step * 2 + wv] = cnt;
+    const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
+    FE3_STAMP(3);
+    if (FE3_ABLATE & 1) { if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw); return; }
+    // ---- sparse outputs ---------------------------------------------------------------------------------------------
+    // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
+    // always).  The values exist only in registers: the flagged lanes park them in a small LDS buffer, four chips at
+    // a time, and the wave writes them out with coalesced stores like bb above.
+    if (!(FE3_ABLATE & 16)) {
+        const unsigned long long wa = (cand | (cand << 1) | 1ull) & ((1ull << AM_CHIPS_AVG) - 1ull);
+        const int nav = __popcll(wa);
+        uint32_t *tab = L.TAB + wv * AM_WAVE;
+        float *avs = L.AVS + wv * (4 * FE3_XS);
+        const bool mine = ((wa >> lane) & 1ull) != 0ull;
+        const int my_rank = __popcll(wa & ((1ull << lane) - 1ull));
+        if (mine) tab[my_rank] = (uint32_t)lane;
+        float *const dst = a.avg_sparse + jstep;
+        const long long lo64 = -jstep, hi64 = a.out_n - jstep;
+        const int lo = lo64 <= 0 ? 0 : (lo64 > 0x7FFFFFF ? 0x7FFFFFF : (int)lo64);
+        const int hi = hi64 <= 0 ? 0 : (hi64 > 0x7FFFFFF ? 0x7FFFFFF : (int)hi64);
+        const int sub = lane >> 3, piece = lane & 7;
+        for (int r0 = 0; r0 < nav; r0 += 4) {                         // (uniform trip count)
+            if (mine && my_rank >= r0 && my_rank < r0 + 4) {
+                float4 *d = reinterpret_cast<float4 *>(avs + (my_rank - r0) * FE3_XS);
+#pragma unroll
+                for (int k = 0; k < SPC / 4; ++k) {
+                    float4 u;
+                    u.x = avgv[4 * k]; u.y = avgv[4 * k + 1]; u.z = avgv[4 * k + 2]; u.w = avgv[4 * k + 3];
+                    d[k] = u;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int r = r0 + sub;
+            if (sub < 4 && r < nav) {
+                const int tc = wv * AM_CHIPS_AVG + (int)tab[r];
+                const float4 u = *reinterpret_cast<const float4 *>(avs + sub * FE3_XS + 4 * piece);
+                const int rel = tc * SPC + 4 * piece;
+                if (!edge || (rel >= lo && rel + 4 <= hi)) *reinterpret_cast<float4 *>(dst + rel) = u;
+                else {
+                    if (rel >= lo && rel < hi) dst[rel] = u.x;
+                    if (rel + 1 >= lo && rel + 1 < hi) dst[rel + 1] = u.y;
+                    if (rel + 2 >= lo && rel + 2 < hi) dst[rel + 2] = u.z;
+                    if (rel + 3 >= lo && rel + 3 < hi) dst[rel + 3] = u.w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    FE3_STAMP(7);
-    fe3_barrier();                                                    // B5: chip masks of this step
-    FE3_STAMP(8);
-    // ---- sparse outputs: bb for the 17 chips from a candidate's chip on, avg for 2 -----------------------------------
-    if (chip_thread && !(FE3_ABLATE & 1)) {
-        // bit i of `win` = chip (tid - 31 + i) has a candidate, chips before this step come from the previous mask
-        const uint32_t *cur = L.MASK + par * 4, *prv = L.MASK + (par ^ 1) * 4;
-        const int w = tid >> 5, sh = tid & 31;
-        const uint32_t hi = cur[w], lo = (w == 0) ? prv[2] : cur[w - 1];
-        const unsigned long long both = ((unsigned long long)hi << 32) | lo;     // chips 32(w-1) .. 32(w+1)-1
-        const uint32_t win = (uint32_t)(both >> (sh + 1));                       // bit 31 = own chip
-        const bool want_bb = (win >> (32 - FE3_BBW)) != 0u;
-        const bool want_avg = (win >> 30) != 0u;
-        const bool inside = !edge || (jrun >= 0 && jrun + SPC <= a.out_n);
-        if (want_bb && inside) {
-            float4 *d = reinterpret_cast<float4 *>(a.bb_sparse + jrun);
-#pragma unroll
-            for (int k = 0; k < SPC / 4; ++k) {
-                float4 t;
-                t.x = x[4 * k]; t.y = x[4 * k + 1]; t.z = x[4 * k + 2]; t.w = x[4 * k + 3];
-                d[k] = t;
-            }
+#if FE3_LOAD_EARLY
+    // raw IQ of the next step (the reference-level registers are free now): in flight under the bb copy and the wait at
+    // the step's last barrier
+    if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
+#endif
+    // bb: the 17 chips from a candidate's chip on, copied from the ring (phase A is 9 chips ahead: chips up to test index
+    // 104 are there) with fully coalesced stores: the flagged chips are ranked, and every wave-instruction moves eight of
+    // them, 8 lanes x 16 bytes = one 128-byte line each.  (A lane storing its own chip's 128 bytes from registers issues
+    // 8 stores that touch one line per lane: store-issue bound, measured 5x slower.)  A wave's mask covers 64 chips from
+    // its first one: wave 0 thereby serves the first 16 chips of wave 1 where its own candidates reach; what wave 1's
+    // candidates need beyond the step is handed to the next step's wave 0 (CARRY).
+    {
+        unsigned long long need = cand;                               // dilate by 16 chips to the right
+        need |= need << 1; need |= need << 2; need |= need << 4; need |= need << 8;
+        need |= cand << 16;
+        if (wv == 0) need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.CARRY[par ^ 1]);
+        else {
+            if (lane == 0) L.CARRY[par] = (uint32_t)(need >> AM_CHIPS_AVG) & 0xFFFFu;
+            need &= (1ull << AM_CHIPS_AVG) - 1ull;
         }
-        if (want_avg && inside) {
-            float4 *d = reinterpret_cast<float4 *>(a.avg_sparse + jrun);
-#pragma unroll
-            for (int k = 0; k < SPC / 4; ++k) {
-                float4 t;
-                t.x = avgv[4 * k]; t.y = avgv[4 * k + 1]; t.z = avgv[4 * k + 2]; t.w = avgv[4 * k + 3];
-                d[k] = t;
-            }
-        }
-        if ((want_bb || want_avg) && !inside) {
-            // ragged end of the stream: element by element
-            const long long left = a.out_n - jrun;
-            const int i1 = left >= SPC ? SPC : (left <= 0 ? 0 : (int)left);
-            const int i0 = jrun >= 0 ? 0 : (jrun <= -SPC ? SPC : (int)(-jrun));
-#pragma unroll
-            for (int i = 0; i < SPC; ++i) {
-                if (i >= i0 && i < i1) {
-                    if (want_bb) a.bb_sparse[jrun + i] = x[i];
-                    if (want_avg) a.avg_sparse[jrun + i] = avgv[i];
+        const int nflag = __popcll(need);
+        uint32_t *tab = L.TAB + wv * AM_WAVE;
+        __builtin_amdgcn_wave_barrier();                              // (the table is reused: the reference level's reads come first)
+        if ((need >> lane) & 1ull) tab[__popcll(need & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+        __builtin_amdgcn_wave_barrier();                              // (one wave: its LDS accesses execute in order)
+        float *const dst = a.bb_sparse + jstep;                       // array coordinate of test index 0 (may lie before the array)
+        const long long lo64 = -jstep, hi64 = a.out_n - jstep;        // elements [lo, hi) of this step's coordinates exist
+        const int lo = lo64 <= 0 ? 0 : (lo64 > 0x7FFFFFF ? 0x7FFFFFF : (int)lo64);
+        const int hi = hi64 <= 0 ? 0 : (hi64 > 0x7FFFFFF ? 0x7FFFFFF : (int)hi64);
+        const int sub = lane >> 3, piece = lane & 7;
+        for (int r0 = 0; r0 < nflag; r0 += 8) {                       // (uniform trip count)
+            const int r = r0 + sub;
+            if (r < nflag) {
+                const int tc = wv * AM_CHIPS_AVG + (int)tab[r];       // test index of the chip, <= 103
+                const int slot = fe3_wrap_dn(fe3_wrap_up(slot0 + tc) - FE3_LAG);
+                const float4 u = *reinterpret_cast<const float4 *>(L.X + slot * FE3_XS + 4 * piece);
+                const int rel = tc * SPC + 4 * piece;
+                if (!edge || (rel >= lo && rel + 4 <= hi)) *reinterpret_cast<float4 *>(dst + rel) = u;
+                else {
+                    if (rel >= lo && rel < hi) dst[rel] = u.x;
+                    if (rel + 1 >= lo && rel + 1 < hi) dst[rel + 1] = u.y;
+                    if (rel + 2 >= lo && rel + 2 < hi) dst[rel + 2] = u.z;
+                    if (rel + 3 >= lo && rel + 3 < hi) dst[rel + 3] = u.w;
                 }
             }
         }
     }
+#if !FE3_LOAD_EARLY
+    // raw IQ of the next step: in flight during the wait at the step's last barrier
+    if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
+#endif
 }
 
 __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 {
     HIP_DYNAMIC_SHARED(unsigned char, smem);
     fe3_smem L;
-    L.raw = smem;
-    L.X = reinterpret_cast<float *>(smem + (FE3_DMA ? FE3_RAWB : 0));
-    L.TOT = L.X + FE3_CR * FE3_XS;
-    L.RTOT = L.TOT + FE3_CR;
+    // (arrays read or written 16 bytes at a time first: their sizes are multiples of 16 bytes)
+    L.X = reinterpret_cast<float *>(smem);
+    L.SB0 = L.X + FE3_CR * FE3_XS;
+    L.M47 = L.SB0 + 64;
+    L.AVS = L.M47 + 32;
+    L.RTOT = L.AVS + 2 * 4 * FE3_XS;
     L.PT = L.RTOT + FE3_CR;
     L.ST = L.PT + FE3_CR;
-    L.SB0 = L.ST + FE3_CR;
-    L.SB1 = L.SB0 + 64;
-    L.MASK = reinterpret_cast<uint32_t *>(L.SB1 + 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned raw_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
-#else
-    const unsigned raw_lds = 0;
-#endif
-    const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
+    L.CARRY = reinterpret_cast<uint32_t *>(L.ST + FE3_CR);
+    L.TAB = L.CARRY + 2;
+    const int tid = threadIdx.x;
     const int sb = (int)(blockIdx.x * a.steps_per_wg);
     if (sb >= (int)a.nsteps) return;
     const int se = (sb + (int)a.steps_per_wg < (int)a.nsteps) ? sb + (int)a.steps_per_wg : (int)a.nsteps;
 
-    fe3_thread T;
-    {
-        const int t = tid < FE3_S ? tid : 0;
-        T.raw_addr = (unsigned)t * 256u + (((unsigned)t & 15u) << 4);          // = t*256 ^ swizzle (low 8 bits of t*256 are 0)
-        // wave-instruction j = 4g + r of a wave moves LDS pieces [64 j', 64 j' + 64), j' = 12 wave + j: lane l is chip
-        // 4 j' + (l >> 4), slot l & 15 of that chip, i.e. the chip's piece (l & 15) ^ ((4 r + (l >> 4)) & 15)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const unsigned k = ((unsigned)lane & 15u) ^ ((4u * (unsigned)r + ((unsigned)lane >> 4)) & 15u);
-            T.dma_off[r] = ((unsigned)lane >> 4) * 256u + k * 16u;
-        }
-    }
-    // rings start empty; the first step's chip 0 has no predecessor (its bb is never used); chips before the
-    // segment count as "had candidates" so that the first 17 chips' bb is always written
-    for (int i = tid; i < FE3_CR * FE3_XS + 4 * FE3_CR + 96; i += FE3_NT) L.X[i] = 0.0f;
-    if (tid < 8) L.MASK[tid] = 0xFFFFFFFFu;
-#if !FE3_DMA
+    // rings start empty; the first step's chip 0 has no predecessor (its bb is never used); the bb of the first 16
+    // chips of a segment is always written (the candidates of the previous segment's tail are not known here)
+    for (int i = tid; i < FE3_CR * FE3_XS + 96 + 2 * 4 * FE3_XS + 3 * FE3_CR; i += FE3_NT) L.X[i] = 0.0f;
+    if (tid < 2) L.CARRY[tid] = 0xFFFFu;
     fe3_barrier();                                                    // (the first step stages into the ring right away)
-#endif
 
-    int step = sb - 1;                                                // the step before the segment rebuilds the rings
-    bool fast = step >= a.raw_lo && step < a.raw_hi;
-#if FE3_DMA
-    if (fast)
-        fe3_issue_dma(reinterpret_cast<const unsigned char *>(a.iq) + (size_t)((a.out_abs0 + (long long)step * FE3_T) - a.src_abs0) * 8,
-                      L, T, raw_lds, wv, lane);
-#else
-    (void)raw_lds; (void)lane; (void)wv;
-#endif
     int slot0 = 0, par = 0;
     fe3_prof PR;
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     for (int k = 0; k < 12; ++k) PR.acc[k] = 0;
     PR.last = (long long)__builtin_readcyclecounter();
 #endif
-    for (; step < se; ++step) {
+    fe3_raw raw;
+    bool have = (sb - 1) >= a.raw_lo && (sb - 1) < a.raw_hi;          // the step's raw samples are in `raw`
+    if (have) fe3_load_step(a, a.out_abs0 + (long long)(sb - 1) * FE3_T, tid, raw);
+    for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
-        const bool next_fast = (step + 1 < se) && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
-        const bool edge = !fast || (test && !(step >= a.test_lo && step < a.test_hi));
-        FE3_STAMP(9);
-#if FE3_DMA
-        if (fast) fe3_dma_wait();
-        else {
-            fe3_barrier();                                            // (the staging buffer may still be read)
-            fe3_fill_raw_guarded(a, L, a.out_abs0 + (long long)step * FE3_T, tid);
-        }
-#else
-        if (fast) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+        const bool edge = !have || (test && !(step >= a.test_lo && step < a.test_hi));
+        const bool next_fast = step + 1 < se && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
+        FE3_STAMP(4);
+        // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
+        if (have) fe3_store_step(L, slot0, tid, raw);
         else fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
-#endif
-        FE3_STAMP(10);
-        fe3_barrier();                                                // B1: raw of this step landed (all waves); LDS reuse
+        FE3_STAMP(5);
+        fe3_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
-        fe3_step(a, L, T, raw_lds, step, test, slot0, par, next_fast, edge, PR);
-        fast = next_fast;
+        fe3_step(a, L, step, test, slot0, par, edge, next_fast, raw, PR);
+        have = next_fast;
         slot0 = fe3_wrap_up(slot0 + FE3_S);
         par ^= 1;
+        FE3_STAMP(6);
+        fe3_barrier();                                                // B5: every ring read of this step done
     }
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    if (a.prof && lane == 0)
-        for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * 2 + wv) * 12 + k] = PR.acc[k];
+    if (a.prof && (tid & (AM_WAVE - 1)) == 0)
+        for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * 2 + tid / AM_WAVE) * 12 + k] = PR.acc[k];
 #endif
 }
 
@@ -745,12 +669,16 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     hipError_t lrc = hipGetLastError();
 #if defined(FE3_PROFILE)
     if (a.prof) {
+        int occ = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(&am_k_fe3), FE3_NT, FE3_LDS_BYTES);
+        fprintf(stderr, "fe3: grid %u, %u steps per workgroup, %d bytes of LDS, runtime says %d workgroups per CU\n", grid, spw,
+                (int)FE3_LDS_BYTES, occ);
         std::vector<long long> h((size_t)grid * 24);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), a.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         (void)hipFree(a.prof);
-        static const char *names[12] = {"B1wait", "A1 raw+chains", "B2wait", "A2 pmf+totals+ring", "B3wait", "scan|B1 loads",
-                                        "B4wait", "B2 avg+test", "B5wait", "sparse+loop", "dma wait", "-"};
+        static const char *names[12] = {"B1wait", "A pmf+totals+scans+ring", "B3wait", "B avg+test", "B5wait", "stage (wait loads, lds)",
+                                        "next loads+sparse", "-", "-", "-", "-", "-"};
         for (int w = 0; w < 2; ++w) {
             double acc[12] = {};
             for (unsigned b = 0; b < grid; ++b)
@@ -759,9 +687,8 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
             double tot = 0;
             for (int k = 0; k < 11; ++k) tot += acc[k];
             fprintf(stderr, "fe3 clocks/step wave %d (total %.0f):", w, tot / steps);
-            // order of execution: 10 (dma wait) 0 (B1) 1 2 3 4 5 6 7 8 9
-            static const int order[11] = {10, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
-            for (int k = 0; k < 11; ++k) fprintf(stderr, " %s:%.0f", names[order[k]], acc[order[k]] / steps);
+            static const int order[7] = {5, 0, 1, 2, 3, 6, 4};       // order of execution
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %s:%.0f", names[order[k]], acc[order[k]] / steps);
             fprintf(stderr, "\n");
         }
     }

@@ -43,7 +43,7 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
                          unsigned *ntiles, unsigned *tile_len, hipStream_t s);
 /* streaming fused front end (am_fe3.hip; 32 samples per chip): persistent workgroups, LDS-DMA staging, sparse
  * outputs.  Candidates leave as a bitmap: bit b of word w = array coordinate w*32 + b - am_fe3_lag(); seg_cnt holds
- * the number of candidates per (step, wave): wave 0 = words 0..63 of a step's 96, wave 1 = words 64..95. */
+ * the number of candidates per (step, wave): wave w = words 48w .. 48w+47 of a step's 96. */
 int am_fe3_supported(int spc);
 unsigned am_fe3_tile(void);                 /* positions per step (3072) */
 unsigned am_fe3_lag(void);                  /* 288 */
@@ -51,10 +51,11 @@ unsigned am_fe3_steps(long long out_n);
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *seg_cnt, unsigned *nsteps, hipStream_t s);
-/* flat candidate positions + dcount from the bitmap; blk_off = exclusive scan of seg_cnt (2 segments per step) */
-hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *blk_off, uint32_t nseg, uint32_t M, int spc,
-                                 uint32_t lag, uint32_t *pos, uint32_t *dcount, hipStream_t s,
-                                 const uint32_t *Mp = nullptr);
+/* flat candidate positions + dcount from the bitmap; off_local / blk_base = two-level exclusive scan of seg_cnt
+ * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals; 2 segments per step) */
+hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
+                                 const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
+                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr);
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,

@@ -444,18 +444,21 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 // Word w, bit b = array coordinate 32*w + b - lag.  dcount needs the distance to the candidate before, capped
 // at spc + 1 <= 64: the two words in front of a word are all the history it can need.
 __global__ void __launch_bounds__(AM_WAVE)
-am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ blk_off, uint32_t nseg, uint32_t Mcap,
-                 int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
+am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ seg_cnt,
+                 const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t nseg,
+                 uint32_t Mcap, int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
                  const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t seg = blockIdx.x;
-    const uint32_t off = blk_off[seg], cnt = blk_off[seg + 1u] - off;
-    if (cnt == 0 || off >= M) return;                        // uniform
+    const uint32_t cnt = seg_cnt[seg];
+    if (cnt == 0) return;                                    // uniform
+    const uint32_t off = off_local[seg] + blk_base[seg / AM_SCAN_BLK];   // two-level exclusive scan of seg_cnt
+    if (off >= M) return;
     const int lane = threadIdx.x;
     const uint32_t half = seg & 1u;
-    const uint32_t nw = half ? 32u : 64u;                    // words of this segment
-    const size_t w = (size_t)(seg >> 1) * 96u + half * 64u + (uint32_t)lane;
+    const uint32_t nw = 48u;                                 // words of this segment (one wave = one 48-chip block)
+    const size_t w = (size_t)(seg >> 1) * 96u + half * 48u + (uint32_t)lane;
     uint32_t word = 0, p1 = 0, p2 = 0;
     if ((uint32_t)lane < nw) {
         word = bits[w];
@@ -490,12 +493,14 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
     }
 }
 
-hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *blk_off, uint32_t nseg, uint32_t M, int spc,
-                                 uint32_t lag, uint32_t *pos, uint32_t *dcount, hipStream_t s, const uint32_t *Mp)
+hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
+                                 const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
+                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0 || nseg == 0) return hipSuccess;
     if (spc + 1 > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(am_k_gather_bits, dim3(nseg), dim3(AM_WAVE), 0, s, bits, blk_off, nseg, M, spc, lag, pos, dcount, Mp);
+    hipLaunchKernelGGL(am_k_gather_bits, dim3(nseg), dim3(AM_WAVE), 0, s, bits, seg_cnt, off_local, blk_base, nseg, M, spc,
+                       lag, pos, dcount, Mp);
     return hipGetLastError();
 }
 
@@ -1389,15 +1394,27 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     const float2 *iq2 = reinterpret_cast<const float2 *>(iq);
     const long long wlo = ae - (spc - 1);
     if (pmf) {
-        for (int k = tid; k < nwin; k += 256) {
-            const long long n = wlo + k;
-            float mv = 0.0f;
-            if (n >= src_abs0 && n < src_abs1) {
-                const float2 t = iq2[n - src_abs0];
-                const float r = t.x * t.x, q = t.y * t.y;
-                mv = r + q;
+        // two samples (16 bytes) per lane where the source allows it
+        const long long rel = wlo - src_abs0;
+        const bool wide = (reinterpret_cast<uintptr_t>(iq) & 15u) == 0;
+        const long long n0 = wlo - (wide ? (rel & 1) : 0);           // first sample of pair 0 (even offset into iq)
+        const int npair = (int)((wlo + nwin - n0 + 1) >> 1);
+        const float4 *iq4 = reinterpret_cast<const float4 *>(iq);
+        for (int q = tid; q < npair; q += 256) {
+            const long long n = n0 + 2 * (long long)q;
+            float m0 = 0.0f, m1 = 0.0f;
+            if (wide && n >= src_abs0 && n + 1 < src_abs1) {
+                const float4 t = iq4[(n - src_abs0) >> 1];
+                const float r0 = t.x * t.x, q0 = t.y * t.y, r1 = t.z * t.z, q1 = t.w * t.w;
+                m0 = r0 + q0;
+                m1 = r1 + q1;
+            } else {
+                if (n >= src_abs0 && n < src_abs1) { const float2 t = iq2[n - src_abs0]; const float r = t.x * t.x, qq = t.y * t.y; m0 = r + qq; }
+                if (n + 1 >= src_abs0 && n + 1 < src_abs1) { const float2 t = iq2[n + 1 - src_abs0]; const float r = t.x * t.x, qq = t.y * t.y; m1 = r + qq; }
             }
-            W[k + (k >> 5)] = mv;
+            const int k = (int)(n - wlo);
+            if (k >= 0 && k < nwin) W[k + (k >> 5)] = m0;
+            if (k + 1 >= 0 && k + 1 < nwin) W[k + 1 + ((k + 1) >> 5)] = m1;
         }
         __syncthreads();
     }
