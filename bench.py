@@ -1,26 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Mode-S receive hot path on MI355X.
 
-A "step" is one pass of the whole hot path (IQ -> packet list) over one batch of synthetic
-IQ that is already resident in HBM when the timed region starts.
+A "step" is one pass of the whole hot path (IQ -> packet list) over one batch of synthetic IQ that is
+already resident in HBM when the timed region starts.
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload 64msps|2msps|20msps]
+  python bench.py [--gpus N --steps K --warmup W] [--workload 64msps|2msps|20msps] [--lambda L] [--replicas]
 
-N = 1: workload "64msps" (BASELINE.json configs[2]: synthetic 64 Msps IQ, Poisson-injected
-       Mode-S bursts in AWGN) -- `--workload 2msps` runs configs[1]'s capture instead.
-N > 1: configs[3]: the same 64 Msps stream model time-sharded over the N GPUs, one process per
-       GPU (torch.distributed over RCCL): neighbours' boundary samples are exchanged with an
-       all-gather of fixed-size halo slabs, every rank scans its chunk, the sparse candidate
-       records are all-gathered, every rank resolves the greedy chain and slices its own hits.
-       Per-GPU work is fixed as N grows ("weak").
+N = 1  workload "64msps" (BASELINE.json configs[2]: synthetic 64 Msps IQ, Poisson-injected Mode-S bursts in
+       AWGN).  The timed loop rotates over three distinct 512 MB batches (the 256 MiB Infinity Cache cannot
+       serve them), the packets of the last batch are compared with the oracle (`parity`).  The default burst
+       rate (20 000 /s, 87 % airtime) is a stress density; `realistic_density` repeats the measurement at
+       2 000 bursts/s in the same run.
+N > 1  configs[3]: one 64 Msps stream time-sharded over the N GPUs, one process per GPU (torch.distributed
+       over RCCL): neighbours' boundary samples travel in one all-gather of fixed-size halo slabs, every rank
+       scans its chunk, the scan's exit tables are all-gathered, every rank slices its own hits.  Per-GPU
+       work is fixed as N grows ("weak").  `python bench.py --gpus N` launches the N ranks itself when it is
+       not already running under torch.distributed.run.  `parity` for N > 1: a short stream through the same
+       N-rank code path against the oracle over the whole stream, plus rank 0's full-size packets against
+       the oracle over its chunk and halo.
+       --replicas: configs[4] instead -- N independent receivers (20 Msps each unless --workload says
+       otherwise), one per GPU, no collective; aggregate samples/s and packets/s, every rank checked
+       against the oracle.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the front end, the only
-kernel that touches every sample): algorithmic bytes = 8 B per complex sample.
-`cpu_baseline` is the oracle (a scalar C port of the reference path) timed on this host.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the front end, the only kernel that
+touches every sample): algorithmic bytes = 8 B per complex sample.  `cpu_baseline` is the oracle (a scalar C
+port of the reference path) timed on this host.
+
+--emu (tests only): the same orchestration on CPU -- gloo, the CPU-fiber build of the kernels (tests/emu),
+tiny sizes.  The line it prints carries "emulated": true and is not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +47,7 @@ import torch  # noqa: E402  (before the HIP library: one HIP runtime per process
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+REALISTIC_LAMBDA = 2000.0  # bursts per second of the second density
 
 
 def ctx_messages(ctx, packets):
@@ -41,115 +55,229 @@ def ctx_messages(ctx, packets):
     return [ctx.lib.format_message(packets[i:i + 1], i == 0) for i in range(len(packets))]
 
 
-def main():
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="64msps", choices=["64msps", "2msps", "20msps"])
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=None, choices=["64msps", "2msps", "20msps"])
     ap.add_argument("--seconds", type=float, default=None, help="signal seconds per GPU per step")
+    ap.add_argument("--lambda", dest="lam", type=float, default=None, help="bursts per second (default: the workload's)")
+    ap.add_argument("--batches", type=int, default=3, help="distinct batches the timed loop rotates over (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the realistic-density and batches-in-flight figures")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (contexts/streams driven by host threads)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 3-batches-in-flight figure (profiling runs)")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
-    args = ap.parse_args()
+    ap.add_argument("--replicas", action="store_true", help="N independent receivers, one per GPU (configs[4])")
+    ap.add_argument("--emu", action="store_true", help="tests only: CPU emulation of the kernels, gloo")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one process per GPU ourselves
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        dist.init_process_group("gloo" if args.emu else "nccl", rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+    if args.emu:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+
+    def sync():
+        if not args.emu:
+            torch.cuda.synchronize()
 
     import synth
     from air_modes import _capi
 
-    rate, secs, lam, seed = synth.CONFIGS[args.workload]
+    lib = _capi.Library(os.path.join(ROOT, "tests", "emu", "libairmodes_emu.so")) if args.emu else None
+    mode = "replicas" if (args.replicas and world >= 1) else ("sharded" if (world > 1 or args.force_sharded) else "single")
+    workload = args.workload or ("20msps" if args.replicas else "64msps")
+    rate, secs, lam, seed = synth.CONFIGS[workload]
     if args.seconds is not None:
         secs = args.seconds
+    if args.lam is not None:
+        lam = args.lam
     n = int(round(rate * secs))                       # samples per GPU per step
     spc = int(rate / 2e6)
-    iq, truth = synth.synth_capture(rate, n, lam, seed + rank)
-    ctx = _capi.Context(rate, 7.0, True, device=local)
 
-    if world == 1 and not args.force_sharded:
-        d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)
-        torch.cuda.synchronize()
+    def new_ctx():
+        return _capi.Context(rate, 7.0, True, device=(0 if args.emu else local), lib=lib) if lib is not None else \
+            _capi.Context(rate, 7.0, True, device=local)
 
-        def step():
-            return ctx.process_iq_device(d_iq.data_ptr(), n, flush=True)
+    ctx = new_ctx()
+    extra = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    if mode in ("single", "replicas"):
+        nb = max(1, args.batches if mode == "single" else 1)
+        host_batches = [synth.synth_capture(rate, n, lam, seed + rank + 100 * b)[0] for b in range(nb)]
+        d_batches = [torch.from_numpy(b.view(np.float32)).to(dev) for b in host_batches]
+        sync()
+        inflight = max(1, args.inflight) if mode == "single" else 1
+        ctxs = [ctx] + [new_ctx() for _ in range(inflight - 1)]
+
+        def run_steps(count, ctxs_, flight, batches):
+            import threading
+            last = [None] * flight
+            fe = [[] for _ in range(flight)]
+
+            def worker(w):
+                c = ctxs_[w]
+                for k in range(w, count, flight):
+                    last[w] = (k, c.process_iq_device(batches[k % len(batches)].data_ptr(), n, flush=True))
+                    fe[w].append(c.last_dom_ms())
+            if flight == 1:
+                worker(0)
+            else:
+                ths = [threading.Thread(target=worker, args=(w,)) for w in range(flight)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+            done = [x for x in last if x is not None]
+            k_last, pk_last = max(done, key=lambda x: x[0]) if done else (None, None)
+            return k_last, pk_last, [x for f in fe for x in f]
+
+        def timed(count, ctxs_, flight, batches):
+            if world > 1:
+                dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            k_last, pk, fe_ms = run_steps(count, ctxs_, flight, batches)
+            sync()
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0, k_last, pk, fe_ms
+
+        # untimed: every context past its first (allocating) and second (capacity) call, every batch seen once
+        per_batch = []
+        for b in range(nb):
+            per_batch.append(len(ctx.process_iq_device(d_batches[b].data_ptr(), n, flush=True)))
+        run_steps(max(args.warmup, 2 * inflight), ctxs, inflight, d_batches)
+        dt, k_last, pk, fe_ms = timed(args.steps, ctxs, inflight, d_batches)
+        last_batch = (k_last % nb) if k_last is not None else 0
+        npk_steps = sum(per_batch[k % nb] for k in range(args.steps))
+        if mode == "single" and not args.no_extra and not args.no_pipelined and inflight == 1 and args.steps >= 3:
+            # the same steps with 3 batches in flight (3 contexts / HIP streams driven by 3 host threads): the
+            # launch-latency-bound tail of one batch overlaps the streaming kernel of the next
+            c3 = [ctx] + [new_ctx() for _ in range(2)]
+            run_steps(9, c3, 3, d_batches)
+            dt3, _, _, _ = timed(args.steps, c3, 3, d_batches)
+            extra["pipelined"] = {"batches_in_flight": 3, "value": n * args.steps / dt3, "unit": "samples/s",
+                                  "ms_per_step": dt3 / args.steps * 1e3}
+        if mode == "single" and not args.no_extra and lam != REALISTIC_LAMBDA:
+            iq_r = synth.synth_capture(rate, n, REALISTIC_LAMBDA, seed + 7)[0]
+            d_r = [torch.from_numpy(iq_r.view(np.float32)).to(dev)]
+            run_steps(3, [ctx], 1, d_r)
+            ks = max(5, args.steps // 2)
+            dtr, _, pkr, fer = timed(ks, [ctx], 1, d_r)
+            fe_r = float(np.mean(fer)) if fer else 0.0
+            extra["realistic_density"] = {
+                "bursts_per_second": REALISTIC_LAMBDA, "value": n * ks / dtr, "unit": "samples/s",
+                "ms_per_step": dtr / ks * 1e3, "packets_per_step": len(pkr), "kernel_ms": fe_r,
+                "roofline_frac": (8.0 * n / (fe_r * 1e-3) / 1e9 / HBM_PEAK_GBS) if fe_r > 0 else 0.0}
+            if not args.no_cpu_baseline:
+                import oracle
+                extra["realistic_density"]["parity"] = bool(np.array_equal(pkr, oracle.demod(iq_r, rate, 7.0, True)))
+            run_steps(2, [ctx], 1, d_batches)          # back to the main density (capacity estimate of the context)
+        iq_check = host_batches[last_batch]
+        parity = None
+        if mode == "replicas":
+            import oracle
+            ok = bool(np.array_equal(pk, oracle.demod(iq_check, rate, 7.0, True)))
+            if world > 1:
+                t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = bool(t[0].item() > 0.5)
+            parity = ok
+    # ------------------------------------------------------------------------------------------------------------
     else:
         # time-sharded: rank r owns samples [r*n, (r+1)*n) of one stream of world*n samples
         from air_modes.sharded import ShardedReceiver
+        iq = synth.synth_capture(rate, n, lam, seed + rank)[0]
         rx = ShardedReceiver(ctx, rank, world, n, device=dev)
         rx.chunk.copy_(torch.from_numpy(iq.view(np.float32)))     # resident in HBM before the timed region
-        torch.cuda.synchronize()
-
-        def step():
-            return rx.step()
-
-    # Steps are independent batches (each ends its stream with a flush), so `inflight` of them can be
-    # in flight at once: one context + HIP stream per host thread; while one batch is in its
-    # launch-latency-bound tail (greedy chain, slicer) the next batch's streaming kernel fills the GPU.
-    inflight = max(1, args.inflight) if (world == 1 and not args.force_sharded) else 1
-    ctxs = [ctx] + [_capi.Context(rate, 7.0, True, device=local) for _ in range(inflight - 1)]
-
-    def run_steps(count):
-        import threading
-        results = [None] * inflight
-        fe = [[] for _ in range(inflight)]
-
-        def worker(w):
-            c = ctxs[w]
-            for k in range(w, count, inflight):
-                if world == 1 and not args.force_sharded:
-                    results[w] = c.process_iq_device(d_iq.data_ptr(), n, flush=True)
-                else:
-                    results[w] = step()
-                fe[w].append(c.last_dom_ms())
-        if inflight == 1:
-            worker(0)
+        sync()
+        fe_ms = []
+        pk = None
+        for _ in range(max(args.warmup, 2)):
+            pk = rx.step()
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pk = rx.step()
+            fe_ms.append(ctx.last_dom_ms())
+        sync()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        npk_steps = len(pk) * args.steps
+        inflight, nb, per_batch = 1, 1, [len(pk)]
+        # parity, part 1: a short stream through the same N-rank path against the oracle over the WHOLE stream
+        import oracle
+        ns = max(4 * max(rx.left, rx.right), 30000 * spc)
+        whole = synth.synth_capture(rate, world * ns, lam, 4242)[0]
+        ctx_s = new_ctx()
+        rx_s = ShardedReceiver(ctx_s, rank, world, ns, device=dev)
+        rx_s.chunk.copy_(torch.from_numpy(whole[rank * ns:(rank + 1) * ns].copy().view(np.float32)))
+        mine = rx_s.step()
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, mine.tobytes())
+            got = np.concatenate([np.frombuffer(p, _capi.PACKET_DTYPE) for p in parts])
         else:
-            ths = [threading.Thread(target=worker, args=(w,)) for w in range(inflight)]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-        last = [r for r in results if r is not None]
-        return last[-1] if last else None, [x for f in fe for x in f]
+            got = mine
+        parity_small = bool(np.array_equal(got, oracle.demod(whole, rate, 7.0, True)))
+        # part 2: rank 0's full-size packets against the oracle over its chunk + the halo it received from rank 1
+        parity_rank0 = None
+        if rank == 0:
+            hl, hr = rx.left, rx.right
+            view = rx._buf[hl * 2:(hl + n + (hr if world > 1 else 0)) * 2].cpu().numpy().view(np.complex64)
+            want = oracle.demod(view, rate, 7.0, True) if world > 1 else oracle.demod(view, rate, 7.0, True)
+            if world > 1:
+                # the oracle saw a stream that ends after the halo: packets of this chunk are those the scan reaches
+                # before it leaves the chunk -- a prefix; what follows starts in the halo
+                keep = want[:len(pk)]
+                rest = want[len(pk):]
+                parity_rank0 = bool(np.array_equal(pk, keep) and (len(rest) == 0 or int(rest["sample"][0]) >= n - 2 * spc))
+            else:
+                parity_rank0 = bool(np.array_equal(pk, want))
+        parity = parity_small if parity_rank0 is None else bool(parity_small and parity_rank0)
+        extra["parity_detail"] = {"short_stream_all_ranks": parity_small, "rank0_full_size": parity_rank0,
+                                  "short_stream_samples_per_rank": ns}
+        iq_check = iq
 
-    pk, _ = run_steps(max(args.warmup, 3 * inflight if args.warmup else 0))
+    # ------------------------------------------------------------------------------------------------------------
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pk, fe_ms = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    npk = len(pk)
-    pipelined = None
-    if world == 1 and not args.force_sharded and inflight == 1 and args.steps >= 3 and not args.no_pipelined:
-        # additional figure: the same steps with 3 batches in flight (3 contexts / HIP streams driven by
-        # 3 host threads): the launch-latency-bound tail of one batch overlaps the streaming kernel of the
-        # next.  Reported separately so that `value`, `roofline` and the rocprof summaries stay one-to-one.
-        inflight = 3
-        ctxs = [ctx] + [_capi.Context(rate, 7.0, True, device=local) for _ in range(inflight - 1)]
-        run_steps(3 * inflight)            # every context past its first (allocating) and second (capacity) call
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        pk3, _ = run_steps(args.steps)
-        torch.cuda.synchronize()
-        dt3 = time.perf_counter() - t1
-        pipelined = {"batches_in_flight": 3, "value": n * args.steps / dt3, "unit": "samples/s",
-                     "ms_per_step": dt3 / args.steps * 1e3, "same_packets": bool(np.array_equal(pk3, pk))}
-        inflight = 1
-    if world > 1:
-        t = torch.tensor([dt, float(npk)], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, float(npk_steps)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -157,62 +285,74 @@ def main():
         dt = float(tmax[0].item())
         npk_total = int(tsum[1].item())
     else:
-        npk_total = npk
+        npk_total = npk_steps
 
     if rank == 0:
         total_samples = world * n * args.steps
         value = total_samples / dt
         fe_avg_ms = float(np.mean(fe_ms)) if fe_ms else 0.0
-        achieved = (8.0 * (n + (0 if world == 1 else 0))) / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
-        fused = spc in (1, 2, 4, 5, 8, 10, 16, 20, 32)
-        kernel_name = ("am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc) if fused \
-            else "am_k_frontend"
+        achieved = 8.0 * n / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
+        fe_kind = ctx.last_frontend()
+        kernel_name = {3: "am_k_fe3 (streaming fused |iq|^2 + PMF + reference level + preamble detection, sparse outputs)",
+                       2: "am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc}.get(fe_kind, "am_k_frontend")
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "current_traffic.json")
-        if world == 1 and os.path.exists(tj):
+        if mode == "single" and os.path.exists(tj) and not args.emu:
             with open(tj) as f:
                 t = json.load(f)
-            if t.get("workload") == args.workload and args.seconds is None:
+            if t.get("workload") == workload and args.seconds is None and args.lam is None and t.get("kernel", "") in kernel_name:
                 traffic = t["traffic_bytes"]
                 traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        par = {"single": "single GPU", "replicas": "%d independent receivers, one per GPU, no collective" % world,
+               "sharded": "time-chunk shards x%d, RCCL halo exchange + scan exit-table all-gather" % world}[mode]
         res = {
             "metric": "complex samples/sec demodulated (IQ -> Mode-S packet list)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "packets_per_sec": npk_total * args.steps / dt, "packets_per_step": npk_total,
+            "packets_per_sec": npk_total / dt, "packets_per_step": npk_total / args.steps,
             "config": {"workload": "%s synthetic IQ, %.3g s per GPU per step (%d complex samples), Poisson %g "
-                                   "bursts/s in AWGN, seed %d+rank, threshold 7 dB, pmf on%s"
-                                   % (args.workload, secs, n, lam, seed,
-                                      "" if world == 1 else ", one stream time-sharded over %d GPUs" % world),
+                                   "bursts/s in AWGN, seed %d+rank(+100*batch), threshold 7 dB, pmf on%s"
+                                   % (workload, secs, n, lam, seed,
+                                      {"single": "", "replicas": ", %d independent streams" % world,
+                                       "sharded": ", one stream time-sharded over %d GPUs" % world}[mode]),
                        "rate_sps": rate, "samples_per_gpu_per_step": n, "batches_in_flight": inflight,
-                       "parallelism": "single GPU" if world == 1 else "time-chunk shards x%d, RCCL halo exchange + scan exit-table all-gather" % world},
+                       "distinct_batches": nb, "packets_per_batch": per_batch, "bursts_per_second": lam,
+                       "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel_ms": fe_avg_ms,
                          "algorithmic_bytes_per_launch": 8 * n},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.emu:
+            res["emulated"] = True
+        if parity is not None:
+            res["parity"] = parity
+        if not args.no_cpu_baseline and not args.emu or (args.emu and mode == "single"):
             import oracle
             t1 = time.perf_counter()
-            want = oracle.demod(iq, rate, 7.0, True)
+            want = oracle.demod(iq_check, rate, 7.0, True)
             cpu_dt = time.perf_counter() - t1
             res["cpu_baseline"] = {"value": n / cpu_dt, "unit": "samples/s", "cores": 1, "kind": "port",
-                                   "sample": "the same %d-sample batch, one pass of oracle/airmodes_oracle.c "
+                                   "sample": "one %d-sample batch of this run, one pass of oracle/airmodes_oracle.c "
                                              "(scalar C, gcc -O2, 1 thread), %.2f s" % (n, cpu_dt),
                                    "host_cores_available": os.cpu_count()}
-            res["parity"] = bool(np.array_equal(pk, want))
+            if mode == "single":
+                res["parity"] = bool(np.array_equal(pk, want))
             res["speedup_vs_cpu_baseline"] = value / (n / cpu_dt)
+        if mode == "single" and not args.no_cpu_baseline and not args.emu:
+            import oracle
             # the same port on every host core: the batch cut into one time chunk per thread (each with the
             # look-ahead a chunk needs), timed only -- SURVEY 8(d) asks for both figures
             from concurrent.futures import ThreadPoolExecutor
             P = max(1, os.cpu_count() or 1)
             halo = 400 * spc
             cuts = [(k * n) // P for k in range(P + 1)]
+
             def chunk(k):
                 a, b = cuts[k], min(n, cuts[k + 1] + halo)
-                return len(oracle.demod(iq[a:b], rate, 7.0, True))
+                return len(oracle.demod(iq_check[a:b], rate, 7.0, True))
             with ThreadPoolExecutor(P) as ex:
                 list(ex.map(chunk, range(min(P, 8))))            # threads up, library loaded
                 best = None
@@ -221,16 +361,20 @@ def main():
                     list(ex.map(chunk, range(P)))
                     d = time.perf_counter() - t2
                     best = d if best is None or d < best else best
+            res["cpu_baseline_all_cores"] = {"value": n / best, "unit": "samples/s", "cores": P, "kind": "port",
+                                             "sample": "the same batch cut into %d time chunks (+%d samples of "
+                                                       "look-ahead each), one oracle thread per chunk, best of 3 "
+                                                       "passes, %.3f s" % (P, halo, best)}
             # the reference's OWN C++ (lib/preamble_impl.cc, slicer_impl.cc, modes_crc.cc compiled by path into
             # oracle/_ref, which travels with the repository) behind the port's front end, where it exists:
             # bounded sample, messages compared with the GPU path's
             if oracle.have_ref():
                 nr = min(n, 8 * 1000 * 1000)
                 t3 = time.perf_counter()
-                rbb, ravg = oracle.frontend(iq[:nr], spc, True)
+                rbb, ravg = oracle.frontend(iq_check[:nr], spc, True)
                 rmsgs = oracle.ref_preamble_slicer(rbb, ravg, spc, 7.0, rate)[2]
                 ref_dt = time.perf_counter() - t3
-                sub = ctx.process_iq(iq[:nr], flush=True)
+                sub = ctx.process_iq(iq_check[:nr], flush=True)
                 res["cpu_baseline_reference"] = {
                     "value": nr / ref_dt, "unit": "samples/s", "cores": 1, "kind": "reference",
                     "sample": "the first %d samples of the batch: port front end (|iq|^2, PMF, reference level) + "
@@ -238,12 +382,7 @@ def main():
                               "against the GNU Radio API stub, 1 thread, %.2f s" % (nr, ref_dt),
                     # (the reference driver also reports hits past the canonical end of the stream: a prefix match)
                     "messages_match_gpu": bool(rmsgs[:len(sub)] == ctx_messages(ctx, sub) and len(sub) > 0)}
-            res["cpu_baseline_all_cores"] = {"value": n / best, "unit": "samples/s", "cores": P, "kind": "port",
-                                             "sample": "the same batch cut into %d time chunks (+%d samples of "
-                                                       "look-ahead each), one oracle thread per chunk, best of 3 "
-                                                       "passes, %.3f s" % (P, halo, best)}
-        if pipelined:
-            res["pipelined"] = pipelined
+        res.update(extra)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

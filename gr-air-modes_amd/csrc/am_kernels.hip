@@ -440,22 +440,24 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
     }
 }
 
-// Flat candidate positions from the streaming front end's bitmap (am_fe3.hip): one wave per (step, wave) segment.
+// Flat candidate positions from the streaming front end's bitmap (am_fe3.hip): one wave per (step, wave) segment,
+// four segments per workgroup.
 // Word w, bit b = array coordinate 32*w + b - lag.  dcount needs the distance to the candidate before, capped
 // at spc + 1 <= 64: the two words in front of a word are all the history it can need.
-__global__ void __launch_bounds__(AM_WAVE)
+__global__ void __launch_bounds__(4 * AM_WAVE)
 am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ seg_cnt,
                  const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t nseg,
                  uint32_t Mcap, int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
                  const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t seg = blockIdx.x;
+    const uint32_t seg = blockIdx.x * 4u + threadIdx.x / AM_WAVE;
+    if (seg >= nseg) return;                                 // (wave-uniform; no workgroup barrier below)
     const uint32_t cnt = seg_cnt[seg];
-    if (cnt == 0) return;                                    // uniform
+    if (cnt == 0) return;
     const uint32_t off = off_local[seg] + blk_base[seg / AM_SCAN_BLK];   // two-level exclusive scan of seg_cnt
     if (off >= M) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t half = seg & 1u;
     const uint32_t nw = 48u;                                 // words of this segment (one wave = one 48-chip block)
     const size_t w = (size_t)(seg >> 1) * 96u + half * 48u + (uint32_t)lane;
@@ -499,7 +501,7 @@ hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, 
 {
     if (M == 0 || nseg == 0) return hipSuccess;
     if (spc + 1 > 64) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(am_k_gather_bits, dim3(nseg), dim3(AM_WAVE), 0, s, bits, seg_cnt, off_local, blk_base, nseg, M, spc,
+    hipLaunchKernelGGL(am_k_gather_bits, dim3((nseg + 3u) / 4u), dim3(4 * AM_WAVE), 0, s, bits, seg_cnt, off_local, blk_base, nseg, M, spc,
                        lag, pos, dcount, Mp);
     return hipGetLastError();
 }

@@ -1,0 +1,51 @@
+"""bench.py's own orchestration on CPU: `--gpus N` launches the ranks itself, the N > 1 legs carry a
+parity verdict, `--replicas` runs independent receivers.  Kernels = the CPU-fiber build (tests/emu),
+collectives = gloo; the line printed is marked "emulated" and is not a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import conftest
+
+
+def run_bench(*extra):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--emu", "--steps", "2", "--warmup", "1",
+                          "--no-extra"] + list(extra), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(emu_lib):
+    d = run_bench("--workload", "20msps", "--seconds", "0.01", "--batches", "2")
+    assert d["emulated"] and d["n_gpus"] == 1 and d["parity"] is True
+    assert d["config"]["distinct_batches"] == 2 and len(d["config"]["packets_per_batch"]) == 2
+    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and "cpu_baseline" in d
+
+
+def test_gpus_2_launches_two_ranks_time_sharded(emu_lib):
+    d = run_bench("--gpus", "2", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["parity"] is True and d["parity_detail"]["short_stream_all_ranks"] is True
+    assert d["parity_detail"]["rank0_full_size"] is True
+    assert "time-chunk shards x2" in d["config"]["parallelism"]
+
+
+def test_replicas_two_receivers(emu_lib):
+    d = run_bench("--gpus", "2", "--replicas", "--seconds", "0.008", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["parity"] is True
+    assert "independent receivers" in d["config"]["parallelism"]
+    assert d["config"]["rate_sps"] == 20e6
+
+
+def test_lambda_knob(emu_lib):
+    d = run_bench("--workload", "20msps", "--seconds", "0.01", "--lambda", "500", "--batches", "1")
+    assert d["config"]["bursts_per_second"] == 500 and d["parity"] is True
