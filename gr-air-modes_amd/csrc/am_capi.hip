@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <new>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -75,6 +76,7 @@ struct am_ctx {
     bool total_pending = false;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
+    bool poison = false;          // AIRMODES_POISON=1 (tests): NaN-fill the sparse bb / reference-level arrays before every scan
     bool allow_fe3 = true;        // AIRMODES_FE=2 keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
     // extraction recomputes from these samples (they must stay valid until the scan's hits are sliced)
@@ -225,7 +227,13 @@ hipError_t wait_for_ticket(am_ctx *c, uint32_t seq)
     const double t0 = am_now_us();
     unsigned spins = 0;
     while (*word != seq) {
-        if ((++spins & 1023u) == 0 && am_now_us() - t0 > 50000.0) return hipStreamSynchronize(c->stream);
+        if ((++spins & 255u) == 0) {
+            // a scan takes a fraction of a millisecond: spin that long, then give the core away between looks,
+            // and after 50 ms block in the runtime
+            const double waited = am_now_us() - t0;
+            if (waited > 50000.0) return hipStreamSynchronize(c->stream);
+            if (waited > 2000.0) std::this_thread::yield();
+        }
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return hipSuccess;
@@ -409,6 +417,11 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         ENSURE(c, c->blk_off, ((size_t)ns * 2 + 9) * sizeof(uint32_t));
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
         unsigned nsteps = 0;
+        if (c->poison) {
+            // test aid (AIRMODES_POISON=1): whatever the sparse arrays are read for must have been written by this scan
+            HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->avg.p, 0xFF, out_n * sizeof(float), c->stream));
+        }
         HIPCHK(c, am_launch_fe3(src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
                                 (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
@@ -512,12 +525,12 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
         if (c->pin_tags) (void)hipHostFree(c->pin_tags);
         c->pin_packets = nullptr; c->pin_tags = nullptr; c->pin_cap = 0;
         const size_t want = (size_t)n_max + n_max / 4 + 64;
-        HIPCHK(c, hipHostMalloc((void **)&c->pin_packets, want * sizeof(am_packet), hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->pin_tags, want * sizeof(am_tag), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_packets, want * sizeof(am_packet), hipHostMallocCoherent | hipHostMallocMapped));
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_tags, want * sizeof(am_tag), hipHostMallocCoherent | hipHostMallocMapped));
         c->pin_cap = (uint32_t)want;
     }
     if (!c->pin_scalars) {
-        HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
         memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));     // [0..2] results of the slice launch, [8] completion ticket
     }
     HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
@@ -672,6 +685,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->force_generic = g && g[0] == '1';
             const char *fe = getenv("AIRMODES_FE");
             c->allow_fe3 = !(fe && fe[0] == '2');
+            const char *po = getenv("AIRMODES_POISON");
+            c->poison = po && po[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");
             c->allow_spec = !(sp && sp[0] == '1');
             if (const char *sf = getenv("AIRMODES_SPEC_FLOOR")) c->spec_floor = atof(sf);
@@ -1034,16 +1049,19 @@ int am_slicer_work(am_ctx *c, const float *bursts, const am_tag *tags, uint64_t 
 // modes_crc.cc:55-63 semantics (generator 0xFFF409, zero start value), byte-serial
 uint32_t am_crc24(const uint8_t *data, int nbytes)
 {
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
-        for (uint32_t v = 0; v < 256; v++) {
-            uint32_t r = v << 16;
-            for (int k = 0; k < 8; k++) r = (r & 0x800000u) ? ((r << 1) ^ 0xFFF409u) : (r << 1);
-            table[v] = r & 0xFFFFFFu;
+    struct Table {
+        uint32_t v[256];
+        Table()
+        {
+            for (uint32_t b = 0; b < 256; b++) {
+                uint32_t r = b << 16;
+                for (int k = 0; k < 8; k++) r = (r & 0x800000u) ? ((r << 1) ^ 0xFFF409u) : (r << 1);
+                v[b] = r & 0xFFFFFFu;
+            }
         }
-        ready = true;
-    }
+    };
+    static const Table tab;                                     // (function-local static: initialised once, thread-safe)
+    const uint32_t *table = tab.v;
     uint32_t r = 0;
     for (int i = 0; i < nbytes; i++) r = ((r << 8) ^ table[((r >> 16) ^ data[i]) & 0xFFu]) & 0xFFFFFFu;
     return r;
@@ -1147,7 +1165,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         n_dev = (uint32_t)std::min<uint64_t>(M, lead + 1);
         uint32_t actual = M;
         if (!c->pin_scalars) {
-            HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocDefault));
+            HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
             memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));
         }
         if (n_dev) {
@@ -1156,7 +1174,7 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
                 if (c->pin_exit) (void)hipHostFree(c->pin_exit);
                 c->pin_exit = nullptr; c->pin_exit_cap = 0;
                 HIPCHK(c, hipHostMalloc((void **)&c->pin_exit, ((size_t)n_dev + 64) * sizeof(am_shard_exit),
-                                        hipHostMallocDefault));
+                                        hipHostMallocCoherent | hipHostMallocMapped));
                 c->pin_exit_cap = n_dev + 64;
             }
             HIPCHK(c, am_launch_chain_exit_table((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, n_dev,
@@ -1182,7 +1200,10 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     c->last_dom_ms = 0.0f;
     if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
     uint64_t nt = 0;
-    for (uint32_t i = 0; i < n_dev; i++) {
+    // (a capacity launch may have written an end marker {pos = ~0} behind the last real candidate: not an entry)
+    const uint32_t n_real = (uint32_t)std::min<uint64_t>(n_dev, c->last_M);
+    for (uint32_t i = 0; i < n_real; i++) {
+        if (c->pin_exit[i].pos == ~(uint64_t)0) break;
         nt = i + 1;
         if (c->pin_exit[i].pos >= lead_end) break;              // first candidate past the lead-in: last entry
     }

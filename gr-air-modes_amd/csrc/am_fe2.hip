@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -134,12 +135,23 @@ __device__ __forceinline__ void fe2_store_tile(const float *X, int lhp, float *d
     }
 }
 
-// phase stamps (profiling builds of the host set a.clk): lane 0 of wave 0 and of wave 5
+// Profiling builds only (-DFE2_PROFILING=1, tools/build_variants.sh): phase stamps (lane 0 of wave 0 and of wave 5),
+// phase ablation, start-up stagger and LDS reservation from the environment.  The default build contains none of
+// it: no environment variable can change what the kernel computes.
+#ifndef FE2_PROFILING
+#define FE2_PROFILING 0
+#endif
+#if FE2_PROFILING
+#define FE2_ABL(a) ((a).ablate)
 #define FE2_STAMP(k)                                                                            \
     do {                                                                                       \
         if (a.clk && (tid == 0 || tid == 5 * AM_WAVE))                                          \
             a.clk[(size_t)tile * 32 + (tid ? 16 : 0) + (k)] = (long long)clock64();             \
     } while (0)
+#else
+#define FE2_ABL(a) 0u
+#define FE2_STAMP(k) do { } while (0)
+#endif
 
 #include "am_fe_cmpx.h"
 
@@ -246,7 +258,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
         const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
         const long long len = a.src_abs1 - a.src_abs0;
         const bool vec = (rel0 & 1) == 0 && (reinterpret_cast<uintptr_t>(a.iq) & 15u) == 0 && len >= 2;
-        if (a.ablate & 16u) {
+        if (FE2_ABL(a) & 16u) {
             for (int i = tid; i < fe2_padn(LHP + T + RH); i += FE2_NT) X[i] = 1.0f;
         } else if (vec) {
             const float4 *iq4 = reinterpret_cast<const float4 *>(a.iq);
@@ -323,7 +335,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
 
     // ---- P2: pulse matched filter (a3), registers; P3: chip totals -----------------------------
     // halo chip first (its temporaries die before the run's registers come alive)
-    const bool do_pmf = a.use_pmf && SPC > 1 && !(a.ablate & 1u);
+    const bool do_pmf = a.use_pmf && SPC > 1 && !(FE2_ABL(a) & 1u);
     float hb[SPC] = {};
     if (has_halo) {
         fe2_lds_load<SPC, CHIP_AL, CHIP_IG>(X, chip_base(hq), hb);
@@ -387,7 +399,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
 
     // ---- P4: exclusive prefix / suffix of chip totals inside each 48-chip block ----------------
     // (the 48 totals are fetched in one batch; the additions keep the canonical sequential order)
-    if (!(a.ablate & 2u))
+    if (!(FE2_ABL(a) & 2u))
     for (int idx = tid; idx < 2 * NBLK; idx += FE2_NT) {
         const int qb = 1 + AM_CHIPS_AVG * (idx >> 1);
         float t[AM_CHIPS_AVG];
@@ -413,7 +425,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     const uint32_t jt0 = (uint32_t)(tile0 - a.out_abs0);   // array coordinate of the tile start
     // bb out (coalesced, from X) as soon as it is complete in LDS: the writes drain under the reference
     // level / detection / list phases instead of holding the finished workgroup's resources
-    if (a.bb && !(a.ablate & 4u)) fe2_store_tile<T, EDGE>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
+    if (a.bb && !(FE2_ABL(a) & 4u)) fe2_store_tile<T, EDGE>(X, LHP, a.bb, (long long)jt0, a.out_n, tid);
 
     // ---- P5: reference level (a4) + first-stage preamble test (a6) ------------------------------
 #if defined(__HIP_DEVICE_COMPILE__) && FE2_NO_PREFIX_CSE
@@ -425,7 +437,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     for (int i = 0; i < R; ++i) asm volatile("" : "+v"(bbv[i]));
 #endif
     float avgv[R];
-    if (a.ablate & 2u) {
+    if (FE2_ABL(a) & 2u) {
 #pragma unroll
         for (int i = 0; i < R; ++i) avgv[i] = bbv[i];
     } else
@@ -455,7 +467,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
             avgv[k * SPC + i] = s * a.sL;
         }
     }
-    if (a.avg && !(a.ablate & 8u)) {
+    if (a.avg && !(FE2_ABL(a) & 8u)) {
         // block-level API only (am_frontend_work): dense reference level, one 4*R-byte run per lane
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -469,7 +481,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
     // wide LDS loads.  The result is folded into one bit per sample at the end.
     static_assert(R <= 32, "one candidate word per thread");
     uint32_t cm = 0u;
-    if (!(a.ablate & 64u)) {
+    if (!(FE2_ABL(a) & 64u)) {
         constexpr int CH = (R % 16 == 0) ? 16 : R;           // samples per pass (scalar register budget)
         static_assert(R % CH == 0, "passes tile the run");
         const float nxt = X[fe2_pidx(run_base + R)];
@@ -557,7 +569,7 @@ __device__ __forceinline__ void fe2_tile(const am_fe2_args &a, const unsigned ti
 
     // the refinement kernels need avg[e] for e in a candidate's run or the next one;
     // write those runs only (plus the tile's first run, for candidates at the end of the previous tile)
-    if (a.avg_sparse && !(a.ablate & 64u)) {
+    if (a.avg_sparse && !(FE2_ABL(a) & 64u)) {
         const bool need = tid == 0 || RUNANY[tid] != 0u || RUNANY[tid - 1] != 0u;
         if (need) {
 #pragma unroll
@@ -625,7 +637,7 @@ __global__ void __launch_bounds__(FE2_NT, FE2_WPS) am_k_fe2(am_fe2_args a)
     const unsigned fwd = (blockIdx.x % 8u) * per + blockIdx.x / 8u;
     if (fwd >= nb) return;                                  // whole workgroup (uniform)
     const unsigned tile = nb - 1u - fwd;
-    if (a.ablate & 1024u) { if (threadIdx.x == 0) a.blk_cnt[tile] = 0; return; }
+    if (FE2_ABL(a) & 1024u) { if (threadIdx.x == 0) a.blk_cnt[tile] = 0; return; }
     if (a.stagger && blockIdx.x < a.stagger_n) {
         // first round of workgroups (one per CU): spread their start over `stagger` clocks so that the
         // CUs do not all load, and then all compute, at the same time
@@ -636,19 +648,21 @@ __global__ void __launch_bounds__(FE2_NT, FE2_WPS) am_k_fe2(am_fe2_args a)
     const long long rel0 = a.out_abs0 + jt0 - LH - a.src_abs0;
     const bool interior = rel0 >= 1 && rel0 + W + 2 <= a.src_abs1 - a.src_abs0 &&
                           (reinterpret_cast<uintptr_t>(a.iq) & 15u) == 0 && jt0 >= (long long)a.j0 &&
-                          jt0 + T <= (long long)a.j1 && jt0 + T <= a.out_n && !(a.ablate & (16u | 2048u));
+                          jt0 + T <= (long long)a.j1 && jt0 + T <= a.out_n && !(FE2_ABL(a) & (16u | 2048u));
     if (interior) fe2_tile<SPC, CPT, false>(a, tile, smem);
     else fe2_tile<SPC, CPT, true>(a, tile, smem);
 }
 
 static int ncu_for_stagger()
 {
-    static int ncu = 0;
+    static std::atomic<int> ncu_cache{0};
+    int ncu = ncu_cache.load(std::memory_order_relaxed);
     if (ncu == 0) {
         hipDeviceProp_t prop;
         int dev = 0;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        ncu_cache.store(ncu, std::memory_order_relaxed);
     }
     return ncu;
 }
@@ -664,20 +678,23 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
                        sizeof(float);
     am_fe2_args a = a_in;
     size_t lds_req = lds;
+#if FE2_PROFILING
     if (const char *x = getenv("AIRMODES_FE2_LDS_EXTRA")) lds_req += (size_t)atoi(x);   // occupancy experiments
+#endif
     a.ntiles = (unsigned)((a.out_n + T - 1) / T);
     *ntiles = a.ntiles;
     *tile_len = T;
     if (a.ntiles == 0) return hipSuccess;
     // (once per device and LDS size: the call is not free and this launch is on the critical path)
-    static size_t attr_lds[64] = {};
+    // (contexts may be driven from several host threads: the cache is atomic, setting the attribute twice is harmless)
+    static std::atomic<size_t> attr_lds[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || attr_lds[dev] != lds_req) {
+    if (dev < 0 || dev >= 64 || attr_lds[dev].load(std::memory_order_acquire) != lds_req) {
         hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe2<SPC, CPT>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_req);
         if (rc != hipSuccess) return rc;
-        if (dev >= 0 && dev < 64) attr_lds[dev] = lds_req;
+        if (dev >= 0 && dev < 64) attr_lds[dev].store(lds_req, std::memory_order_release);
     }
     const unsigned grid = ((a.ntiles + 7u) / 8u) * 8u;     // whole XCD rounds (extra groups exit)
     // Workgroups that start together stay in lockstep (same work per tile): the whole chip would load
@@ -687,9 +704,15 @@ static hipError_t fe2_launch(const am_fe2_args &a_in, hipStream_t s, unsigned *n
     // later workgroups inherit the offsets because each starts when its CU becomes free.
     a.stagger = (SPC >= 8) ? 1300u * (unsigned)R : 0u;
     a.stagger_n = (unsigned)ncu_for_stagger();
+#if FE2_PROFILING
     if (const char *x = getenv("AIRMODES_FE2_STAGGER")) a.stagger = (unsigned)atoi(x);
+#endif
     // profiling only: per-phase clock stamps, printed as average cycles between stamps (blocking)
+#if FE2_PROFILING
     static const bool want_clk = getenv("AIRMODES_FE2_CLOCK") != nullptr;
+#else
+    const bool want_clk = false;
+#endif
     a.clk = nullptr;
     if (want_clk && hipMalloc(reinterpret_cast<void **>(&a.clk), (size_t)a.ntiles * 32 * sizeof(long long)) != hipSuccess)
         a.clk = nullptr;
@@ -741,8 +764,12 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
     a.bb = bb; a.avg = avg; a.j0 = j0; a.j1 = j1; a.seg_pos = seg_pos; a.blk_cnt = blk_cnt; a.ntiles = 0;
     a.use_pmf = use_pmf; a.s1 = s1; a.sL = sL; a.thr_lin = thr_lin;
     {
+#if FE2_PROFILING
         const char *ab = getenv("AIRMODES_FE2_ABLATE");
         a.ablate = ab ? (unsigned)atoi(ab) : 0u;
+#else
+        a.ablate = 0u;
+#endif
     }
     switch (spc) {
     // (SPC, chips per thread): run = SPC*CPT samples per thread, chosen so that the per-chip

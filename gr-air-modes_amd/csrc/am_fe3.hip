@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -610,16 +611,16 @@ static long long fe3_ceil_div(long long x, long long d) { return -fe3_floor_div(
 
 static int fe3_wgs_for_device()
 {
-    static int cached[64] = {};
+    static std::atomic<int> cached[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev] == 0) {
+    if (cached[dev].load(std::memory_order_relaxed) == 0) {
         hipDeviceProp_t prop;
         const int ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                             ? prop.multiProcessorCount : 256;
-        cached[dev] = FE3_WG_PER_CU * ncu;                            // resident workgroups (LDS)
+        cached[dev].store(FE3_WG_PER_CU * ncu, std::memory_order_relaxed);   // resident workgroups
     }
-    return cached[dev];
+    return cached[dev].load(std::memory_order_relaxed);
 }
 
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
@@ -651,14 +652,14 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     if (spw < 4) spw = 4;
     a.steps_per_wg = spw;
     const unsigned grid = (a.nsteps + spw - 1) / spw;
-    static bool attr_done[64] = {};
+    static std::atomic<bool> attr_done[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
         hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe3),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)FE3_LDS_BYTES);
         if (rc != hipSuccess) return rc;
-        if (dev >= 0 && dev < 64) attr_done[dev] = true;
+        if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
     }
     a.prof = nullptr;
 #if defined(FE3_PROFILE)

@@ -310,7 +310,9 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
             if (in[k + j] > space_thr) valid = 0;
         if (!valid) { k++; continue; }                             /* :209 */
 
-        if (ninputs - k < BURST_CHIPS * S) break;                  /* :212 end of stream */
+        /* :212 end of stream (the reference's `ninputs - i` is a signed int: a late-peak shift past ninputs counts as
+         * no room too) */
+        if (k >= ninputs || ninputs - k < BURST_CHIPS * S) break;
 
         if (hits < cap) {
             float *o = bursts + hits * BURST_CHIPS;

@@ -19,6 +19,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A plain `pytest tests` on a box without a HIP device skips the GPU tests; asked for explicitly
+    (`-m gpu`) they fail loudly instead -- there is no CPU fallback to hide behind."""
+    asked = "gpu" in (config.getoption("-m") or "")
+    if asked:
+        return
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no HIP device (run with -m gpu on the GPU box)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle

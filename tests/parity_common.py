@@ -236,3 +236,44 @@ def edge_inputs(rate, seed=5):
     nan[rng.integers(0, len(nan), 25)] = np.complex64(complex(float("inf"), -1.0))
     cases["nan_inf"] = nan
     return cases
+
+
+def nonfinite_stream(rate, n, seed=17, lam=15000.0):
+    """A stream many tiles / steps long with NaN, +-inf, huge and denormal samples sprinkled over it:
+    interior tiles of the fused kernels (their fast bodies, the EXEC-narrowing compares) see them too."""
+    iq, _ = synth.synth_capture(rate, n, lam, seed)
+    iq = iq.copy()
+    rng = np.random.default_rng(seed)
+    k = max(8, n // 4000)
+    iq[rng.integers(0, n, k)] = np.complex64(complex(float("nan"), 0.5))
+    iq[rng.integers(0, n, k)] = np.complex64(complex(float("inf"), -1.0))
+    iq[rng.integers(0, n, k)] = np.complex64(complex(-2.0, float("-inf")))
+    iq[rng.integers(0, n, k)] *= np.complex64(3e18)        # |.|^2 overflows
+    idx = rng.integers(0, n - 600, k)
+    for i in idx[:k // 2]:
+        iq[i:i + 500] *= np.complex64(1e-22)               # denormal stretches
+    return iq
+
+
+def check_front_ends_agree(lib, rate, iq, monkeypatch, thr=7.0, pmf=True, expect_streaming=True):
+    """The streaming kernel (default where it exists) and the tile kernel (AIRMODES_FE=2) against the oracle."""
+    want = oracle.demod(iq, rate, thr, pmf)
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    got = ctx.process_iq(iq, flush=True)
+    fe = ctx.last_frontend()
+    ctx.close()
+    if got.tobytes() != want.tobytes():                    # (bytes: a NaN reference level is equal to itself here)
+        m = min(len(got), len(want))
+        d = [i for i in range(m) if got[i].tobytes() != want[i].tobytes()]
+        raise AssertionError("default front end (%d) differs from the oracle: %d vs %d packets, first differences at %r: "
+                             "want %r got %r" % (fe, len(got), len(want), d[:4], [want[i] for i in d[:2]], [got[i] for i in d[:2]]))
+    if expect_streaming:
+        assert fe == 3, "the streaming front end did not run (front end %d)" % fe
+    monkeypatch.setenv("AIRMODES_FE", "2")
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    got2 = ctx.process_iq(iq, flush=True)
+    fe2 = ctx.last_frontend()
+    ctx.close()
+    monkeypatch.delenv("AIRMODES_FE")
+    assert fe2 == 2 and got2.tobytes() == want.tobytes(), "tile kernel differs from the oracle"
+    return len(want)

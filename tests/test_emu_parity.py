@@ -204,3 +204,26 @@ def test_rx_time_reference_golden(emu_lib, path):
 def test_rx_time_tags(emu_lib, rate, n):
     """am_set_rx_time: block level, streaming (tags arriving with their chunk / in advance), sharded."""
     assert pc.check_rx_time(emu_lib, rate, n, 3000.0, 91) >= 3
+
+
+def test_streaming_and_tile_front_ends_agree(emu_lib, monkeypatch):
+    """64 Msps: am_k_fe3 (default) and am_k_fe2 (AIRMODES_FE=2) give the oracle's packets, also without the
+    pulse-matched filter and with non-finite samples in interior tiles / steps."""
+    iq, _ = synth.synth_capture(64e6, 600000, 20000.0, 77)
+    assert pc.check_front_ends_agree(emu_lib, 64e6, iq, monkeypatch) > 5
+    assert pc.check_front_ends_agree(emu_lib, 64e6, iq[:400000], monkeypatch, thr=5.0, pmf=False) > 3
+    bad = pc.nonfinite_stream(64e6, 400000)
+    pc.check_front_ends_agree(emu_lib, 64e6, bad, monkeypatch)
+    # a rate without the streaming kernel: the tile kernel with non-finite samples in interior tiles
+    bad20 = pc.nonfinite_stream(20e6, 150000)
+    pc.check_front_ends_agree(emu_lib, 20e6, bad20, monkeypatch, expect_streaming=False)
+
+
+def test_streaming_front_end_unaligned_and_short_inputs(emu_lib, monkeypatch):
+    """Chunk boundaries at odd samples (8-byte aligned sources: every step takes the guarded loads), chunks shorter
+    than a step, and a context that switches between quiet and busy stretches."""
+    monkeypatch.setenv("AIRMODES_POISON", "1")     # NaN-fill the sparse arrays before every scan: no stale value can help
+    iq, _ = synth.synth_capture(64e6, 500000, 20000.0, 78)
+    want = oracle.demod(iq, 64e6)
+    assert pc.check_chunked(emu_lib, 64e6, iq, [1, 3073, 100001, 100002, 250001, 250002 + 3071], want=want) > 5
+    assert pc.check_chunked(emu_lib, 64e6, iq, list(range(7001, 500000, 7001)), want=want) > 5

@@ -226,3 +226,25 @@ def test_chain_walk_beyond_64k_of_lds(lib):
     assert np.array_equal(pk, want) and len(want) > 2000
     pc.check_sharded(lib, rate, iq, 2, thr=thr, want=want)
     ctx.close()
+
+
+def test_streaming_and_tile_front_ends_agree(lib, monkeypatch):
+    """64 Msps: am_k_fe3 (default) and am_k_fe2 (AIRMODES_FE=2) give the oracle's packets -- also without the
+    pulse-matched filter and with NaN / inf / denormal samples in INTERIOR tiles and steps (the EXEC-narrowing
+    compares of the fast bodies only exist on the device)."""
+    iq, _ = synth.synth_capture(64e6, 6000000, 20000.0, 77)
+    assert pc.check_front_ends_agree(lib, 64e6, iq, monkeypatch) > 50
+    assert pc.check_front_ends_agree(lib, 64e6, iq[:3000000], monkeypatch, thr=5.0, pmf=False) > 20
+    bad = pc.nonfinite_stream(64e6, 4000000)
+    pc.check_front_ends_agree(lib, 64e6, bad, monkeypatch)
+    for rate in (20e6, 16e6, 4e6):
+        pc.check_front_ends_agree(lib, rate, pc.nonfinite_stream(rate, 1500000), monkeypatch, expect_streaming=False)
+
+
+def test_streaming_front_end_unaligned_and_short_inputs(lib, monkeypatch):
+    monkeypatch.setenv("AIRMODES_POISON", "1")     # NaN-fill the sparse arrays before every scan: no stale value can help
+    iq, _ = synth.synth_capture(64e6, 5000000, 20000.0, 78)
+    want = oracle.demod(iq, 64e6)
+    assert pc.check_chunked(lib, 64e6, iq, [1, 3073, 1000001, 1000002, 2500001, 2500002 + 3071], want=want) > 50
+    assert pc.check_chunked(lib, 64e6, iq, list(range(70001, 5000000, 70001)), want=want) > 50
+    assert pc.check_sharded(lib, 64e6, iq, 5, want=want) > 50
