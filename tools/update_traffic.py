@@ -13,6 +13,9 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "64msps"
 
 def mean_of(section):
     part = text.split("== %s per dispatch" % section)[1]
+    m = re.search(r"am_k_fe3\(.*?mean ([0-9.e+]+)", part)
+    if m:
+        return "am_k_fe3", float(m.group(1))
     m = re.search(r"am_k_fe2<(\d+), (\d+)>.*?mean ([0-9.e+]+)", part)
     return "am_k_fe2<%s,%s>" % (m.group(1), m.group(2)), float(m.group(3))
 
@@ -24,7 +27,7 @@ doc = {"workload": workload, "kernel": kernel, "fetch_size_kib_raw": fetch, "wri
        "traffic_bytes": int(fetch * 1024 * 2 + write * 1024), "source": sys.argv[1],
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 "
                "--warmup 1 --no-cpu-baseline --no-pipelined`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 "
-               "reports half of a coalesced stream); WRITE_SIZE uncalibrated (matches the dense bb array + sparse "
-               "avg + candidate lists)"}
+               "reports half of a coalesced stream); WRITE_SIZE uncalibrated (streaming kernel: candidate bitmap + sparse bb / reference level "
+               "runs; tile kernel: dense bb + sparse reference level + candidate lists)"}
 json.dump(doc, open("profiles/current_traffic.json", "w"), indent=1)
 print(doc)
