@@ -412,9 +412,10 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     if (!avg && c->allow_fe3 && am_fe3_supported(c->spc)) {
         // streaming kernel: candidate bitmap + per-(step, wave) counts; bb and the reference level only around candidates
         const unsigned ns = am_fe3_steps((long long)out_n);
-        ENSURE(c, c->bits, ((size_t)ns * 96 + 64) * sizeof(uint32_t));
-        ENSURE(c, c->blk_cnt, ((size_t)ns * 2 + 8) * sizeof(uint32_t));
-        ENSURE(c, c->blk_off, ((size_t)ns * 2 + 9) * sizeof(uint32_t));
+        const unsigned nwv = am_fe3_waves();
+        ENSURE(c, c->bits, ((size_t)ns * 48 * nwv + 64) * sizeof(uint32_t));
+        ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
+        ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
         unsigned nsteps = 0;
         if (c->poison) {
@@ -437,7 +438,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
             const double want = c->spec_density * npos * 1.25 + c->spec_floor;
             cap3 = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
         }
-        return run_refine(c, bb, (const float *)c->avg.p, nsteps * 2, 0, 3, M_out,
+        return run_refine(c, bb, (const float *)c->avg.p, nsteps * nwv, 0, 3, M_out,
                           (uint32_t)std::min<uint64_t>(endj3, 0xFFFFFFFFull), cap3);
     }
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);

@@ -41,20 +41,23 @@
 #define FE3_ABLATE 0
 #endif
 #ifndef FE3_LOAD_EARLY
-#define FE3_LOAD_EARLY 1
+#define FE3_LOAD_EARLY 2
 #endif
 #ifndef FE3_WPS
-#define FE3_WPS 2                         /* launch bound, waves per SIMD (<= 256 VGPRs; at 168 the prefetched loads spill) */
+#define FE3_WPS 3                         /* launch bound, waves per SIMD (<= 168 VGPRs)               */
 #endif
 #ifndef FE3_WG_PER_CU
-#define FE3_WG_PER_CU 4                   /* resident workgroups per CU (8 waves of <= 256 VGPRs)      */
+#define FE3_WG_PER_CU 6                   /* resident workgroups per CU (26 KB of LDS, 2 waves of <= 168 VGPRs each) */
 #endif
 #define FE3_SPC 32
-#define FE3_S 96                          /* chips per step: two 48-chip blocks, one per wave          */
-#define FE3_NT 128                        /* two waves: lanes 0..47 = the block's chips, all 128 threads stage the loads */
+#ifndef FE3_NW
+#define FE3_NW 2                          /* waves per workgroup = 48-chip blocks per step              */
+#endif
+#define FE3_S (AM_CHIPS_AVG * FE3_NW)     /* chips per step: one 48-chip block per wave                 */
+#define FE3_NT (AM_WAVE * FE3_NW)         /* lanes 0..47 of a wave = its block's chips; all threads stage the loads */
 #define FE3_T (FE3_S * FE3_SPC)           /* samples per step                                          */
 #define FE3_LAG 9                         /* phase B runs this many chips behind phase A               */
-#define FE3_CR 154                        /* ring capacity in chips: 96 new + 9 lag + 48 back + 1           */
+#define FE3_CR (FE3_S + FE3_LAG + AM_CHIPS_AVG + 1)   /* ring capacity in chips: a step + lag + 48 back + 1 */
 #define FE3_XS 36                         /* floats per ring chip: 32 + 4 pad (16-byte reads of consecutive chips hit all banks) */
 #define FE3_BBW 17                        /* chips of bb kept from a candidate's chip on (am_k_cand reads up to pos + 16*spc) */
 
@@ -117,6 +120,36 @@ __device__ __forceinline__ float fe3_from_next_lane(float v, float last, int lan
 #endif
 }
 
+// streaming loads / stores (tuning builds compare the cache policies: FE3_NT_LOADS, FE3_NT_STORES)
+#ifndef FE3_NT_LOADS
+#define FE3_NT_LOADS 1
+#endif
+#ifndef FE3_NT_STORES
+#define FE3_NT_STORES 0
+#endif
+#if defined(__clang__)
+typedef float fe3_f4 __attribute__((ext_vector_type(4)));
+#endif
+__device__ __forceinline__ float4 fe3_gload16(const void *p)
+{
+#if FE3_NT_LOADS && defined(__HIP_DEVICE_COMPILE__)
+    const fe3_f4 t = __builtin_nontemporal_load(reinterpret_cast<const fe3_f4 *>(p));
+    float4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    return r;
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+__device__ __forceinline__ void fe3_gstore16(float *p, const float4 &u)
+{
+#if FE3_NT_STORES && defined(__HIP_DEVICE_COMPILE__)
+    fe3_f4 t; t.x = u.x; t.y = u.y; t.z = u.z; t.w = u.w;
+    __builtin_nontemporal_store(t, reinterpret_cast<fe3_f4 *>(p));
+#else
+    *reinterpret_cast<float4 *>(p) = u;
+#endif
+}
+
 // Profiling builds only (-DFE3_PROFILE, tools/build_variants.sh): cycles per phase, summed over a workgroup's steps
 // by lane 0 of each wave.  The default build contains none of it.
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -136,7 +169,7 @@ struct fe3_smem {
     uint32_t *TAB;            // [2][64] per wave: lane of the r-th chip whose bb / reference level is written
     float *AVS;               // [2][4 * FE3_XS] per wave: four chips of reference level on their way out
 };
-#define FE3_LDS_BYTES (FE3_CR * FE3_XS * 4 + 3 * 32 * 4 + 2 * 4 * FE3_XS * 4 + 3 * FE3_CR * 4 + 2 * 4 + 2 * 64 * 4)
+#define FE3_LDS_BYTES (FE3_CR * FE3_XS * 4 + (64 + 32 * (FE3_NW - 1)) * 4 + FE3_NW * 4 * FE3_XS * 4 + 3 * FE3_CR * 4 + 2 * 4 + FE3_NW * 64 * 4)
 
 struct fe3_raw { float4 v[12]; };      // a thread's 12 pieces of a step's raw IQ (piece tid + 128 j)
 
@@ -146,7 +179,7 @@ __device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0
     const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
     const unsigned off = (unsigned)tid * 16u;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) r.v[j] = *reinterpret_cast<const float4 *>(gb + (off + (unsigned)j * (FE3_NT * 16u)));
+    for (int j = 0; j < 12; ++j) r.v[j] = fe3_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
 }
 __device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int tid, const fe3_raw &r)
 {
@@ -157,9 +190,11 @@ __device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int
         float2 mm;
         mm.x = r0 + i0;                                               // a1: fl(fl(I*I) + fl(Q*Q))
         mm.y = r1 + i1;
-        const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
+        const int cc = c0 + (FE3_NT / 16) * j;                        // chip of the piece
+        const int slot = fe3_wrap_up(slot0 + cc);
         *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
-        if (j == 5 && c0 == 7) *reinterpret_cast<float2 *>(L.M47 + 2 * k) = mm;   // chip 47 = pieces 752 .. 767
+        if ((cc + 1) % AM_CHIPS_AVG == 0 && cc + 1 < FE3_S)           // the chip before a later wave's first
+            *reinterpret_cast<float2 *>(L.M47 + ((cc + 1) / AM_CHIPS_AVG - 1) * 32 + 2 * k) = mm;
     }
 }
 
@@ -185,9 +220,11 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
             float2 mm;
             mm.x = r0 + i0;
             mm.y = r1 + i1;
-            const int slot = fe3_wrap_up(slot0 + c0 + 8 * j);
+            const int cc = c0 + (FE3_NT / 16) * j;
+            const int slot = fe3_wrap_up(slot0 + cc);
             *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
-            if (j == 5 && c0 == 7) *reinterpret_cast<float2 *>(L.M47 + 2 * k) = mm;
+            if ((cc + 1) % AM_CHIPS_AVG == 0 && cc + 1 < FE3_S)
+                *reinterpret_cast<float2 *>(L.M47 + ((cc + 1) / AM_CHIPS_AVG - 1) * 32 + 2 * k) = mm;
         }
         return;
     }
@@ -230,7 +267,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
 #pragma unroll
             for (int i = SPC - 1; i >= 0; --i) { acc = acc + m[i]; sx[i] = acc; }
             // the step's last chip hands its sums to the next step's first chip
-            if (tid == AM_WAVE + AM_CHIPS_AVG - 1) {
+            if (tid == (FE3_NW - 1) * AM_WAVE + AM_CHIPS_AVG - 1) {
                 float4 *dst = reinterpret_cast<float4 *>(L.SB0 + par * 32);
 #pragma unroll
                 for (int k = 0; k < SPC / 4; ++k) {
@@ -243,7 +280,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             // wave 1: chip 47, recomputed from its staged |.|^2 (every lane reads them: a broadcast)
             float pv[SPC];
             {
-                const float4 *src = reinterpret_cast<const float4 *>((wv == 0) ? (L.SB0 + (par ^ 1) * 32) : L.M47);
+                const float4 *src = reinterpret_cast<const float4 *>((wv == 0) ? (L.SB0 + (par ^ 1) * 32) : (L.M47 + (wv - 1) * 32));
 #pragma unroll
                 for (int k = 0; k < SPC / 4; ++k) {
                     const float4 u = src[k];
@@ -313,7 +350,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     fe3_barrier();                                                    // B3: ring, totals and scans of this step complete
     FE3_STAMP(2);
     if (!test) {                                                      // (uniform) ring rebuild only
-        if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
+        if (load_next && FE3_LOAD_EARLY != 2) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
         return;
     }
 
@@ -441,10 +478,10 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     if (chip_thread) a.bits[(size_t)step * FE3_S + t] = cm;
     uint32_t cnt = (uint32_t)__popcll((unsigned long long)cm);
     for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, AM_WAVE);
-    if (lane == 0) a.seg_cnt[(size_t)step * 2 + wv] = cnt;
+    if (lane == 0) a.seg_cnt[(size_t)step * FE3_NW + wv] = cnt;
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
     FE3_STAMP(3);
-    if (FE3_ABLATE & 1) { if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw); return; }
+    if (FE3_ABLATE & 1) { if (load_next && FE3_LOAD_EARLY != 2) fe3_load_step(a, A0 + FE3_T, tid, nextraw); return; }
     // ---- sparse outputs ---------------------------------------------------------------------------------------------
     // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
     // always).  The values exist only in registers: the flagged lanes park them in a small LDS buffer, four chips at
@@ -478,7 +515,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                 const int tc = wv * AM_CHIPS_AVG + (int)tab[r];
                 const float4 u = *reinterpret_cast<const float4 *>(avs + sub * FE3_XS + 4 * piece);
                 const int rel = tc * SPC + 4 * piece;
-                if (!edge || (rel >= lo && rel + 4 <= hi)) *reinterpret_cast<float4 *>(dst + rel) = u;
+                if (!edge || (rel >= lo && rel + 4 <= hi)) fe3_gstore16(dst + rel, u);
                 else {
                     if (rel >= lo && rel < hi) dst[rel] = u.x;
                     if (rel + 1 >= lo && rel + 1 < hi) dst[rel + 1] = u.y;
@@ -489,7 +526,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             __builtin_amdgcn_wave_barrier();
         }
     }
-#if FE3_LOAD_EARLY
+#if FE3_LOAD_EARLY == 1
     // raw IQ of the next step (the reference-level registers are free now): in flight under the bb copy and the wait at
     // the step's last barrier
     if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
@@ -505,7 +542,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         need |= need << 1; need |= need << 2; need |= need << 4; need |= need << 8;
         need |= cand << 16;
         if (wv == 0) need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.CARRY[par ^ 1]);
-        else {
+        if (wv == FE3_NW - 1) {
             if (lane == 0) L.CARRY[par] = (uint32_t)(need >> AM_CHIPS_AVG) & 0xFFFFu;
             need &= (1ull << AM_CHIPS_AVG) - 1ull;
         }
@@ -526,7 +563,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                 const int slot = fe3_wrap_dn(fe3_wrap_up(slot0 + tc) - FE3_LAG);
                 const float4 u = *reinterpret_cast<const float4 *>(L.X + slot * FE3_XS + 4 * piece);
                 const int rel = tc * SPC + 4 * piece;
-                if (!edge || (rel >= lo && rel + 4 <= hi)) *reinterpret_cast<float4 *>(dst + rel) = u;
+                if (!edge || (rel >= lo && rel + 4 <= hi)) fe3_gstore16(dst + rel, u);
                 else {
                     if (rel >= lo && rel < hi) dst[rel] = u.x;
                     if (rel + 1 >= lo && rel + 1 < hi) dst[rel + 1] = u.y;
@@ -536,7 +573,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             }
         }
     }
-#if !FE3_LOAD_EARLY
+#if FE3_LOAD_EARLY == 0
     // raw IQ of the next step: in flight during the wait at the step's last barrier
     if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
 #endif
@@ -550,8 +587,8 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     L.X = reinterpret_cast<float *>(smem);
     L.SB0 = L.X + FE3_CR * FE3_XS;
     L.M47 = L.SB0 + 64;
-    L.AVS = L.M47 + 32;
-    L.RTOT = L.AVS + 2 * 4 * FE3_XS;
+    L.AVS = L.M47 + 32 * (FE3_NW - 1);
+    L.RTOT = L.AVS + FE3_NW * 4 * FE3_XS;
     L.PT = L.RTOT + FE3_CR;
     L.ST = L.PT + FE3_CR;
     L.CARRY = reinterpret_cast<uint32_t *>(L.ST + FE3_CR);
@@ -563,7 +600,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 
     // rings start empty; the first step's chip 0 has no predecessor (its bb is never used); the bb of the first 16
     // chips of a segment is always written (the candidates of the previous segment's tail are not known here)
-    for (int i = tid; i < FE3_CR * FE3_XS + 96 + 2 * 4 * FE3_XS + 3 * FE3_CR; i += FE3_NT) L.X[i] = 0.0f;
+    for (int i = tid; i < FE3_CR * FE3_XS + 64 + 32 * (FE3_NW - 1) + FE3_NW * 4 * FE3_XS + 3 * FE3_CR; i += FE3_NT) L.X[i] = 0.0f;
     if (tid < 2) L.CARRY[tid] = 0xFFFFu;
     fe3_barrier();                                                    // (the first step stages into the ring right away)
 
@@ -575,14 +612,20 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 #endif
     fe3_raw raw;
     bool have = (sb - 1) >= a.raw_lo && (sb - 1) < a.raw_hi;          // the step's raw samples are in `raw`
+#if FE3_LOAD_EARLY != 2
     if (have) fe3_load_step(a, a.out_abs0 + (long long)(sb - 1) * FE3_T, tid, raw);
+#endif
     for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
         const bool edge = !have || (test && !(step >= a.test_lo && step < a.test_hi));
         const bool next_fast = step + 1 < se && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
         FE3_STAMP(4);
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
+#if FE3_LOAD_EARLY == 2
+        if (have) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);   // no prefetch: load, wait, stage
+#else
         if (have) fe3_store_step(L, slot0, tid, raw);
+#endif
         else fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
         FE3_STAMP(5);
         fe3_barrier();                                                // B1: |.|^2 of this step staged
@@ -596,7 +639,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     }
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if (a.prof && (tid & (AM_WAVE - 1)) == 0)
-        for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * 2 + tid / AM_WAVE) * 12 + k] = PR.acc[k];
+        for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * FE3_NW + tid / AM_WAVE) * 12 + k] = PR.acc[k];
 #endif
 }
 
@@ -604,6 +647,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 int am_fe3_supported(int spc) { return spc == FE3_SPC ? 1 : 0; }
 unsigned am_fe3_tile(void) { return FE3_T; }
 unsigned am_fe3_lag(void) { return FE3_LAG * FE3_SPC; }
+unsigned am_fe3_waves(void) { return FE3_NW; }
 unsigned am_fe3_steps(long long out_n) { return (unsigned)((out_n + FE3_LAG * FE3_SPC + FE3_T - 1) / FE3_T); }
 
 static long long fe3_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
@@ -664,7 +708,7 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     a.prof = nullptr;
 #if defined(FE3_PROFILE)
     // blocking; prints mean cycles per step and phase (wave 0 / wave 1) -- never in the default build
-    if (hipMalloc(reinterpret_cast<void **>(&a.prof), (size_t)grid * 24 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&a.prof), (size_t)grid * FE3_NW * 12 * sizeof(long long)) != hipSuccess) a.prof = nullptr;
 #endif
     hipLaunchKernelGGL(am_k_fe3, dim3(grid), dim3(FE3_NT), FE3_LDS_BYTES, s, a);
     hipError_t lrc = hipGetLastError();
@@ -674,16 +718,16 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(&am_k_fe3), FE3_NT, FE3_LDS_BYTES);
         fprintf(stderr, "fe3: grid %u, %u steps per workgroup, %d bytes of LDS, runtime says %d workgroups per CU\n", grid, spw,
                 (int)FE3_LDS_BYTES, occ);
-        std::vector<long long> h((size_t)grid * 24);
+        std::vector<long long> h((size_t)grid * FE3_NW * 12);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), a.prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         (void)hipFree(a.prof);
         static const char *names[12] = {"B1wait", "A pmf+totals+scans+ring", "B3wait", "B avg+test", "B5wait", "stage (wait loads, lds)",
                                         "next loads+sparse", "-", "-", "-", "-", "-"};
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < FE3_NW; ++w) {
             double acc[12] = {};
             for (unsigned b = 0; b < grid; ++b)
-                for (int k = 0; k < 12; ++k) acc[k] += (double)h[((size_t)b * 2 + w) * 12 + k];
+                for (int k = 0; k < 12; ++k) acc[k] += (double)h[((size_t)b * FE3_NW + w) * 12 + k];
             const double steps = (double)grid * (double)(spw + 1);
             double tot = 0;
             for (int k = 0; k < 11; ++k) tot += acc[k];

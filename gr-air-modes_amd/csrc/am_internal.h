@@ -47,6 +47,7 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
 int am_fe3_supported(int spc);
 unsigned am_fe3_tile(void);                 /* positions per step (3072) */
 unsigned am_fe3_lag(void);                  /* 288 */
+unsigned am_fe3_waves(void);                /* segments (waves, 48 chips = 48 bitmap words each) per step */
 unsigned am_fe3_steps(long long out_n);
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
@@ -55,7 +56,7 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
  * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals; 2 segments per step) */
 hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
                                  const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
-                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr);
+                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr);   /* segment k = words 48k .. 48k+47 */
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,

@@ -458,9 +458,8 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
     const uint32_t off = off_local[seg] + blk_base[seg / AM_SCAN_BLK];   // two-level exclusive scan of seg_cnt
     if (off >= M) return;
     const int lane = threadIdx.x & (AM_WAVE - 1);
-    const uint32_t half = seg & 1u;
-    const uint32_t nw = 48u;                                 // words of this segment (one wave = one 48-chip block)
-    const size_t w = (size_t)(seg >> 1) * 96u + half * 48u + (uint32_t)lane;
+    const uint32_t nw = 48u;                                 // words of a segment (one wave of the front end = one 48-chip block)
+    const size_t w = (size_t)seg * 48u + (uint32_t)lane;
     uint32_t word = 0, p1 = 0, p2 = 0;
     if ((uint32_t)lane < nw) {
         word = bits[w];
