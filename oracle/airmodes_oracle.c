@@ -205,29 +205,35 @@ int amo_frontend(const float *iq, uint64_t n, int spc, int use_pmf,
     return rc;
 }
 
-/* GNU-Radio-like running sum (sum += new; out = sum*scale; sum -= old),
- * re-seeded at every multiple of `chunk` outputs.  Sensitivity study only. */
+/* GNU-Radio-like running sum (sum += new; out = sum*scale; sum -= old), re-seeded at the outputs
+ * first, first + chunk, first + 2 chunk, ... (and at 0): the scheduler-dependent part of GNU Radio 3.8's
+ * moving_average_ff (it re-seeds at the start of every work() call and every <= 4096 outputs inside one).
+ * Sensitivity study only (tools/frontend_sensitivity.py). */
 static void running_average(const float *x, uint64_t n, uint64_t len, float scale,
-                            uint32_t chunk, float *out)
+                            uint32_t chunk, uint32_t first, float *out)
 {
-    for (uint64_t o0 = 0; o0 < n; o0 += chunk) {
+    uint64_t o0 = 0;
+    uint64_t o1 = (first > 0 && first < chunk) ? first : chunk;
+    while (o0 < n) {
+        if (o1 > n) o1 = n;
         float sum = 0.0f;
         for (uint64_t i = 0; i + 1 < len; i++) {
             int64_t idx = (int64_t)o0 - (int64_t)(len - 1) + (int64_t)i;
             sum = sum + (idx >= 0 ? x[idx] : 0.0f);
         }
-        uint64_t o1 = o0 + chunk < n ? o0 + chunk : n;
         for (uint64_t o = o0; o < o1; o++) {
             sum = sum + x[o];
             out[o] = sum * scale;
             int64_t old = (int64_t)o - (int64_t)(len - 1);
             sum = sum - (old >= 0 ? x[old] : 0.0f);
         }
+        o0 = o1;
+        o1 = o0 + chunk;
     }
 }
 
-int amo_frontend_running(const float *iq, uint64_t n, int spc, int use_pmf,
-                         uint32_t chunk, float *bb, float *avg)
+int amo_frontend_running2(const float *iq, uint64_t n, int spc, int use_pmf,
+                          uint32_t chunk, uint32_t first, float *bb, float *avg)
 {
     if (spc < 1 || chunk == 0) return -1;
     if (n == 0) return 0;
@@ -235,13 +241,19 @@ int amo_frontend_running(const float *iq, uint64_t n, int spc, int use_pmf,
     if (!m) return -1;
     amo_mag2(iq, n, m);
     if (use_pmf)
-        running_average(m, n, (uint64_t)spc, (float)(1.0 / (double)spc), chunk, bb);
+        running_average(m, n, (uint64_t)spc, (float)(1.0 / (double)spc), chunk, first, bb);
     else
         memcpy(bb, m, n * sizeof(float));
     running_average(bb, n, (uint64_t)CHIPS_PER_AVG * spc,
-                    (float)(1.0 / (double)(CHIPS_PER_AVG * spc)), chunk, avg);
+                    (float)(1.0 / (double)(CHIPS_PER_AVG * spc)), chunk, first, avg);
     free(m);
     return 0;
+}
+
+int amo_frontend_running(const float *iq, uint64_t n, int spc, int use_pmf,
+                         uint32_t chunk, float *bb, float *avg)
+{
+    return amo_frontend_running2(iq, n, spc, use_pmf, chunk, 0, bb, avg);
 }
 
 /* ------------------------------------------------------------ a6 - a9 ---- */

@@ -69,6 +69,9 @@ int amo_frontend(const float *iq, uint64_t n, int spc, int use_pmf,
  * scheduler-dependent running-sum order (re-seeded every `chunk` outputs). */
 int amo_frontend_running(const float *iq, uint64_t n, int spc, int use_pmf,
                          uint32_t chunk, float *bb, float *avg);
+/* the same with the first re-seed after `first` outputs (0: after `chunk`) */
+int amo_frontend_running2(const float *iq, uint64_t n, int spc, int use_pmf,
+                          uint32_t chunk, uint32_t first, float *bb, float *avg);
 
 /* a5-a9: greedy preamble scan over the two float streams the reference block
  * sees (in = bb, inavg = avg), canonical whole-stream semantics.

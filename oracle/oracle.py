@@ -49,6 +49,7 @@ def lib():
         L.amo_mag2.argtypes = [_f32p, C.c_uint64, _f32p]
         L.amo_frontend.argtypes = [_f32p, C.c_uint64, C.c_int, C.c_int, _f32p, _f32p]
         L.amo_frontend_running.argtypes = [_f32p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, _f32p, _f32p]
+        L.amo_frontend_running2.argtypes = [_f32p, C.c_uint64, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _f32p, _f32p]
         L.amo_preamble_scan.restype = C.c_uint64
         L.amo_preamble_scan.argtypes = [_f32p, _f32p, C.c_uint64, C.c_int, C.c_float, C.c_uint64,
                                         _f32p, C.c_void_p, C.c_uint64]
@@ -112,13 +113,15 @@ def mag2(iq):
     return out
 
 
-def frontend(iq, spc, use_pmf=True, running_chunk=None):
+def frontend(iq, spc, use_pmf=True, running_chunk=None, running_first=0):
+    """bb, avg in the canonical summation order; with running_chunk: GNU Radio's running sum instead, re-seeded
+    every running_chunk outputs (the first time after running_first outputs) -- sensitivity study only."""
     f = as_iq_f32(iq)
     n = f.size // 2
     bb = np.empty(n, np.float32)
     avg = np.empty(n, np.float32)
     if running_chunk:
-        rc = lib().amo_frontend_running(f, n, spc, int(use_pmf), running_chunk, bb, avg)
+        rc = lib().amo_frontend_running2(f, n, spc, int(use_pmf), running_chunk, int(running_first), bb, avg)
     else:
         rc = lib().amo_frontend(f, n, spc, int(use_pmf), bb, avg)
     if rc != 0:
