@@ -102,6 +102,7 @@ class Library(object):
         L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
         L.am_last_num_candidates.restype = C.c_longlong
         L.am_last_num_candidates.argtypes = [vp]
+        L.am_set_stream.argtypes = [vp, vp]
         L.am_last_frontend.restype = C.c_int
         L.am_last_frontend.argtypes = [vp]
         self.L = L
@@ -194,6 +195,11 @@ class Context(object):
 
     def last_num_candidates(self):
         return int(self.lib.L.am_last_num_candidates(self._h))
+
+    def set_stream(self, hip_stream):
+        """Device work of this context goes to the caller's HIP stream (raw handle, e.g.
+        torch.cuda.current_stream().cuda_stream); None / 0: the context's own stream again."""
+        self._chk(self.lib.L.am_set_stream(self._h, C.c_void_p(int(hip_stream or 0))))
 
     def last_frontend(self):
         """3 = streaming kernel, 2 = tile kernel, 1 = rate-generic kernels, 0 = no scan yet (diagnostic)."""

@@ -6,9 +6,11 @@ chunks.  The reference's preamble scan is sequential, but the only state that cr
 boundary is the position at which the scan resumes, and that can reach at most 241*spc
 samples into the next chunk.  Per step:
 
-  1. halo exchange   every rank publishes [its last `left` samples | its first `right` samples]
-                     in ONE all_gather of fixed-size slabs (KB-scale: latency bound, far below
-                     the 153 GB/s per xGMI link) and keeps its two neighbours' slabs;
+  1. halo exchange   every rank sends its first `right` samples to the rank before it and its last `left`
+                     samples to the rank after it (two point-to-point pairs over xGMI, KB-scale: latency
+                     bound, far below the 153 GB/s of a link), received straight into the halo regions of
+                     the chunk buffer; the context's kernels run on the same PyTorch stream the receives
+                     are ordered on, so no host synchronisation separates the exchange from the scan;
   2. local scan      am_shard_scan: front end, detection, refinement, the successor array and block exits of the
                      chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan
                      could enter the chunk at (those in its first 241*spc samples), where the
@@ -57,8 +59,9 @@ class ShardedReceiver(object):
         t = self.torch
         hl, hr, n = self.left, self.right, self.n
         self._buf = t.zeros((hl + n + hr) * 2, dtype=t.float32, device=dev)
-        self._slab = t.empty((hl + hr) * 2, dtype=t.float32, device=dev)
-        self._slabs = [t.empty_like(self._slab) for _ in range(self.world)]
+        if self._buf.is_cuda:
+            # the library's launches go to the stream the collectives are ordered on
+            self.ctx.set_stream(t.cuda.current_stream(self._buf.device).cuda_stream)
         # exit table message: [count, pos0, exit0, pos1, exit1, ...] as int64, in two sizes
         self._msg = t.zeros(1 + 2 * self.tab_cap, dtype=t.int64, device=dev)
         self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
@@ -84,15 +87,15 @@ class ShardedReceiver(object):
         own = self.chunk
         on_gpu = buf.is_cuda
         if world > 1:
-            self._slab[:hl * 2] = own[(n - hl) * 2:]
-            self._slab[hl * 2:] = own[:hr * 2]
-            dist.all_gather(self._slabs, self._slab, group=self.group)
+            ops = []
             if rank > 0:
-                buf[:hl * 2] = self._slabs[rank - 1][:hl * 2]
+                ops.append(dist.P2POp(dist.isend, own[:hr * 2], rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[:hl * 2], rank - 1, self.group))
             if rank < world - 1:
-                buf[(hl + n) * 2:] = self._slabs[rank + 1][hl * 2:]
-        if on_gpu:
-            t.cuda.synchronize()
+                ops.append(dist.P2POp(dist.isend, own[(n - hl) * 2:], rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[(hl + n) * 2:], rank + 1, self.group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()              # (RCCL: orders the current stream behind the transfer, the host does not block)
         lo = max(0, self.a0 - hl)
         off = (hl - (self.a0 - lo)) * 2                      # floats to skip at the stream start
         L = self.ctx.lib.L

@@ -40,6 +40,7 @@ char g_create_err[256] = "";
 struct am_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;   // created by am_create; `stream` is this one unless am_set_stream replaced it
     double rate = 0.0;
     uint64_t rate_i = 0;
     int spc = 0;
@@ -671,11 +672,12 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             break;
         }
         c->device = device;
-        if ((rc = hipSetDevice(device)) != hipSuccess || (rc = hipStreamCreate(&c->stream)) != hipSuccess) {
+        if ((rc = hipSetDevice(device)) != hipSuccess || (rc = hipStreamCreate(&c->own_stream)) != hipSuccess) {
             snprintf(g_create_err, sizeof(g_create_err), "device setup: %s", hipGetErrorString(rc));
             code = AM_EHIP;
             break;
         }
+        c->stream = c->own_stream;
         // timing events only: no system-scope cache flush when they execute (results reach the host through
         // pinned memory written by the kernels themselves, and through explicit copies)
         for (int i = 0; i < 4; i++) (void)hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence);
@@ -730,7 +732,7 @@ void am_destroy(am_ctx *c)
     if (c->pin_scalars) (void)hipHostFree(c->pin_scalars);
     if (c->pin_exit) (void)hipHostFree(c->pin_exit);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -774,6 +776,15 @@ int am_set_rx_time(am_ctx *c, uint64_t offset, uint64_t secs, double frac)
     HIPCHK(c, hipSetDevice(c->device));
     ENSURE(c, c->tt_dev, AM_MAX_TIME_TAGS * sizeof(am_time_tag));
     HIPCHK(c, hipMemcpy(c->tt_dev.p, c->tt.data(), c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice));
+    return AM_OK;
+}
+
+int am_set_stream(am_ctx *c, void *hip_stream)
+{
+    if (!c) return AM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));               // nothing of ours is left on the old one
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return AM_OK;
 }
 

@@ -114,6 +114,13 @@ int    am_set_rx_time(am_ctx *ctx, uint64_t offset, uint64_t secs, double frac);
 double am_get_rate(const am_ctx *ctx);
 float  am_get_threshold(const am_ctx *ctx);
 int    am_get_pmf(const am_ctx *ctx);
+/* Run the context's device work on the caller's HIP stream (hipStream_t passed as a pointer; NULL: back to the
+ * context's own stream).  For callers whose input is produced on a stream of their own -- e.g. halo samples that
+ * arrive by an RCCL receive on a PyTorch stream: work enqueued here is then ordered behind it without a host
+ * synchronisation.  The stream must outlive the context or be replaced before it is destroyed.  (No counterpart in
+ * the reference: GNU Radio blocks have no device streams.) */
+int am_set_stream(am_ctx *ctx, void *hip_stream);
+
 /* start a new stream: sample counter, carry-over samples and greedy-scan state are cleared */
 int    am_reset(am_ctx *ctx);
 
