@@ -206,6 +206,19 @@ def main():
                 import oracle
                 extra["realistic_density"]["parity"] = bool(np.array_equal(pkr, oracle.demod(iq_r, rate, 7.0, True)))
             run_steps(2, [ctx], 1, d_batches)          # back to the main density (capacity estimate of the context)
+        if mode == "single" and not args.no_extra:
+            # the same step with the batch in (pageable) HOST memory: one host-to-device copy per step inside the call.
+            # Reported separately, never as `value`.
+            ctx.process_iq(host_batches[0], flush=True)
+            sync()
+            th = time.perf_counter()
+            for _ in range(3):
+                ctx.process_iq(host_batches[0], flush=True)
+            sync()
+            dth = (time.perf_counter() - th) / 3
+            extra["host_input"] = {"value": n / dth, "unit": "samples/s", "ms_per_step": dth * 1e3,
+                                   "what": "am_process_iq on a host pointer (PCIe copy included), 3 steps"}
+            run_steps(2, [ctx], 1, d_batches)
         iq_check = host_batches[last_batch]
         parity = None
         if mode == "replicas":

@@ -8,9 +8,14 @@ blocks.file_source(gr.sizeof_gr_complex, path) reads), pushes it through air_mod
 the GPU chunk by chunk, and prints one line per decoded report in the reference's format
 (python/msprint.py), or the slicer's raw messages with --raw.
 
-Differences from modes_radio, all of them outside the demodulator: no live sources (UHD / osmocom /
-UDP), no ZeroMQ relay (the parser is called directly) and no resampling of sub-4-Msps input to
-4 Msps (radio.py:49-53) -- the rate given is the processing rate.
+Input slower than 4 Msps is resampled to 4 Msps first, as modes_radio does (python/radio.py:49-53) -- with this
+package's own polyphase interpolator (air_modes/resample.py: GNU Radio's taps are not reproducible here, so that
+stage is compared by packet recall, not bit for bit); `--no-resample` processes at the rate given, which is what
+"through rx_path directly" means for the 2 Msps capture of BASELINE.json configs[0..1].
+
+A reader thread keeps one chunk ahead of the GPU (file read and resampling of chunk k+1 run under the GPU call of
+chunk k).  Differences from modes_radio, all of them outside the demodulator: no live sources (UHD / osmocom /
+UDP) and no ZeroMQ relay (the parser is called directly).
 """
 import argparse
 import sys
@@ -33,6 +38,7 @@ def build_parser():
     ap.add_argument("-n", "--no-print", action="store_true", help="do not print decoded reports")       # modes_rx:45
     ap.add_argument("--raw", action="store_true", help="print the slicer's raw messages instead of parsed reports")
     ap.add_argument("--chunk", type=int, default=1 << 22, help="complex samples per GPU call")
+    ap.add_argument("--no-resample", action="store_true", help="process input below 4 Msps at its own rate")
     return ap
 
 
@@ -42,7 +48,11 @@ def main(argv=None, out=None):
     from . import cpr_decoder, make_parser, msg_queue, output_print, pubsub, rx_path
 
     queue = msg_queue()
-    rx = rx_path(args.rate, args.threshold, queue, use_pmf=args.pmf, use_dcblock=args.dcblock)
+    rx_rate, resampler = args.rate, None
+    if args.rate < 4e6 and not args.no_resample:                      # radio.py:49-53
+        from .resample import arb_resampler
+        rx_rate, resampler = 4e6, arb_resampler(4e6 / args.rate)
+    rx = rx_path(rx_rate, args.threshold, queue, use_pmf=args.pmf, use_dcblock=args.dcblock)
     publisher = pubsub()
     feed = make_parser(publisher)
     my_position = [float(n) for n in args.location.split(",")] if args.location else None
@@ -50,26 +60,50 @@ def main(argv=None, out=None):
         output_print(cpr_decoder(my_position), publisher, callback=lambda line: print(line, file=out))
     print("Using file source %s" % args.source, file=sys.stderr)
     print("Rate is %i" % int(args.rate), file=sys.stderr)
-    with open(args.source, "rb") as f:
-        while True:
-            raw = np.fromfile(f, dtype=np.float32, count=2 * args.chunk)
-            last = raw.size < 2 * args.chunk
-            rx.work(raw[: raw.size // 2 * 2], flush=last)
-            while not queue.empty_p():
-                text = queue.delete_head().to_string()
-                if args.raw:
-                    if not args.no_print:
-                        print(text, file=out)
-                else:
-                    try:
-                        feed(text)
-                    except (IndexError, KeyError, ValueError) as err:
-                        # table lookups the reference does unguarded (e.g. emitter category 7 in category
-                        # set B, python/parse.py:274-280): there the exception ends the subscriber thread,
-                        # here the report is skipped and the receiver keeps going
-                        print("skipped %s: %r" % (text.split()[0], err), file=sys.stderr)
-            if last:
-                break
+
+    # reader: one chunk ahead of the GPU (disk read + resampling overlap the previous chunk's GPU call)
+    import queue as _queue
+    import threading
+    chunks = _queue.Queue(maxsize=2)
+
+    def reader():
+        try:
+            with open(args.source, "rb") as f:
+                while True:
+                    raw = np.fromfile(f, dtype=np.float32, count=2 * args.chunk)
+                    last = raw.size < 2 * args.chunk
+                    iq = raw[: raw.size // 2 * 2].view(np.complex64)
+                    if resampler is not None:
+                        iq = resampler.work(iq)
+                    chunks.put((iq, last))
+                    if last:
+                        return
+        except Exception as err:                                      # surfaces in the consumer
+            chunks.put((err, True))
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    while True:
+        iq, last = chunks.get()
+        if isinstance(iq, Exception):
+            raise iq
+        rx.work(iq, flush=last)
+        while not queue.empty_p():
+            text = queue.delete_head().to_string()
+            if args.raw:
+                if not args.no_print:
+                    print(text, file=out)
+            else:
+                try:
+                    feed(text)
+                except (IndexError, KeyError, ValueError) as err:
+                    # table lookups the reference does unguarded (e.g. emitter category 7 in category
+                    # set B, python/parse.py:274-280): there the exception ends the subscriber thread,
+                    # here the report is skipped and the receiver keeps going
+                    print("skipped %s: %r" % (text.split()[0], err), file=sys.stderr)
+        if last:
+            break
+    th.join()
     print("%d samples, %d packets" % (rx.samples, rx.packets), file=sys.stderr)
     return 0
 

@@ -112,12 +112,12 @@ def test_modes_rx_cli_end_to_end(emu_lib, oracle_mod, tmp_path, monkeypatch):
     np.asarray(iq, dtype=np.complex64).tofile(path)
     monkeypatch.setenv("AIRMODES_HIP_LIB", EMU_LIB)          # test infrastructure: kernels on CPU fibers
     raw = io.StringIO()
-    assert modes_rx.main(["-s", str(path), "-r", "2e6", "--raw", "--chunk", "150000"], out=raw) == 0
+    assert modes_rx.main(["-s", str(path), "-r", "2e6", "--raw", "--chunk", "150000", "--no-resample"], out=raw) == 0
     want = oracle_mod.format_messages(oracle_mod.demod(iq, rate, 7.0, True), rate)
     got = raw.getvalue().splitlines()
     assert got == want and len(got) > 20
     parsed = io.StringIO()
-    assert modes_rx.main(["-s", str(path), "-r", "2e6", "-l", "37.7,-122.4"], out=parsed) == 0
+    assert modes_rx.main(["-s", str(path), "-r", "2e6", "-l", "37.7,-122.4", "--no-resample"], out=parsed) == 0
     pub = pubsub()
     lines = []
     msprint.output_print(cpr.cpr_decoder([37.7, -122.4]), pub, callback=lines.append)
