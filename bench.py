@@ -184,13 +184,33 @@ def main():
         last_batch = (k_last % nb) if k_last is not None else 0
         npk_steps = sum(per_batch[k % nb] for k in range(args.steps))
         if mode == "single" and not args.no_extra and not args.no_pipelined and inflight == 1 and args.steps >= 3:
-            # the same steps with 3 batches in flight (3 contexts / HIP streams driven by 3 host threads): the
-            # launch-latency-bound tail of one batch overlaps the streaming kernel of the next
-            c3 = [ctx] + [new_ctx() for _ in range(2)]
-            run_steps(9, c3, 3, d_batches)
-            dt3, _, _, _ = timed(args.steps, c3, 3, d_batches)
-            extra["pipelined"] = {"batches_in_flight": 3, "value": n * args.steps / dt3, "unit": "samples/s",
-                                  "ms_per_step": dt3 / args.steps * 1e3}
+            # the same steps with three batches in flight from ONE host thread (am_pipe: three contexts behind one handle,
+            # submit / collect): the launch-latency-bound tail of one batch overlaps the streaming kernel of the next
+            pipe = _capi.Pipe(rate, 7.0, True, device=(0 if args.emu else local), depth=3, lib=lib) if lib is not None \
+                else _capi.Pipe(rate, 7.0, True, device=local, depth=3)
+
+            def pipe_steps(count):
+                counts, last = [], None
+                for k in range(count):
+                    if pipe.in_flight() == pipe.depth():
+                        last = pipe.collect()
+                        counts.append(len(last))
+                    pipe.submit_device(d_batches[k % nb].data_ptr(), n)
+                while pipe.in_flight():
+                    last = pipe.collect()
+                    counts.append(len(last))
+                return counts, last
+            pipe_steps(9)
+            sync()
+            t3 = time.perf_counter()
+            counts3, last3 = pipe_steps(args.steps)
+            sync()
+            dt3 = time.perf_counter() - t3
+            extra["pipelined"] = {"batches_in_flight": 3, "host_threads": 1, "value": n * args.steps / dt3,
+                                  "unit": "samples/s", "ms_per_step": dt3 / args.steps * 1e3,
+                                  "same_packet_counts": counts3 == [per_batch[k % nb] for k in range(args.steps)],
+                                  "same_packets_last_batch": bool(pk is not None and np.array_equal(last3, pk))}
+            pipe.close()
         if mode == "single" and not args.no_extra and lam != REALISTIC_LAMBDA:
             iq_r = synth.synth_capture(rate, n, REALISTIC_LAMBDA, seed + 7)[0]
             d_r = [torch.from_numpy(iq_r.view(np.float32)).to(dev)]

@@ -103,6 +103,19 @@ class Library(object):
         L.am_last_num_candidates.restype = C.c_longlong
         L.am_last_num_candidates.argtypes = [vp]
         L.am_set_stream.argtypes = [vp, vp]
+        L.am_submit_iq.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+        L.am_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.am_pipe_create.restype = vp
+        L.am_pipe_create.argtypes = [C.c_int, C.c_double, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.am_pipe_destroy.argtypes = [vp]
+        L.am_pipe_submit.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+        L.am_pipe_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.am_pipe_in_flight.argtypes = [vp]
+        L.am_pipe_depth.argtypes = [vp]
+        L.am_pipe_last_error.restype = C.c_char_p
+        L.am_pipe_last_error.argtypes = [vp]
+        L.am_pipe_last_kernel_ms.restype = C.c_float
+        L.am_pipe_last_kernel_ms.argtypes = [vp]
         L.am_last_frontend.restype = C.c_int
         L.am_last_frontend.argtypes = [vp]
         self.L = L
@@ -327,6 +340,61 @@ class Context(object):
             return self._fetch(int(got.value))
         self._chk(rc)
         return self._received(out, got.value)
+
+
+class Pipe(object):
+    """am_pipe wrapper: `depth` contexts used round-robin by one host thread; independent batches (each a whole
+    stream) are submitted and collected in order, the tail of one overlapping the front end of the next."""
+
+    def __init__(self, rate, threshold_db=7.0, use_pmf=True, use_dcblock=False, device=-1, depth=3, lib=None):
+        self.lib = lib or default_library()
+        err = C.c_int(0)
+        self._h = self.lib.L.am_pipe_create(int(device), float(rate), float(threshold_db), int(bool(use_pmf)),
+                                            int(bool(use_dcblock)), int(depth), C.byref(err))
+        if not self._h:
+            raise AirModesError(err.value, self.lib.L.am_last_error(None).decode())
+        self._out = np.zeros(4096, PACKET_DTYPE)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.am_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def in_flight(self):
+        return int(self.lib.L.am_pipe_in_flight(self._h))
+
+    def depth(self):
+        return int(self.lib.L.am_pipe_depth(self._h))
+
+    def _chk(self, rc):
+        if rc != AM_OK:
+            raise AirModesError(rc, self.lib.L.am_pipe_last_error(self._h).decode())
+
+    def submit(self, iq):
+        """A batch in host memory (kept alive by the caller until it is collected)."""
+        f = _iq_f32(iq)
+        self._chk(self.lib.L.am_pipe_submit(self._h, f.ctypes.data if f.size else None, f.size // 2, AM_F_FLUSH))
+
+    def submit_device(self, ptr, n):
+        self._chk(self.lib.L.am_pipe_submit(self._h, int(ptr), int(n), AM_F_FLUSH | AM_F_DEVICE_IN))
+
+    def collect(self):
+        got = C.c_uint64(0)
+        rc = self.lib.L.am_pipe_collect(self._h, self._out.ctypes.data, len(self._out), C.byref(got))
+        if rc == AM_ECAPACITY:
+            self._out = np.zeros(int(got.value) + 1024, PACKET_DTYPE)
+            rc = self.lib.L.am_pipe_collect(self._h, self._out.ctypes.data, len(self._out), C.byref(got))
+        self._chk(rc)
+        return self._out[:int(got.value)].copy()
+
+    def last_kernel_ms(self):
+        return float(self.lib.L.am_pipe_last_kernel_ms(self._h))
 
 
 def shard_entries(lib, tables, starts):

@@ -22,6 +22,8 @@ namespace {
 
 // internal (never leaves this file): a speculative scan must be redone with the exact candidate count
 #define AM_RETRY_EXACT 1000
+// internal: the scan is enqueued, its completion is left to am_collect
+#define AM_DEFERRED 1001
 
 static inline double am_now_us()
 {
@@ -77,6 +79,17 @@ struct am_ctx {
     bool total_pending = false;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
     bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
+    // am_submit_iq / am_collect: the scan of an independent batch is enqueued by one call and completed by the other,
+    // so that one host thread can keep several contexts busy (am_pipe below)
+    bool defer = false;           // set while am_submit_iq runs: chain_finish enqueues and returns AM_DEFERRED
+    struct Pending {
+        bool active = false;      // a submitted batch awaits am_collect
+        bool scanned = false;     // ... and it has a scan in flight (a ticket to wait for)
+        uint32_t seq = 0, M = 0, n_max = 0, cur0 = 0, emax = 0, max_hits = 0, j0 = 0, j1 = 0;
+        const uint32_t *Mp = nullptr;
+        uint64_t out_abs0 = 0, P1 = 0;
+        double T0 = 0.0;
+    } pend;
     bool poison = false;          // AIRMODES_POISON=1 (tests): NaN-fill the sparse bb / reference-level arrays before every scan
     bool allow_fe3 = true;        // AIRMODES_FE=2 keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
@@ -490,6 +503,37 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
     return AM_OK;
 }
 
+// The part of chain_finish behind the completion ticket: counts, resume position, accepted packets.
+int chain_collect(am_ctx *c, uint32_t M, const uint32_t *Mp, uint32_t n_max, bool keep_bursts, uint32_t *final_cur)
+{
+    c->tail_synced = true;
+    if (Mp) {
+        // launched for a capacity: now the real candidate count is known
+        c->last_M = c->pin_scalars[2];
+        if (c->pin_scalars[2] > M) return AM_RETRY_EXACT;    // capacity too small: results are incomplete
+    }
+    const uint32_t n_emit = c->pin_scalars[0];
+    *final_cur = c->pin_scalars[1];
+    if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
+    c->n_hits = n_emit;
+    if (!keep_bursts) {
+        for (uint32_t i = 0; i < n_emit; i++) {
+            if (!c->pin_packets[i].reserved[0]) continue;      // rejected: only this flag was written
+            c->pending.push_back(c->pin_packets[i]);
+            c->pending.back().reserved[0] = 0;
+        }
+        return AM_OK;
+    }
+    c->h_tags.assign(c->pin_tags, c->pin_tags + n_emit);
+    if (n_emit) {
+        c->h_bursts.resize((size_t)n_emit * AM_BURST);
+        HIPCHK(c, hipMemcpyAsync(c->h_bursts.data(), c->bursts.p, (size_t)n_emit * AM_BURST * sizeof(float),
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return AM_OK;
+}
+
 // Greedy chain, part 2: mark the candidates the scan visits when it starts at cur0, then extract
 // and slice the hits (e <= emit_max, first-stage position in [own_lo, own_hi)).
 // keep_bursts (block-level scan): fills h_tags + h_bursts.  Otherwise (streaming / sharded scan) the tags
@@ -561,35 +605,15 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan (behind the ticket)
     c->total_pending = true;
+    if (c->defer && !keep_bursts) {
+        c->pend.scanned = true;
+        c->pend.seq = seq; c->pend.M = M; c->pend.Mp = Mp; c->pend.n_max = n_max;
+        return AM_DEFERRED;
+    }
     const double TS = am_now_us();
     HIPCHK(c, wait_for_ticket(c, seq));
     c->ht[5] += am_now_us() - TS;
-    c->tail_synced = true;
-    if (Mp) {
-        // launched for a capacity: now the real candidate count is known
-        c->last_M = c->pin_scalars[2];
-        if (c->pin_scalars[2] > M) return AM_RETRY_EXACT;    // capacity too small: results are incomplete
-    }
-    const uint32_t n_emit = c->pin_scalars[0];
-    *final_cur = c->pin_scalars[1];
-    if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
-    c->n_hits = n_emit;
-    if (!keep_bursts) {
-        for (uint32_t i = 0; i < n_emit; i++) {
-            if (!c->pin_packets[i].reserved[0]) continue;      // rejected: only this flag was written
-            c->pending.push_back(c->pin_packets[i]);
-            c->pending.back().reserved[0] = 0;
-        }
-        return AM_OK;
-    }
-    c->h_tags.assign(c->pin_tags, c->pin_tags + n_emit);
-    if (n_emit) {
-        c->h_bursts.resize((size_t)n_emit * AM_BURST);
-        HIPCHK(c, hipMemcpyAsync(c->h_bursts.data(), c->bursts.p, (size_t)n_emit * AM_BURST * sizeof(float),
-                                 hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
-    return AM_OK;
+    return chain_collect(c, M, Mp, n_max, keep_bursts, final_cur);
 }
 
 int run_chain_and_slice(am_ctx *c, const float *bb, const float *, uint32_t M, uint32_t cur0, uint32_t emit_max,
@@ -800,12 +824,16 @@ int am_reset(am_ctx *c)
     return AM_OK;
 }
 
-int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_packet *out, uint64_t cap,
-                  uint64_t *n_out)
+// am_process_iq, or with `submit` its first half: everything is enqueued, the wait for the scan and what follows it
+// (packets, stream state) is left to am_collect.  submit needs AM_F_FLUSH: batches in flight are independent streams.
+static int process_iq_core(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_packet *out, uint64_t cap,
+                           uint64_t *n_out, bool submit)
 {
     if (!c) return AM_EINVAL;
     if (n_out) *n_out = 0;
     if (n && !iq) return fail(c, AM_EINVAL, "null iq");
+    if (c->pend.active) return fail(c, AM_EINVAL, "a submitted batch has not been collected (am_collect)");
+    if (submit && !(flags & AM_F_FLUSH)) return fail(c, AM_EINVAL, "am_submit_iq needs AM_F_FLUSH (independent batches)");
     const double T0 = am_now_us();
     HIPCHK(c, hipSetDevice(c->device));
     c->pending.clear();
@@ -888,8 +916,16 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - out_abs0);
         uint32_t fin = cur0;
         const uint32_t max_hits = (uint32_t)((P1 - P0 + S) / ((uint64_t)AM_BURST * S) + 2);
+        c->defer = submit;
         rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, out_abs0, false, &fin, max_hits);
+        c->defer = false;
         c->ht[2] += am_now_us() - T2;
+        if (rc == AM_DEFERRED) {
+            c->pend.active = true;
+            c->pend.cur0 = cur0; c->pend.emax = emax; c->pend.max_hits = max_hits; c->pend.j0 = j0; c->pend.j1 = j1;
+            c->pend.out_abs0 = out_abs0; c->pend.P1 = P1; c->pend.T0 = T0;
+            return AM_OK;
+        }
         if (rc == AM_RETRY_EXACT) {
             if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: capacity %u < %u candidates, scan redone\n", M, c->last_M);
             // more candidates than the capacity this scan was launched for: redo the refinement and
@@ -904,6 +940,13 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
         c->last_tags = c->n_hits;
         if (out_abs0 + fin > c->chain_cur) c->chain_cur = out_abs0 + fin;
         c->next_pos = P1;
+    }
+
+    if (submit) {                                           // nothing was scanned (or no candidate): still a batch to collect
+        c->pend.active = true;
+        c->pend.scanned = false;
+        c->pend.T0 = T0;
+        return AM_OK;
     }
 
     // 3. stream state for the next call
@@ -941,6 +984,52 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
     const int hrc = hand_out(c, out, cap, n_out);
     c->ht[3] += am_now_us() - T5; c->ht[4] += am_now_us() - T0; c->ht_n++;
     return hrc;
+}
+
+int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_packet *out, uint64_t cap,
+                  uint64_t *n_out)
+{
+    return process_iq_core(c, iq, n, flags, out, cap, n_out, false);
+}
+
+int am_submit_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags)
+{
+    return process_iq_core(c, iq, n, flags, nullptr, 0, nullptr, true);
+}
+
+int am_collect(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
+{
+    if (!c) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    if (!c->pend.active) return hand_out(c, out, cap, n_out);        // (also: what an AM_ECAPACITY left behind)
+    HIPCHK(c, hipSetDevice(c->device));
+    am_ctx::Pending &P = c->pend;
+    if (P.scanned) {
+        const double TS = am_now_us();
+        HIPCHK(c, wait_for_ticket(c, P.seq));
+        c->ht[5] += am_now_us() - TS;
+        uint32_t fin = P.cur0, M = P.M;
+        int rc = chain_collect(c, P.M, P.Mp, P.n_max, false, &fin);
+        if (rc == AM_RETRY_EXACT) {
+            // more candidates than the capacity the scan was launched for: redo it with the exact count, now
+            rc = run_refine(c, c->ref_bb, c->ref_avg, c->ref_nseg, c->ref_stride, c->ref_mode, &M, c->ref_endj, 0);
+            if (rc == AM_OK) {
+                fin = P.cur0;
+                rc = run_chain_and_slice(c, (const float *)c->bb.p, nullptr, M, P.cur0, P.emax, P.out_abs0, false, &fin,
+                                         P.max_hits);
+            }
+        }
+        if (rc != AM_OK) { P.active = false; P.scanned = false; return rc; }
+        c->spec_density = (P.j1 > P.j0) ? (double)c->last_M / (double)(P.j1 - P.j0) : 0.0;
+        c->last_tags = c->n_hits;
+    }
+    P.active = false;
+    P.scanned = false;
+    reset_stream(c);                                                  // (submitted batches end their stream: AM_F_FLUSH)
+    c->last_dom_ms = 0.0f;
+    if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
+    c->ht[4] += am_now_us() - P.T0; c->ht_n++;
+    return hand_out(c, out, cap, n_out);
 }
 
 int am_fetch_packets(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
@@ -1266,6 +1355,71 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
     if (rc != AM_OK) return rc;
     c->last_tags = c->n_hits;
     return hand_out(c, out, cap, n_out);
+}
+
+/* ---- several batches in flight from one host thread ------------------------------------------------------- */
+struct am_pipe {
+    std::vector<am_ctx *> sub;
+    size_t head = 0, inflight = 0;
+};
+
+am_pipe *am_pipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err)
+{
+    if (depth < 1 || depth > 16) { if (err) *err = AM_EINVAL; return nullptr; }
+    am_pipe *p = new (std::nothrow) am_pipe();
+    if (!p) { if (err) *err = AM_ENOMEM; return nullptr; }
+    for (int k = 0; k < depth; k++) {
+        am_ctx *c = am_create(device, rate, threshold_db, use_pmf, use_dcblock, err);
+        if (!c) { am_pipe_destroy(p); return nullptr; }
+        p->sub.push_back(c);
+    }
+    if (err) *err = AM_OK;
+    return p;
+}
+
+void am_pipe_destroy(am_pipe *p)
+{
+    if (!p) return;
+    for (am_ctx *c : p->sub) am_destroy(c);
+    delete p;
+}
+
+int am_pipe_depth(const am_pipe *p) { return p ? (int)p->sub.size() : AM_EINVAL; }
+int am_pipe_in_flight(const am_pipe *p) { return p ? (int)p->inflight : AM_EINVAL; }
+
+int am_pipe_submit(am_pipe *p, const float *iq, uint64_t n, uint32_t flags)
+{
+    if (!p) return AM_EINVAL;
+    if (p->inflight == p->sub.size()) return AM_ECAPACITY;          // collect the oldest batch first
+    am_ctx *c = p->sub[(p->head + p->inflight) % p->sub.size()];
+    const int rc = am_submit_iq(c, iq, n, flags | AM_F_FLUSH);
+    if (rc == AM_OK) p->inflight++;
+    return rc;
+}
+
+int am_pipe_collect(am_pipe *p, am_packet *out, uint64_t cap, uint64_t *n_out)
+{
+    if (!p) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    if (p->inflight == 0) return AM_EINVAL;
+    am_ctx *c = p->sub[p->head];
+    const int rc = am_collect(c, out, cap, n_out);
+    if (rc == AM_ECAPACITY) return rc;                              // the packets stay: call again with a larger array
+    p->head = (p->head + 1) % p->sub.size();
+    p->inflight--;
+    return rc;
+}
+
+const char *am_pipe_last_error(const am_pipe *p)
+{
+    if (!p || p->sub.empty()) return g_create_err;
+    return p->sub[(p->head + (p->inflight ? p->inflight - 1 : 0)) % p->sub.size()]->err;
+}
+
+float am_pipe_last_kernel_ms(const am_pipe *p)
+{
+    if (!p || p->sub.empty()) return 0.0f;
+    return p->sub[(p->head + p->sub.size() - 1) % p->sub.size()]->last_dom_ms;   // the batch collected last
 }
 
 const char *am_last_error(const am_ctx *c) { return c ? c->err : g_create_err; }

@@ -114,6 +114,32 @@ int    am_set_rx_time(am_ctx *ctx, uint64_t offset, uint64_t secs, double frac);
 double am_get_rate(const am_ctx *ctx);
 float  am_get_threshold(const am_ctx *ctx);
 int    am_get_pmf(const am_ctx *ctx);
+/* ---- batches in flight ---------------------------------------------------------------------------------------
+ * Under GNU Radio every block of rx_path runs in its own thread, so the slicer works on burst k while the preamble
+ * block scans ahead (thread-per-block scheduler; python/rx_path.py wires five blocks).  The counterpart here: the
+ * launch-latency-bound tail of one batch (greedy chain, extraction, slicer) overlaps the streaming front end of the
+ * next.  A context works on one batch at a time, so the overlap is between contexts:
+ *
+ * am_submit_iq   first half of am_process_iq: copies and kernels of one INDEPENDENT batch (AM_F_FLUSH is required: it
+ *                is a whole stream) are enqueued, nothing is waited for.  The samples must stay valid until am_collect.
+ * am_collect     second half: waits for the batch, returns its packets (same contract as am_process_iq, incl.
+ *                AM_ECAPACITY + am_fetch_packets) and resets the stream state.
+ * am_pipe_*      `depth` contexts behind one handle, used round-robin by ONE host thread: submit up to `depth`
+ *                batches, collect them in submission order.  Results are those of am_process_iq on each batch. */
+int am_submit_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags);
+int am_collect(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
+typedef struct am_pipe am_pipe;
+am_pipe *am_pipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err);
+void am_pipe_destroy(am_pipe *pipe);
+int am_pipe_depth(const am_pipe *pipe);
+int am_pipe_in_flight(const am_pipe *pipe);
+/* AM_ECAPACITY when `depth` batches are already in flight (collect one first) */
+int am_pipe_submit(am_pipe *pipe, const float *iq, uint64_t n_complex, uint32_t flags);
+/* packets of the OLDEST batch in flight; AM_EINVAL when there is none */
+int am_pipe_collect(am_pipe *pipe, am_packet *out, uint64_t cap, uint64_t *n_out);
+const char *am_pipe_last_error(const am_pipe *pipe);
+float am_pipe_last_kernel_ms(const am_pipe *pipe);   /* dominant-kernel time of the batch collected last */
+
 /* Run the context's device work on the caller's HIP stream (hipStream_t passed as a pointer; NULL: back to the
  * context's own stream).  For callers whose input is produced on a stream of their own -- e.g. halo samples that
  * arrive by an RCCL receive on a PyTorch stream: work enqueued here is then ordered behind it without a host

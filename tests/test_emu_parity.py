@@ -227,3 +227,45 @@ def test_streaming_front_end_unaligned_and_short_inputs(emu_lib, monkeypatch):
     want = oracle.demod(iq, 64e6)
     assert pc.check_chunked(emu_lib, 64e6, iq, [1, 3073, 100001, 100002, 250001, 250002 + 3071], want=want) > 5
     assert pc.check_chunked(emu_lib, 64e6, iq, list(range(7001, 500000, 7001)), want=want) > 5
+
+
+def test_batches_in_flight_single_host_thread(emu_lib):
+    """am_pipe: three contexts behind one handle, one host thread; results are those of am_process_iq per batch, in order.
+    Also the pair it is built from (am_submit_iq / am_collect) and the error paths."""
+    rate = 64e6
+    batches = [synth.synth_capture(rate, 300000 + 1000 * k, 20000.0, 500 + k)[0] for k in range(5)]
+    want = [oracle.demod(b, rate) for b in batches]
+    pipe = _capi.Pipe(rate, 7.0, True, depth=3, lib=emu_lib)
+    got = []
+    for k, b in enumerate(batches):
+        if pipe.in_flight() == pipe.depth():
+            got.append(pipe.collect())
+        pipe.submit(b)
+    with pytest.raises(_capi.AirModesError):             # (a fourth batch does not fit)
+        if pipe.in_flight() == pipe.depth():
+            pipe.submit(batches[0])
+        else:
+            raise _capi.AirModesError(_capi.AM_ECAPACITY, "not full")
+    while pipe.in_flight():
+        got.append(pipe.collect())
+    with pytest.raises(_capi.AirModesError):
+        pipe.collect()                                    # nothing in flight
+    assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
+    assert sum(len(w) for w in want) > 20
+    pipe.close()
+    # the pair underneath, on one context, and a submit that is not a whole stream
+    ctx = _capi.Context(rate, 7.0, True, lib=emu_lib)
+    f = np.ascontiguousarray(batches[0]).view(np.float32)
+    L = emu_lib.L
+    assert L.am_submit_iq(ctx._h, f.ctypes.data, len(batches[0]), 0) == _capi.AM_EINVAL
+    assert L.am_submit_iq(ctx._h, f.ctypes.data, len(batches[0]), _capi.AM_F_FLUSH) == _capi.AM_OK
+    assert L.am_submit_iq(ctx._h, f.ctypes.data, len(batches[0]), _capi.AM_F_FLUSH) == _capi.AM_EINVAL   # not collected yet
+    out = np.zeros(2, _capi.PACKET_DTYPE)                 # too small on purpose
+    import ctypes as C
+    n = C.c_uint64(0)
+    assert L.am_collect(ctx._h, out.ctypes.data, len(out), C.byref(n)) == _capi.AM_ECAPACITY and n.value == len(want[0])
+    out = np.zeros(n.value, _capi.PACKET_DTYPE)
+    assert L.am_collect(ctx._h, out.ctypes.data, len(out), C.byref(n)) == _capi.AM_OK
+    assert np.array_equal(out, want[0])
+    assert np.array_equal(ctx.process_iq(batches[1], flush=True), want[1])     # the context is usable as before
+    ctx.close()

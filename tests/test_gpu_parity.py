@@ -248,3 +248,20 @@ def test_streaming_front_end_unaligned_and_short_inputs(lib, monkeypatch):
     assert pc.check_chunked(lib, 64e6, iq, [1, 3073, 1000001, 1000002, 2500001, 2500002 + 3071], want=want) > 50
     assert pc.check_chunked(lib, 64e6, iq, list(range(70001, 5000000, 70001)), want=want) > 50
     assert pc.check_sharded(lib, 64e6, iq, 5, want=want) > 50
+
+
+def test_batches_in_flight_single_host_thread(lib):
+    """am_pipe on the device: batches of different lengths and rates of traffic in flight, packets per batch == oracle."""
+    rate = 64e6
+    batches = [synth.synth_capture(rate, 3000000 + 100001 * k, 20000.0 if k % 2 else 3000.0, 500 + k)[0] for k in range(7)]
+    want = [oracle.demod(b, rate) for b in batches]
+    pipe = _capi.Pipe(rate, 7.0, True, depth=3, lib=lib)
+    got = []
+    for b in batches:
+        if pipe.in_flight() == pipe.depth():
+            got.append(pipe.collect())
+        pipe.submit(b)
+    while pipe.in_flight():
+        got.append(pipe.collect())
+    assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
+    pipe.close()
