@@ -262,10 +262,16 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         }
         if (do_pmf) {
             // suffix sums of the own chip (what the NEXT chip's filter needs): sx[i] = m[31] + ... + m[i], right->left
-            float sx[SPC];
-            float acc = 0.0f;
+            // (the in-chip prefix sums pp[] run left->right through the same loop: two independent chains per iteration)
+            float sx[SPC], pp[SPC];
+            {
+                float as = 0.0f, ap = 0.0f;
 #pragma unroll
-            for (int i = SPC - 1; i >= 0; --i) { acc = acc + m[i]; sx[i] = acc; }
+                for (int i = 0; i < SPC; ++i) {
+                    as = as + m[SPC - 1 - i]; sx[SPC - 1 - i] = as;
+                    ap = ap + m[i]; pp[i] = ap;
+                }
+            }
             // the step's last chip hands its sums to the next step's first chip
             if (tid == (FE3_NW - 1) * AM_WAVE + AM_CHIPS_AVG - 1) {
                 float4 *dst = reinterpret_cast<float4 *>(L.SB0 + par * 32);
@@ -292,12 +298,10 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                     for (int i = SPC - 1; i >= 0; --i) { acc2 = acc2 + pv[i]; pv[i] = acc2; }
                 }
             }
-            acc = 0.0f;
 #pragma unroll
             for (int i = 0; i < SPC; ++i) {
-                acc = acc + m[i];                                     // in-chip prefix, left->right
-                if (i == SPC - 1) bb[i] = acc * a.s1;                 // the window is the chip
-                else bb[i] = (fe3_from_prev_lane(sx[i + 1], pv[i + 1], lane) + acc) * a.s1;
+                if (i == SPC - 1) bb[i] = pp[i] * a.s1;               // the window is the chip
+                else bb[i] = (fe3_from_prev_lane(sx[i + 1], pv[i + 1], lane) + pp[i]) * a.s1;
             }
         } else {
 #pragma unroll
@@ -316,9 +320,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         // chip totals in both directions (canonical level-1 sums); spare lanes contribute zeros to the scans
         float f = 0.0f, b = 0.0f;
 #pragma unroll
-        for (int i = 0; i < SPC; ++i) f = f + bb[i];
-#pragma unroll
-        for (int i = SPC - 1; i >= 0; --i) b = b + bb[i];
+        for (int i = 0; i < SPC; ++i) { f = f + bb[i]; b = b + bb[SPC - 1 - i]; }
         if (!chip_thread) f = 0.0f;
         // exclusive prefix / suffix of the 48 chip totals of this wave's block, strictly sequential (canonical
         // order): x <- x(lane-1) + f repeated 47 times leaves lane j with ((f0 + f1) + ...) + fj (a lane's value is
@@ -379,19 +381,22 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         const float st_a = L.ST[slotS];
         const float suf_last = L.RTOT[slotS1] + L.ST[slotS1];
         const int jb = (t + AM_CHIPS_AVG - FE3_LAG) % AM_CHIPS_AVG;   // chip index inside its 48-chip block
+        // in-chip suffix sums of the chip 48 back (right->left) and prefix sums of the own chip (left->right): two
+        // independent chains per iteration
+        float pre[SPC];
         {
-            float acc = 0.0f;
+            float as = 0.0f, ap = 0.0f;
 #pragma unroll
-            for (int i = SPC - 1; i >= 0; --i) { acc = acc + scv[i]; scv[i] = acc; }   // in-chip suffix sums, 48 chips back
+            for (int i = 0; i < SPC; ++i) {
+                as = as + scv[SPC - 1 - i]; scv[SPC - 1 - i] = as;
+                ap = ap + x[i]; pre[i] = pt + ap;
+            }
         }
-        float acc = 0.0f;
 #pragma unroll
         for (int i = 0; i < SPC; ++i) {
-            acc = acc + x[i];
-            const float PRE = pt + acc;
             float s;
-            if (i == SPC - 1) s = (jb == AM_CHIPS_AVG - 1) ? PRE : (suf_last + PRE);
-            else s = (scv[i + 1] + st_a) + PRE;
+            if (i == SPC - 1) s = (jb == AM_CHIPS_AVG - 1) ? pre[i] : (suf_last + pre[i]);
+            else s = (scv[i + 1] + st_a) + pre[i];
             avgv[i] = s * a.sL;
         }
     }
