@@ -586,6 +586,9 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
     c->pin_scalars[2] = 0;
+    // (the slicing waves write the accepted packets straight to the pinned array.  Routing them through device memory
+    // and one coalesced copy in the ticket kernel was tried: the extraction kernel did not get faster and the copy
+    // added 13 us to the ticket.)
     if (c->bb_sparse && !keep_bursts)
         // bb exists only around the candidates: the 240 soft chips of a hit are recomputed from the scan's samples
         HIPCHK(c, am_launch_extract_slice_iq(c->scan_src, (long long)c->scan_src_abs0, (long long)c->scan_src_abs1,
@@ -738,8 +741,18 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
     return c;
 }
 
+#if defined(AM_XPROF)
+extern "C" int am_debug_xprof(unsigned long long *out, int reset);
+#endif
 void am_destroy(am_ctx *c)
 {
+#if defined(AM_XPROF)
+    {   // tuning builds: phase clocks of the extraction kernel since the last context went away
+        unsigned long long acc[8];
+        if (c && am_debug_xprof(acc, 1) == 0)
+            fprintf(stderr, "xprof head %llu stage %llu sums %llu slice %llu\n", acc[0], acc[1], acc[2], acc[3]);
+    }
+#endif
     if (!c) return;
     if (getenv("AIRMODES_HOST_TRACE") && c->ht_n)
         fprintf(stderr, "airmodes host trace over %u calls (us/call): setup %.1f, front end + refinement enqueue %.1f, chain + tail incl. sync %.1f (of which waiting %.1f), timing + hand-over %.1f, whole call %.1f, event-not-ready %.0f\n",

@@ -37,6 +37,8 @@
 #include "am_fe_cmpx.h"
 
 // tuning builds only (tools/build_variants.sh): FE3_ABLATE bit mask removes parts of the kernel -- results INVALID
+// pieces of the ring-rebuilding step that are not loaded (8 chips each): chips from FE3_S - FE3_LAG - 48 on are needed
+#define FE3_WARM_J0 ((FE3_S - FE3_LAG - AM_CHIPS_AVG) / (FE3_NT / 16))
 #ifndef FE3_ABLATE
 #define FE3_ABLATE 0
 #endif
@@ -174,18 +176,20 @@ struct fe3_smem {
 struct fe3_raw { float4 v[12]; };      // a thread's 12 pieces of a step's raw IQ (piece tid + 128 j)
 
 // unguarded loads of a step (wave-uniform 64-bit base + 32-bit lane offset): issued early, consumed by fe3_store_step
+template <int J0 = 0>
 __device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0, int tid, fe3_raw &r)
 {
     const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
     const unsigned off = (unsigned)tid * 16u;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) r.v[j] = fe3_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
+    for (int j = J0; j < 12; ++j) r.v[j] = fe3_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
 }
+template <int J0 = 0>
 __device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int tid, const fe3_raw &r)
 {
     const int c0 = tid >> 4, k = tid & 15;
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
+    for (int j = J0; j < 12; ++j) {
         const float r0 = r.v[j].x * r.v[j].x, i0 = r.v[j].y * r.v[j].y, r1 = r.v[j].z * r.v[j].z, i1 = r.v[j].w * r.v[j].w;
         float2 mm;
         mm.x = r0 + i0;                                               // a1: fl(fl(I*I) + fl(Q*Q))
@@ -202,7 +206,8 @@ __device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int
 // p = tid + 128 j (16 bytes = samples 2k, 2k+1 of chip p >> 4, k = p & 15 = tid & 15) -> X[slot][2k .. 2k+1].
 // Coalesced loads (consecutive lanes, consecutive pieces), 8-byte LDS stores (16 lanes = one chip's 128 bytes).
 // chip 47's values are stored a second time (M47): wave 1 needs them after chip 47's slot holds bb.
-template <bool GUARD>
+// J0 > 0: only pieces J0.. (chips 8 J0 ..) -- the step that rebuilds the rings needs its last 57 chips only
+template <bool GUARD, int J0 = 0>
 __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_smem &L, long long A0, int slot0, int tid)
 {
     const int c0 = tid >> 4, k = tid & 15;
@@ -229,8 +234,8 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
         return;
     }
     fe3_raw v;
-    fe3_load_step(a, A0, tid, v);
-    fe3_store_step(L, slot0, tid, v);
+    fe3_load_step<J0>(a, A0, tid, v);
+    fe3_store_step<J0>(L, slot0, tid, v);
 }
 
 // One step (its |.|^2 is staged).
@@ -542,7 +547,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     // 8 stores that touch one line per lane: store-issue bound, measured 5x slower.)  A wave's mask covers 64 chips from
     // its first one: wave 0 thereby serves the first 16 chips of wave 1 where its own candidates reach; what wave 1's
     // candidates need beyond the step is handed to the next step's wave 0 (CARRY).
-    {
+    if (!(FE3_ABLATE & 32)) {
         unsigned long long need = cand;                               // dilate by 16 chips to the right
         need |= need << 1; need |= need << 2; need |= need << 4; need |= need << 8;
         need |= cand << 16;
@@ -627,7 +632,12 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         FE3_STAMP(4);
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
 #if FE3_LOAD_EARLY == 2
-        if (have) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);   // no prefetch: load, wait, stage
+        // no prefetch: load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is
+        // chip FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
+        if (have) {
+            if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+            else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+        }
 #else
         if (have) fe3_store_step(L, slot0, tid, raw);
 #endif
@@ -658,19 +668,7 @@ unsigned am_fe3_steps(long long out_n) { return (unsigned)((out_n + FE3_LAG * FE
 static long long fe3_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
 static long long fe3_ceil_div(long long x, long long d) { return -fe3_floor_div(-x, d); }
 
-static int fe3_wgs_for_device()
-{
-    static std::atomic<int> cached[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev].load(std::memory_order_relaxed) == 0) {
-        hipDeviceProp_t prop;
-        const int ncu = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                            ? prop.multiProcessorCount : 256;
-        cached[dev].store(FE3_WG_PER_CU * ncu, std::memory_order_relaxed);   // resident workgroups
-    }
-    return cached[dev].load(std::memory_order_relaxed);
-}
+static int fe3_wgs_for_device() { return FE3_WG_PER_CU * am_device_cus(); }   // resident workgroups
 
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
@@ -699,6 +697,9 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     const unsigned resident = (unsigned)fe3_wgs_for_device();
     unsigned spw = (a.nsteps + resident - 1) / resident;
     if (spw < 4) spw = 4;
+#ifdef FE3_FORCE_SPW
+    spw = FE3_FORCE_SPW;                                              // tuning builds
+#endif
     a.steps_per_wg = spw;
     const unsigned grid = (a.nsteps + spw - 1) / spw;
     static std::atomic<bool> attr_done[64];

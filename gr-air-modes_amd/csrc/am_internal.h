@@ -12,6 +12,8 @@
 #define AM_BURST 240       /* chips handed to the slicer       (lib/preamble_impl.cc:219)  */
 #define AM_WAVE 64
 
+int am_device_cus(void);   /* compute units of the current device (cached)                  */
+
 /* ---- front end ---------------------------------------------------------------------- */
 #define AM_FE_THREADS 512
 #define AM_FE_LDS_BUDGET (80 * 1024)

@@ -13,6 +13,9 @@
 //   slicer + CRC     lib/slicer_impl.cc:67-182, lib/modes_crc.cc:38-63
 // The summation order inside the two moving averages is the chip-aligned two-level order
 // of DESIGN.md section 3 (GNU Radio's own order depends on its scheduler).
+#include <atomic>
+#include <string.h>
+
 #include "am_internal.h"
 
 #if defined(__clang__)
@@ -1034,6 +1037,21 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
     }
 }
 
+// compute units of the current device (cached per device: a process may hold contexts on several)
+int am_device_cus(void)
+{
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
 static uint32_t am_chain_headw(uint32_t nblk)
@@ -1226,6 +1244,23 @@ __device__ __forceinline__ uint32_t am_bitrev8(uint32_t v)
     return v;
 }
 
+// the slicer's long / short decision from the first five data bits of burst b (what am_slice_wave derives from its
+// ballots: slicer_impl.cc:128-140): callers that form the soft chips themselves skip chips 128.. of a short packet
+__device__ __forceinline__ bool am_burst_is_long(const float *b)
+{
+    float s = b[0] + b[2];
+    s = s + b[7];
+    s = s + b[9];
+    const float ref = (float)((double)s / 4.0);
+    const float hi = (float)((double)ref * 1.414);
+    const float lo = (float)((double)ref * 0.707);
+    const double half_lo = (double)lo * 0.5;
+    uint32_t hdr = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) hdr = (hdr << 1) | (uint32_t)(am_chip_pair_slice(b[16 + 2 * k], b[17 + 2 * k], lo, hi, half_lo) & 1);
+    return hdr == 16 || hdr == 17 || hdr == 20 || hdr == 21;
+}
+
 // one wave slices burst b (240 soft chips, global memory or LDS); lane 0 files the packet under index i
 __device__ __forceinline__ void am_slice_wave(const float *b, const am_tag &t, uint32_t i, int lane,
                                               const uint32_t *__restrict__ crc_pow, am_packet *__restrict__ packets)
@@ -1364,11 +1399,122 @@ hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc,
 // samples of a hit are recomputed from IQ in the canonical order: sample n of chip q (offset i) is
 //   bb[n] = fl( (suf + pre) * s1 ),  pre = m[q*spc] + ... + m[n] left->right,
 //                                    suf = m[q*spc-1] + ... + m[n-spc+1] right->left (absent for i = spc-1),
-// m = |iq|^2, zero outside the stream; bb itself reads zero beyond the end of the stream.  One workgroup per hit:
-// the 240*spc samples the burst spans are staged as |.|^2 in LDS (coalesced 8-byte loads), lane c forms sample c.
-__global__ void __launch_bounds__(256)
+// m = |iq|^2, zero outside the stream; bb itself reads zero beyond the end of the stream.
+// Lane c of a workgroup forms sample c: the spc samples its filter window spans are its own 8*spc contiguous bytes
+// of IQ, loaded with 16-byte loads that are all in flight at once and summed in registers -- all 240 samples of a
+// burst sit at the same offset i inside their chips, so the split of the window into pre and suf is uniform.
+// The loads are what the kernel costs (ablation builds: 55 us at the bench density, 11 us without them; staging
+// the window through LDS with coalesced loads -- one hit per workgroup or grid-stride, whole or half bursts, per
+// wave with a row transposition --, slicing hit k under the loads of hit k + 1, packets through device memory:
+// 51-68 us, every one of them: profiles/r2_final/README.md), so it reads fewer bytes where it can: chips 0..127
+// first (preamble + 56 bits), the slicer's long / short decision from the first five bits, and chips 128..239
+// only for a long packet.
+// A workgroup takes hits grid-stride over the device-side hit count: the launch is sized for the chip, not for
+// the bound on the number of hits.
+#if defined(AM_XPROF)
+// tuning builds only: cycles per phase of the extraction kernel, summed over workgroups (am_debug_xprof reads them)
+__device__ unsigned long long am_xprof_acc[8];
+__device__ long long am_xprof_log[4096][4];      // per workgroup of the last launch: start, end (100 MHz real time), hits, longest hit (cycles)
+#define AM_XSTAMP(k) do { if (tid == 0) { const long long now__ = (long long)__builtin_readcyclecounter(); atomicAdd(&am_xprof_acc[k], (unsigned long long)(now__ - xlast)); xlast = now__; } } while (0)
+extern "C" int am_debug_xprof(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(am_xprof_acc), sizeof(am_xprof_acc)) != hipSuccess) return -1;
+    {
+        static long long h[4096][4];
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(am_xprof_log), sizeof(h)) == hipSuccess) {
+            long long t0 = 0x7fffffffffffffffll, t1 = 0, lmax = 0, hmax = 0; int n = 0; double life = 0, hits = 0;
+            for (int b = 0; b < 4096; ++b) if (h[b][2] > 0) {
+                if (h[b][0] < t0) t0 = h[b][0];
+                if (h[b][1] > t1) t1 = h[b][1];
+                if (h[b][1] - h[b][0] > lmax) lmax = h[b][1] - h[b][0];
+                if (h[b][3] > hmax) hmax = h[b][3];
+                life += (double)(h[b][1] - h[b][0]); hits += (double)h[b][2]; ++n;
+            }
+            if (n) fprintf(stderr, "xprof last launch: %d workgroups, %.0f hits, span %.2f us, workgroup life mean %.2f max %.2f us, longest hit %lld cycles\n",
+                           n, hits, (double)(t1 - t0) / 100.0, life / n / 100.0, (double)lmax / 100.0, hmax);
+        }
+    }
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(am_xprof_acc), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define AM_XSTAMP(k) ((void)0)
+#endif
+
+// |.|^2 of absolute sample w, zero outside the source
+__device__ __forceinline__ float am_mag_guarded(const float2 *__restrict__ iq2, long long src_abs0, long long src_abs1, long long w)
+{
+    float mm = 0.0f;
+    if (w >= src_abs0 && w < src_abs1) { const float2 t = iq2[w - src_abs0]; const float r = t.x * t.x, q = t.y * t.y; mm = r + q; }
+    return mm;
+}
+
+// soft chip c of the burst whose first sample has absolute index ae (bb; the reference level comes off later).
+// inside (uniform): every lane's 16-byte loads lie inside the source -- all but the hits at the two ends of the stream
+template <int SPC>
+__device__ __forceinline__ float am_soft_chip_iq(const float *__restrict__ iq, long long src_abs0, long long src_abs1,
+                                                 bool pmf, float s1, long long ae, int c, bool inside)
+{
+    const float2 *iq2 = reinterpret_cast<const float2 *>(iq);
+    const long long n = ae + (long long)c * SPC;                              // the sample this lane forms
+    if (!pmf) {
+        float v = 0.0f;
+        if (n >= src_abs0 && n < src_abs1) {
+            const float2 t = iq2[n - src_abs0];
+            const float r = t.x * t.x, q = t.y * t.y;
+            v = r + q;
+        }
+        return v;
+    }
+    const int ii = (int)(ae % SPC);                                           // offset inside the chip, the same for all 240 samples
+    float v;
+    if (inside) {
+        // window: samples n - SPC + 1 .. n; M[k] = |.|^2 of sample w0 + k, w0 = the window's first sample rounded
+        // down to an even offset into iq (`odd`: uniform, the lanes are SPC samples apart)
+        const long long wfirst = n - (SPC - 1);
+        const int odd = (int)((wfirst - src_abs0) & 1);
+        const float4 *src = reinterpret_cast<const float4 *>(iq) + ((wfirst - odd - src_abs0) >> 1);
+        float4 t[SPC / 2 + 1];
+#pragma unroll
+        for (int k = 0; k < SPC / 2 + 1; ++k) t[k] = src[k];
+        float M[SPC + 2];
+#pragma unroll
+        for (int k = 0; k < SPC / 2 + 1; ++k) {
+            const float r0 = t[k].x * t[k].x, q0 = t[k].y * t[k].y, r1 = t[k].z * t[k].z, q1 = t[k].w * t[k].w;
+            M[2 * k] = r0 + q0;
+            M[2 * k + 1] = r1 + q1;
+        }
+        // m[w] = M[w + odd], as a bit select (a plain ?: becomes an indexed read of M[] through scratch memory)
+        float m[SPC];
+        const uint32_t omask = 0u - (uint32_t)odd;
+#pragma unroll
+        for (int w = 0; w < SPC; ++w)
+            m[w] = __uint_as_float((__float_as_uint(M[w + 1]) & omask) | (__float_as_uint(M[w]) & ~omask));
+        const int wb = SPC - 1 - ii;                                          // window index of the chip's first sample
+        float pre = 0.0f, suf = 0.0f;
+#pragma unroll
+        for (int w = 0; w < SPC; ++w) {
+            if (w >= wb) pre = pre + m[w];                                    // (uniform conditions)
+            if (SPC - 1 - w < wb) suf = suf + m[SPC - 1 - w];
+        }
+        v = (ii == SPC - 1) ? pre * s1 : (suf + pre) * s1;
+    } else {
+        // (rare: one sample at a time, rolled loops, the canonical order directly)
+        float pre = 0.0f, suf = 0.0f;
+#pragma unroll 1
+        for (long long w = n - ii; w <= n; ++w) pre = pre + am_mag_guarded(iq2, src_abs0, src_abs1, w);
+#pragma unroll 1
+        for (long long w = n - ii - 1; w >= n - SPC + 1; --w) suf = suf + am_mag_guarded(iq2, src_abs0, src_abs1, w);
+        v = (ii == SPC - 1) ? pre * s1 : (suf + pre) * s1;
+    }
+    if (n >= src_abs1) v = 0.0f;                                              // bb reads zero beyond the end of the stream
+    return v;
+}
+
+template <int SPC>
+__global__ void __launch_bounds__(256, 5)
 am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
-                      const float *__restrict__ inavg, int spc, const uint32_t *__restrict__ emit_idx,
+                      const float *__restrict__ inavg, const uint32_t *__restrict__ emit_idx,
                       const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ pos,
                       const uint32_t *__restrict__ eo, uint64_t base_abs, uint64_t rate,
                       const am_time_tag *__restrict__ tt, uint32_t ntt, float *__restrict__ bursts_out,
@@ -1376,82 +1522,71 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
                       am_packet *__restrict__ packets, const uint32_t *__restrict__ scalars,
                       uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
 {
-    HIP_DYNAMIC_SHARED(float, W);                             // [240*spc padded 1 per 32] then the burst [240]
+    static_assert(SPC % 2 == 0 && SPC >= 2, "pairs of samples per 16-byte load");
+    constexpr int HEAD = 128;                                 // chips of a short packet: 16 + 2 * 56
+    __shared__ float sb[AM_BURST];
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1);
-    const uint32_t i = blockIdx.x;
+#if defined(AM_XPROF)
+    long long xlast = (long long)__builtin_readcyclecounter();
+    const long long xstart = (long long)__builtin_amdgcn_s_memrealtime();
+    long long xhits = 0, xlong = 0;
+#endif
+    const uint32_t nhit = *n_ptr;                             // device-side hit count
     if (host_out && blockIdx.x == 0 && threadIdx.x == 0) {
-        host_out[0] = *n_ptr;
+        host_out[0] = nhit;
         host_out[1] = scalars[0];
         host_out[2] = Mp ? *Mp : 0u;
     }
-    if (i >= *n_ptr) return;                                  // uniform; device-side hit count
-    const uint32_t g = emit_idx[i];
-    const uint32_t e = eo[g];
-    const float av = inavg[g];
-    const long long ae = (long long)base_abs + (long long)e;  // absolute index of the burst's first sample
-    const bool pmf = use_pmf && spc > 1;
-    const int nwin = AM_BURST * spc;
-    float *sb = W + nwin + (nwin >> 5) + 8;
-    const float2 *iq2 = reinterpret_cast<const float2 *>(iq);
-    const long long wlo = ae - (spc - 1);
-    if (pmf) {
-        // two samples (16 bytes) per lane where the source allows it
-        const long long rel = wlo - src_abs0;
-        const bool wide = (reinterpret_cast<uintptr_t>(iq) & 15u) == 0;
-        const long long n0 = wlo - (wide ? (rel & 1) : 0);           // first sample of pair 0 (even offset into iq)
-        const int npair = (int)((wlo + nwin - n0 + 1) >> 1);
-        const float4 *iq4 = reinterpret_cast<const float4 *>(iq);
-        for (int q = tid; q < npair; q += 256) {
-            const long long n = n0 + 2 * (long long)q;
-            float m0 = 0.0f, m1 = 0.0f;
-            if (wide && n >= src_abs0 && n + 1 < src_abs1) {
-                const float4 t = iq4[(n - src_abs0) >> 1];
-                const float r0 = t.x * t.x, q0 = t.y * t.y, r1 = t.z * t.z, q1 = t.w * t.w;
-                m0 = r0 + q0;
-                m1 = r1 + q1;
-            } else {
-                if (n >= src_abs0 && n < src_abs1) { const float2 t = iq2[n - src_abs0]; const float r = t.x * t.x, qq = t.y * t.y; m0 = r + qq; }
-                if (n + 1 >= src_abs0 && n + 1 < src_abs1) { const float2 t = iq2[n + 1 - src_abs0]; const float r = t.x * t.x, qq = t.y * t.y; m1 = r + qq; }
-            }
-            const int k = (int)(n - wlo);
-            if (k >= 0 && k < nwin) W[k + (k >> 5)] = m0;
-            if (k + 1 >= 0 && k + 1 < nwin) W[k + 1 + ((k + 1) >> 5)] = m1;
+    const bool pmf = use_pmf != 0;
+    const bool wide = (reinterpret_cast<uintptr_t>(iq) & 15u) == 0;
+    for (uint32_t i = blockIdx.x; i < nhit; i += gridDim.x) {                 // (uniform)
+        const uint32_t g = emit_idx[i];
+        const uint32_t e = eo[g];
+        const float av = inavg[g];
+        const long long ae = (long long)base_abs + (long long)e;             // absolute index of the burst's first sample
+        // (uniform) every lane's loads inside the source: all but the hits at the two ends of the stream
+        const bool inside = pmf && wide && ae - SPC >= src_abs0 && ae + (long long)(AM_BURST - 1) * SPC + 2 < src_abs1;
+#if defined(AM_XPROF)
+        const long long xh0 = (long long)__builtin_readcyclecounter();
+#endif
+        AM_XSTAMP(0);
+        if (tid < HEAD) {
+            const float v = am_soft_chip_iq<SPC>(iq, src_abs0, src_abs1, pmf, s1, ae, tid, inside) - av;   // preamble_impl.cc:219-221
+            sb[tid] = v;
+            if (bursts_out) bursts_out[(size_t)i * AM_BURST + tid] = v;
         }
         __syncthreads();
-    }
-    if (tid < AM_BURST) {
-        const long long n = ae + (long long)tid * spc;
-        float v = 0.0f;
-        if (n < src_abs1) {
-            if (!pmf) {
-                if (n >= src_abs0) {
-                    const float2 t = iq2[n - src_abs0];
-                    const float r = t.x * t.x, q = t.y * t.y;
-                    v = r + q;
-                }
-            } else {
-                const int ii = (int)(n % spc);                // offset inside the chip (chips start at multiples of spc)
-                const int kn = (int)(n - wlo);                // window index of sample n
-                float pre = 0.0f;
-                for (int k = kn - ii; k <= kn; ++k) pre = pre + W[k + (k >> 5)];
-                if (ii == spc - 1) v = pre * s1;
-                else {
-                    float suf = 0.0f;
-                    for (int k = kn - ii - 1; k >= kn - spc + 1; --k) suf = suf + W[k + (k >> 5)];
-                    v = (suf + pre) * s1;
-                }
+        AM_XSTAMP(1);
+        const bool all = bursts_out != nullptr || am_burst_is_long(sb);       // (uniform)
+        if (tid >= HEAD && tid < AM_BURST) {
+            float v = 0.0f;                                                   // (never looked at in a short packet)
+            if (all) {
+                v = am_soft_chip_iq<SPC>(iq, src_abs0, src_abs1, pmf, s1, ae, tid, inside) - av;
+                if (bursts_out) bursts_out[(size_t)i * AM_BURST + tid] = v;
             }
+            sb[tid] = v;
         }
-        v = v - av;                                           // preamble_impl.cc:219-221
-        sb[tid] = v;
-        if (bursts_out) bursts_out[(size_t)i * AM_BURST + tid] = v;
+        __syncthreads();
+        AM_XSTAMP(2);
+        if (tid < AM_WAVE) {
+            am_tag t = am_make_tag(base_abs + e + (uint64_t)(2 * SPC - 1), rate, tt, ntt);
+            t.inavg = av;
+            t.how_late = e - pos[g];
+            if (tags_out && tid == 0) tags_out[i] = t;
+            am_slice_wave(sb, t, i, lane, crc_pow, packets);
+        }
+        __syncthreads();                                          // (sb is rewritten by the next hit)
+        AM_XSTAMP(3);
+#if defined(AM_XPROF)
+        { const long long d = (long long)__builtin_readcyclecounter() - xh0; if (d > xlong) xlong = d; ++xhits; }
+#endif
     }
-    am_tag t = am_make_tag(base_abs + e + (uint64_t)(2 * spc - 1), rate, tt, ntt);
-    t.inavg = av;
-    t.how_late = e - pos[g];
-    if (tags_out && tid == 0) tags_out[i] = t;
-    __syncthreads();
-    if (tid < AM_WAVE) am_slice_wave(sb, t, i, lane, crc_pow, packets);
+#if defined(AM_XPROF)
+    if (tid == 0 && blockIdx.x < 4096) {
+        am_xprof_log[blockIdx.x][0] = xstart; am_xprof_log[blockIdx.x][1] = (long long)__builtin_amdgcn_s_memrealtime();
+        am_xprof_log[blockIdx.x][2] = xhits; am_xprof_log[blockIdx.x][3] = xlong;
+    }
+#endif
 }
 
 hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
@@ -1462,12 +1597,12 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
                                       const uint32_t *scalars, uint32_t *host_out, hipStream_t s, const uint32_t *Mp)
 {
     if (n_max == 0) return hipSuccess;
-    const int nwin = AM_BURST * spc;
-    const size_t lds = ((size_t)nwin + (nwin >> 5) + 8 + AM_BURST) * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;        // (rates served by the streaming front end are far below)
-    hipLaunchKernelGGL(am_k_extract_slice_iq, dim3(n_max), dim3(256), lds, s, iq, src_abs0, src_abs1, use_pmf, s1, inavg,
-                       spc, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow, packets,
-                       scalars, host_out, Mp);
+    if (spc != 32) return hipErrorInvalidValue;              // (the rate the streaming front end serves)
+    const uint32_t resident = (uint32_t)am_device_cus() * 5u;   // five workgroups of 256 threads per CU (registers)
+    const uint32_t grid = n_max < resident ? n_max : resident;
+    hipLaunchKernelGGL((am_k_extract_slice_iq<32>), dim3(grid), dim3(256), 0, s, iq, src_abs0, src_abs1, use_pmf, s1,
+                       inavg, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow,
+                       packets, scalars, host_out, Mp);
     return hipGetLastError();
 }
 

@@ -22,6 +22,10 @@ struct dim3 {
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline void __threadfence_system() {}
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
