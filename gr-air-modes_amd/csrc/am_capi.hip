@@ -115,8 +115,10 @@ struct am_ctx {
 
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
-        emit, jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
+        jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y;
+    DevBuf lb_seg, lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
+    uint32_t lb_epoch = 0;
 
     // results of the last scan
     std::vector<am_packet> h_packets;   // am_slicer_work: every sliced burst, reserved[0] = accepted
@@ -182,6 +184,17 @@ int ensure(am_ctx *c, DevBuf &b, size_t bytes)
         int rc__ = ensure((c), (buf), (bytes));            \
         if (rc__ != AM_OK) return rc__;                    \
     } while (0)
+
+// slots of a chained scan for n workgroups: zeroed when (re)allocated (epoch 0 is never used)
+int ensure_slots(am_ctx *c, DevBuf &b, size_t n)
+{
+    const size_t bytes = (n + 8) * sizeof(unsigned long long);
+    if (bytes <= b.cap && b.p) return AM_OK;
+    int rc = ensure(c, b, bytes);
+    if (rc != AM_OK) return rc;
+    if (hipMemsetAsync(b.p, 0, b.cap, c->stream) != hipSuccess) return fail(c, AM_EHIP, "hipMemsetAsync");
+    return AM_OK;
+}
 
 void release(DevBuf &b)
 {
@@ -325,9 +338,10 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         const uint32_t nbs = (nseg + 2047u) / 2048u;
         ENSURE(c, c->seg_tot, ((size_t)nbs + 1) * sizeof(uint32_t));
         ENSURE(c, c->seg_base, ((size_t)nbs + 2) * sizeof(uint32_t));
-        HIPCHK(c, am_launch_exscan_blocks((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, (uint32_t *)c->seg_tot.p,
-                                          nseg, c->stream));
-        HIPCHK(c, am_launch_scan_u32((uint32_t *)c->seg_tot.p, (uint32_t *)c->seg_base.p, nbs, c->stream));
+        if (int rc = ensure_slots(c, c->lb_seg, nbs); rc != AM_OK) return rc;
+        HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg,
+                                         (unsigned long long *)c->lb_seg.p, ++c->lb_epoch, (uint32_t *)c->seg_base.p + nbs,
+                                         c->stream));
         count_ptr = (const uint32_t *)c->seg_base.p + nbs;
     } else
         HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg, c->stream));
@@ -362,18 +376,20 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
             if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
                 HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p,
-                                                (uint32_t *)c->seg_base.p, nseg, M, c->spc, am_fe3_lag(),
+                                                nullptr, nseg, M, c->spc, am_fe3_lag(),
                                                 (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             else
                 HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
                                                c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
-            HIPCHK(c, am_launch_exscan_blocks((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
-                                              (uint32_t *)c->blk_tot2.p, M, c->stream, Mp));
-            HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_tot2.p, (uint32_t *)c->blk_base2.p, nb, c->stream));
+            // compact index of each candidate's first energy: one chained scan of the counts (global offsets)
+            if (int rc = ensure_slots(c, c->lb_dc, nb); rc != AM_OK) return rc;
+            HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p, M,
+                                             (unsigned long long *)c->lb_dc.p, ++c->lb_epoch, (uint32_t *)c->blk_base2.p + nb,
+                                             c->stream, Mp));
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
-                                       (uint32_t *)c->blk_base2.p, M, c->spc, (double *)c->energy.p, c->stream, Mp));
+                                       nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp));
             HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
-                                     (uint32_t *)c->off_local.p, (uint32_t *)c->blk_base2.p, (double *)c->energy.p, M,
+                                     (uint32_t *)c->off_local.p, nullptr, (double *)c->energy.p, M,
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
                                      (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream, Mp));
         } else
@@ -494,7 +510,6 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
     c->chain_Mp = Mp;
     if (M == 0) return AM_OK;
     const size_t stride = (size_t)M + 1;
-    ENSURE(c, c->emit, stride);
     ENSURE(c, c->jump, stride * sizeof(uint32_t));
     ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
     ENSURE(c, c->cscratch, am_chain_scratch_bytes(M));
@@ -552,19 +567,19 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     *final_cur = cur0;
     if (M == 0) return AM_OK;
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
-    ENSURE(c, c->cblk_cnt, (size_t)nb * sizeof(uint32_t));
     ENSURE(c, c->cblk_off, ((size_t)nb + 1) * sizeof(uint32_t));
-    HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
-                                    (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
-                                    own_hi, (uint8_t *)c->emit.p, (uint32_t *)c->cblk_cnt.p, (uint32_t *)c->scalars.p,
-                                    emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
-    HIPCHK(c, am_launch_scan_u32((uint32_t *)c->cblk_cnt.p, (uint32_t *)c->cblk_off.p, nb, c->stream));
     // Hits are at least 240*spc apart, so their number is bounded by the span of the candidates;
     // everything downstream is launched for that bound and reads the real count on the device.
     // Packets and tags land directly in pinned host memory: one synchronisation for the whole tail.
     const uint32_t n_max = max_hits < M ? max_hits : M;
-    const uint32_t *n_ptr = (const uint32_t *)c->cblk_off.p + nb;
+    uint32_t *n_ptr = (uint32_t *)c->cblk_off.p + nb;
     ENSURE(c, c->emit_idx, (size_t)n_max * sizeof(uint32_t));
+    if (int rc = ensure_slots(c, c->lb_mark, nb); rc != AM_OK) return rc;
+    // which candidates the scan visits, which of them are hits, and their ordered list -- one launch after the walk
+    HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
+                                    (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
+                                    own_hi, (uint32_t *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
+                                    ++c->lb_epoch, (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
     if (keep_bursts) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
         if (c->pin_packets) (void)hipHostFree(c->pin_packets);
@@ -579,8 +594,6 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
         HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
         memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));     // [0..2] results of the slice launch, [8] completion ticket
     }
-    HIPCHK(c, am_launch_flag_scatter((uint8_t *)c->emit.p, M, (uint32_t *)c->cblk_off.p,
-                                     (uint32_t *)c->emit_idx.p, c->stream, Mp));
     // extraction + slicing in one launch; the bursts and their tags leave the kernel only for the block-level
     // caller (am_preamble_work), the accepted packets always land in pinned host memory
     c->pin_scalars[0] = 0;
@@ -760,8 +773,8 @@ void am_destroy(am_ctx *c)
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->bits, &c->seg_tot, &c->seg_base, &c->blk_cnt, &c->blk_off,
-                     &c->pos, &c->e, &c->tgt, &c->valid, &c->emit, &c->jump, &c->emit_idx,
-                     &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
+                     &c->pos, &c->e, &c->tgt, &c->valid, &c->jump, &c->emit_idx,
+                     &c->lb_seg, &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
                      &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);

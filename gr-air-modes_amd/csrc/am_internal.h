@@ -73,6 +73,10 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
                           uint8_t *valid, hipStream_t s, const uint32_t *Mp = nullptr);
+/* exclusive scan of n counts in ONE launch (2048 per workgroup, chained through slots[]: am_chain_prefix);
+ * slots: one 64-bit word per workgroup, zero at allocation; epoch: a value no earlier launch on these slots used */
+hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
+                                  uint32_t *total_out, hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s, const uint32_t *count_src = nullptr,
                             uint32_t *count_dst = nullptr);
 
@@ -123,14 +127,13 @@ hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uin
                                    uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
-                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
-                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp = nullptr);
+                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
+                                 unsigned long long *slots, uint32_t epoch, uint32_t *scalars, int want_resume,
+                                 hipStream_t s, const uint32_t *Mp = nullptr);
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
                                       hipStream_t s, const uint32_t *Mp = nullptr);
-hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
-                                  uint32_t *out_idx, hipStream_t s, const uint32_t *Mp = nullptr);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
 /* "rx_time" stream tag (lib/preamble_impl.cc:165-170): from item `offset` on, time = (secs, frac) +

@@ -458,7 +458,7 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
     if (seg >= nseg) return;                                 // (wave-uniform; no workgroup barrier below)
     const uint32_t cnt = seg_cnt[seg];
     if (cnt == 0) return;
-    const uint32_t off = off_local[seg] + blk_base[seg / AM_SCAN_BLK];   // two-level exclusive scan of seg_cnt
+    const uint32_t off = off_local[seg] + (blk_base ? blk_base[seg / AM_SCAN_BLK] : 0u);   // exclusive scan of seg_cnt (two-level, or global)
     if (off >= M) return;
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t nw = 48u;                                 // words of a segment (one wave of the front end = one 48-chip block)
@@ -508,6 +508,72 @@ hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Exclusive prefix of one value per workgroup inside a single launch (a chained scan in its plainest form).
+// Workgroup b publishes (epoch, value) in slots[b] and adds up the values of the workgroups before it, waiting
+// for the ones that have not published yet: those were dispatched before b, so they are running or done and the
+// wait cannot deadlock.  `epoch` differs from launch to launch (the host counts), so the slots are never reset.
+// The word carries its own payload, so the atomics are relaxed (device scope): release / acquire would write back
+// and invalidate the whole L2 of the XCD at every step (measured: the marking kernel 18 -> 35 us).
+// All threads of the workgroup call it (it synchronises); red = LDS scratch, one word per wave.
+// What it replaces: a one-workgroup scan launch between producer and consumer, 4.7 us each, three per scan.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, uint32_t b, uint32_t epoch, uint32_t mine,
+                                                    uint32_t *red)
+{
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&slots[b], ((unsigned long long)epoch << 32) | (unsigned long long)mine, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t acc = 0;
+    for (uint32_t k = threadIdx.x; k < b; k += blockDim.x) {
+        unsigned long long v = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((uint32_t)(v >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        acc += (uint32_t)v;
+    }
+    for (int o = AM_WAVE / 2; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, AM_WAVE);
+    const int nw = (int)(blockDim.x / AM_WAVE);
+    __syncthreads();                                          // (red may still be read from an earlier use)
+    if ((threadIdx.x & (AM_WAVE - 1)) == 0) red[threadIdx.x / AM_WAVE] = acc;
+    __syncthreads();
+    uint32_t tot = 0;
+    for (int k = 0; k < nw; ++k) tot += red[k];
+    return tot;
+}
+
+// exclusive scan of n counts in one launch: 2048 elements per workgroup, the offsets of the workgroups before it
+// through am_chain_prefix; *total_out = the sum of all counts
+__global__ void __launch_bounds__(256)
+am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t ncap,
+                  const uint32_t *__restrict__ Mp, unsigned long long *slots, uint32_t epoch,
+                  uint32_t *__restrict__ total_out)
+{
+    const uint32_t n = am_count(ncap, Mp);
+    __shared__ uint32_t ws[256 / AM_WAVE];
+    __shared__ uint32_t red[256 / AM_WAVE];
+    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
+    const uint32_t base = blockIdx.x * AM_SCAN_BLK + threadIdx.x * 8;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+    for (int d = 1; d < AM_WAVE; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
+        if (lane >= d) incl += up;
+    }
+    if (lane == AM_WAVE - 1) ws[wv] = incl;
+    __syncthreads();
+    uint32_t off = incl - sum, total = 0;
+    for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) off += ws[k]; total += ws[k]; }
+    const uint32_t before = am_chain_prefix(slots, blockIdx.x, epoch, total, red);
+    off += before;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = off; off += v[k]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = before + total;
+}
+
 // block-local exclusive scan (2048 elements per workgroup) + block totals
 __global__ void __launch_bounds__(256)
 am_k_exscan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out_local, uint32_t *__restrict__ blk_tot,
@@ -537,7 +603,7 @@ am_k_exscan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out_l
 __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_local,
                                               const uint32_t *__restrict__ blk_base, uint32_t c)
 {
-    return off_local[c] + blk_base[c / AM_SCAN_BLK];
+    return off_local[c] + (blk_base ? blk_base[c / AM_SCAN_BLK] : 0u);   // (null: the offsets are global already)
 }
 
 // E(q) for every compact index.  One workgroup owns AM_ECB consecutive candidates, whose compact
@@ -692,6 +758,14 @@ hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint
                        out_local, blk_tot, n, Mp);
     return hipGetLastError();
 }
+hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
+                                  uint32_t *total_out, hipStream_t s, const uint32_t *Mp)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_k_exscan_chain, dim3((n + AM_SCAN_BLK - 1) / AM_SCAN_BLK), dim3(256), 0, s, in, out, n, Mp, slots,
+                       epoch, total_out);
+    return hipGetLastError();
+}
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
                             double *energy, hipStream_t s, const uint32_t *Mp)
@@ -761,20 +835,25 @@ am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ t
 #define AM_CB_THREADS 256
 #define AM_CB_PER (AM_CB / AM_CB_THREADS)
 #define AM_CB_LEVELS 11             /* 2^11 = AM_CB */
-#define AM_CB_HEADW 128             /* head nodes per block the walk keeps in LDS ... */
-#define AM_CB_HEADCAP 36864         /* ... as long as all of them fit (144 KB) */
+#define AM_CB_HEADW 256             /* head nodes per block the walk keeps in LDS (16-bit links) ... */
+#define AM_CB_HEADCAP 65534         /* ... as long as all of them fit (slots are 16-bit, two values reserved; 128 KB of links + the group tables) */
 #define AM_CB_NONE 0xFFFFFFFFu
+#define AM_CB_END 0xFFFFu            /* link: the orbit leaves the candidate list */
+#define AM_CB_OUT 0xFFFEu            /* link: it lands beyond the next block's head (resolved through exitnode[]) */
+#ifndef AM_CB_GROUP
+#define AM_CB_GROUP 16              /* blocks per group of the two-level walk */
+#endif
 
 __global__ void __launch_bounds__(AM_CB_THREADS)
 am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw, uint32_t *__restrict__ exitnode,
-               uint32_t *__restrict__ lastnode, uint32_t *__restrict__ headexit, const uint32_t *__restrict__ Mp)
+               uint32_t *__restrict__ lastnode, uint16_t *__restrict__ headlink, const uint32_t *__restrict__ Mp)
 {
     __shared__ uint32_t e[2][AM_CB];           // orbit node 2^r hops ahead, clipped to the first one outside
     __shared__ uint32_t l[2][AM_CB];           // the orbit node just before it (always inside the block)
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t base = blockIdx.x * AM_CB;
     if (base >= M) {                                          // (capacity launch: nothing here)
-        for (uint32_t i = threadIdx.x; i < headw; i += blockDim.x) headexit[(size_t)blockIdx.x * headw + i] = M;
+        for (uint32_t i = threadIdx.x; i < headw; i += blockDim.x) headlink[(size_t)blockIdx.x * headw + i] = (uint16_t)AM_CB_END;
         return;
     }
     const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
@@ -803,7 +882,11 @@ am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw
             exitnode[base + i] = e[cur][i];
             if (lastnode) lastnode[base + i] = l[cur][i];
         }
-        if (i < headw) headexit[(size_t)blockIdx.x * headw + i] = (i < n) ? e[cur][i] : M;
+        if (i < headw) {
+            // the head's exits as links to the next table slot (slot = block * headw + index in block; headw = 2^k)
+            const uint32_t g = (i < n) ? e[cur][i] : M, kb = g / AM_CB, ki = g % AM_CB;
+            headlink[(size_t)blockIdx.x * headw + i] = (uint16_t)(g >= M ? AM_CB_END : (ki < headw ? kb * headw + ki : AM_CB_OUT));
+        }
     }
 }
 
@@ -814,86 +897,195 @@ am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw
 // be: the head table is turned into "next table slot" links (16 bit: slot = block * headw + index),
 // and a hop is one dependent LDS read plus one LDS write that records the block's entry; node
 // numbers, global memory and the entry array only appear outside that loop.
-#define AM_CB_END 0xFFFFu            /* link: the orbit leaves the candidate list */
-#define AM_CB_OUT 0xFFFEu            /* link: it lands beyond the next block's head (resolved through exitnode[]) */
 
-// head table -> LDS as 16-bit links to the next table slot (slot = block * headw + index in block),
-// in batches of 8 independent loads per thread (one memory round trip per batch, not per word)
-__device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint32_t *__restrict__ headexit,
-                                                   uint32_t total, uint32_t headw, uint32_t M)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AM_PIN_U4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#else
+#define AM_PIN_U4(v) ((void)0)
+#endif
+// head table (16-bit links, written by am_k_cblk_exit) -> LDS, 16 bytes per load, all of a thread's loads in
+// flight at once (eight)
+__device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint16_t *__restrict__ headlink, uint32_t total)
 {
-    for (uint32_t f0 = threadIdx.x; f0 < total; f0 += 8u * blockDim.x) {
-        uint32_t t[8];
+    const uint32_t nvec = total / 8u;                        // (the table starts 16-byte aligned in the scratch buffer)
+    const uint4 *src = reinterpret_cast<const uint4 *>(headlink);
+    uint4 *dst = reinterpret_cast<uint4 *>(lnk);
+    for (uint32_t f0 = threadIdx.x; f0 < nvec; f0 += 8u * blockDim.x) {
+        uint4 t[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t f = f0 + (uint32_t)k * blockDim.x;
-            t[k] = headexit[f < total ? f : total - 1u];
+            t[k] = src[f < nvec ? f : nvec - 1u];
         }
+        // (all eight loads go out before the first store waits for its own: without the pin the compiler sinks each
+        // load to its store, eight memory round trips instead of one)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) AM_PIN_U4(t[k]);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t f = f0 + (uint32_t)k * blockDim.x;
-            if (f < total) {
-                const uint32_t g = t[k], kb = g / AM_CB, ki = g % AM_CB;
-                lnk[f] = (uint16_t)(g >= M ? AM_CB_END : (ki < headw ? kb * headw + ki : AM_CB_OUT));   // headw = 2^k
-            }
+            if (f < nvec) dst[f] = t[k];
         }
     }
+    for (uint32_t f = nvec * 8u + threadIdx.x; f < total; f += blockDim.x) lnk[f] = headlink[f];
 }
 
+#if defined(AM_WALK_DEBUG)
+// tuning builds only: what the walk does (printed by its lane 0, on the device or in the CPU emulation)
+#include <stdio.h>
+#define AM_WALK_COUNT(k) (wdbg[k]++)
+#define AM_WALK_ITER(k) (wdbg[2 + (k)]++)
+#define AM_WALK_CLOCK(k) (wclk[k] = (long long)__builtin_readcyclecounter())
+#define AM_WALK_REPORT() printf("walk: nblk %u headw %u M %u root %u | global hops %d + %d, group jumps %d, plain hops %d, step-3 hops (lane 0) %d | cycles: load+root %lld, step 1 %lld, step 2 %lld, step 3 %lld\n", nblk, headw, M, root_s, wdbg[0], wdbg[1], wdbg[2], wdbg[3], wdbg[4], wclk[1] - wclk[0], wclk[2] - wclk[1], wclk[3] - wclk[2], wclk[4] - wclk[3])
+#else
+#define AM_WALK_COUNT(k) ((void)0)
+#define AM_WALK_ITER(k) ((void)0)
+#define AM_WALK_CLOCK(k) ((void)0)
+#define AM_WALK_REPORT() ((void)0)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define AM_KEEP_VGPR(x) asm volatile("" : "+v"(x))
 #else
 #define AM_KEEP_VGPR(x) ((void)0)
 #endif
 
+// entry[b] = node at which the scan that starts at position cur0 enters block b, AM_CB_NONE if it
+// jumps over the block.  scalars[0] = cur0 (the emit kernel raises it to the resume position),
+// scalars[1] = 0.
+// The walk is one hop per block (a dependent LDS read each), so it is done on two levels: the blocks are cut into
+// groups of AM_CB_GROUP; (1) in parallel, from EVERY head slot of every group's first block, the slot at which the
+// orbit leaves the group (<= AM_CB_GROUP hops each); (2) one lane goes from group to group through that table;
+// (3) in parallel, one lane per group repeats the hops inside its group from the slot (2) found and records the
+// entry node of each block.  Global memory only for the root, for a link that lands beyond a head, and for an
+// unusually long head (ki >= headw): those go hop by hop in step (2).
 __global__ void __launch_bounds__(1024)
 am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
-               const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
+               const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
                uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
-    HIP_DYNAMIC_SHARED(uint16_t, lnk);         // [nblk * headw] links | [nblk] index of each block's entry node
+#if defined(AM_WALK_DEBUG)
+    int wdbg[5] = {0, 0, 0, 0, 0};
+    long long wclk[5] = {0, 0, 0, 0, 0};
+    AM_WALK_CLOCK(0);
+#endif
+    HIP_DYNAMIC_SHARED(uint16_t, lnk);         // [nblk * headw (+pad to 8)] links | [nblk] entry index | [ngrp * headw] group exits | [ngrp] group entry slots
     const uint32_t total = nblk * headw;
-    uint16_t *ent = lnk + total;
+    const uint32_t ngrp = (nblk + AM_CB_GROUP - 1u) / AM_CB_GROUP;
+    uint16_t *ent = lnk + ((total + 7u) & ~7u);
+    uint16_t *gex = ent + nblk;
+    uint16_t *gin = gex + ngrp * headw;
     __shared__ uint32_t seg, root_s;
-    am_cblk_load_links(lnk, headexit, total, headw, M);
-    for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) ent[bb] = (uint16_t)AM_CB_END;
-    // root = first candidate with pos >= cur0, in two parallel rounds (two dependent loads in all):
-    // which of 1024 equal segments holds it, then which node of that segment
+    // root = first candidate with pos >= cur0, in two parallel rounds (two dependent loads in all): which of 1024
+    // equal segments holds it, then which node of that segment.  The first round's loads go out together with the
+    // table's.
     const uint32_t stride = (M + blockDim.x - 1u) / blockDim.x;
+    const uint32_t lo = threadIdx.x * stride;
+    const uint32_t hi = (lo + stride < M) ? lo + stride : M;
+    uint32_t p_hi = 0, p_lo = 0;
+#if !(defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 1))
+    if (stride && lo < M) { p_hi = pos[hi - 1u]; p_lo = lo ? pos[lo - 1u] : 0u; }
+#endif
     if (threadIdx.x == 0) { seg = M; root_s = M; scalars[0] = cur0; scalars[1] = 0u; }
+#if defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 1)
+    if (threadIdx.x == 0) root_s = 0;                         // (tuning builds: valid when the scan starts before the first candidate)
+#endif
+#if !(defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 2))
+    am_cblk_load_links(lnk, headlink, total);
+#endif
+    for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) ent[bb] = (uint16_t)AM_CB_END;
+    for (uint32_t gg = threadIdx.x; gg < ngrp; gg += blockDim.x) gin[gg] = (uint16_t)AM_CB_END;
     __syncthreads();
-    if (stride) {
-        const uint32_t lo = threadIdx.x * stride;
-        const uint32_t hi = (lo + stride < M) ? lo + stride : M;
-        if (lo < M && pos[hi - 1u] >= cur0 && (lo == 0 || pos[lo - 1u] < cur0)) seg = lo;
-    }
+    if (stride && lo < M && p_hi >= cur0 && (lo == 0 || p_lo < cur0)) seg = lo;
     __syncthreads();
+#if !(defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 1))
     for (uint32_t g = seg + threadIdx.x; g < M && g < seg + stride; g += blockDim.x)
         if (pos[g] >= cur0 && (g == 0 || pos[g - 1u] < cur0)) root_s = g;
+#endif
+    const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
+    AM_WALK_CLOCK(1);
+    // (1) group exits: the slot reached from head slot h of group gi's first block once the orbit is past the group,
+    // or the slot inside the group whose link is not a slot (END / OUT)
+#if defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 4)
+    if (false)
+#endif
+    // (one walker at a time per thread: four side by side were tried, 50 % slower)
+    for (uint32_t idx = threadIdx.x; idx < ngrp * headw; idx += blockDim.x) {
+        const uint32_t gi = idx >> hs, h = idx & hm;
+        const uint32_t limit = (gi + 1u) * AM_CB_GROUP;      // first block of the next group
+        uint32_t slot = ((gi * AM_CB_GROUP) << hs) + h;
+        for (int hop = 0; hop < AM_CB_GROUP; ++hop) {        // (a link leads to a later block: <= AM_CB_GROUP hops)
+            const uint32_t nx = lnk[slot];
+            if (nx >= AM_CB_OUT) break;
+            slot = nx;
+            if ((slot >> hs) >= limit) break;
+        }
+        gex[idx] = (uint16_t)slot;
+    }
     __syncthreads();
+    AM_WALK_CLOCK(2);
+    // (2) one lane, group to group
+#if defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 12)
+    if (false) {
+#else
     if (threadIdx.x == 0) {
-        const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
-        uint32_t g = root_s;                                 // node the orbit is at (outside the fast loop)
+#endif
+        uint32_t g = root_s;                                 // node the orbit is at
         while (g < M) {
-            uint32_t kb = g / AM_CB, ki = g % AM_CB;
-            ent[kb] = (uint16_t)ki;
-            if (ki >= headw) { g = __builtin_nontemporal_load(&exitnode[g]); continue; }   // root / long head
-            uint32_t slot = (kb << hs) + ki, nx;
-            // The slot stays in a vector register: everything here is uniform (one lane), and the compiler
-            // would otherwise move each loaded link to the scalar unit (v_readfirstlane + scalar address
-            // arithmetic + v_mov back) -- all of it on the load-to-load dependency chain of the walk.
-            AM_KEEP_VGPR(slot);
-            while ((nx = lnk[slot]) < AM_CB_OUT) {           // the fast loop: one hop per block
-                slot = nx;
-                ent[slot >> hs] = (uint16_t)(slot & hm);
+            const uint32_t kb = g / AM_CB, ki = g % AM_CB;
+            if (ki >= headw) {                               // root / long head: the node itself is the entry; one global hop
+                ent[kb] = (uint16_t)ki;
+                g = exitnode[g];
+                AM_WALK_COUNT(0);
+                continue;
             }
-            if (nx == AM_CB_END) break;
-            // lands beyond a head: one hop through global memory
-            g = __builtin_nontemporal_load(&exitnode[(slot >> hs) * AM_CB + (slot & hm)]);
+            uint32_t slot = (kb << hs) + ki;
+            bool done = false;
+            for (;;) {
+                const uint32_t b = slot >> hs;
+                uint32_t nx;
+                if (b % AM_CB_GROUP == 0u) {                 // a group's first block: through the group in one step
+                    const uint32_t gi = b / AM_CB_GROUP;
+                    gin[gi] = (uint16_t)slot;                // (step 3 records the entries from here)
+                    const uint32_t r = gex[(gi << hs) + (slot & hm)];
+                    AM_WALK_ITER(0);
+                    if ((r >> hs) >= (gi + 1u) * AM_CB_GROUP) { slot = r; continue; }
+                    slot = r;                                // stuck inside the group: its link is END or OUT
+                    nx = lnk[slot];
+                } else {                                     // (after a global hop: plain hops to the next group)
+                    ent[b] = (uint16_t)(slot & hm);
+                    nx = lnk[slot];
+                    AM_WALK_ITER(1);
+                    if (nx < AM_CB_OUT) { slot = nx; continue; }
+                }
+                if (nx == AM_CB_END) { done = true; break; }
+                // lands beyond a head: one hop through global memory
+                g = exitnode[(slot >> hs) * AM_CB + (slot & hm)];
+                AM_WALK_COUNT(1);
+                break;
+            }
+            if (done) break;
         }
     }
     __syncthreads();
+    AM_WALK_CLOCK(3);
+    // (3) the entries inside every group the orbit entered at its first block
+    for (uint32_t gi = threadIdx.x; gi < ngrp; gi += blockDim.x) {
+        uint32_t slot = gin[gi];
+        if (slot == AM_CB_END) continue;
+        const uint32_t limit = (gi + 1u) * AM_CB_GROUP;
+        for (int hop = 0; hop <= AM_CB_GROUP; ++hop) {
+            if ((slot >> hs) >= limit) break;
+            ent[slot >> hs] = (uint16_t)(slot & hm);
+            AM_WALK_ITER(2);
+            const uint32_t nx = lnk[slot];
+            if (nx >= AM_CB_OUT) break;
+            slot = nx;
+        }
+    }
+    __syncthreads();
+    AM_WALK_CLOCK(4);
+    if (threadIdx.x == 0) AM_WALK_REPORT();
     for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) {
         const uint32_t ki = ent[bb];
         entry[bb] = (ki == AM_CB_END) ? AM_CB_NONE : bb * AM_CB + ki;
@@ -905,13 +1097,13 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
 __global__ void __launch_bounds__(1024)
 am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt,
                      const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ lastnode,
-                     const uint32_t *__restrict__ headexit, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t n,
+                     const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t n,
                      uint32_t lead_end, uint64_t base_abs, am_shard_exit *__restrict__ table,
                      const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
     HIP_DYNAMIC_SHARED(uint16_t, lnk);
-    am_cblk_load_links(lnk, headexit, nblk * headw, headw, M);
+    am_cblk_load_links(lnk, headlink, nblk * headw);
     __syncthreads();
     const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -953,8 +1145,10 @@ struct am_emit_args {
     uint32_t emit_max;              // room rule (:212): a valid hit too close to the end of the stream is not
                                     // emitted (and nothing after it can be)
     uint32_t own_lo, own_hi;        // first-stage positions this GPU's time chunk owns (everything on one GPU)
-    uint8_t *emit;                  // out: per candidate, 1 = a hit to extract
-    uint32_t *blk_cnt;              // out: hits per block of AM_CB candidates (for the ordered compaction)
+    uint32_t *emit_idx;             // out: the candidates to extract, in position order
+    uint32_t *n_out;                // out: how many
+    unsigned long long *slots;      // chained scan of the per-block hit counts (am_chain_prefix)
+    uint32_t epoch;
     uint32_t *scalars;              // [0]: raised to the largest resume target of a visited candidate
     int want_resume;
 };
@@ -965,76 +1159,89 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
 {
     __shared__ uint16_t J[AM_CB_LEVELS][AM_CB];
     __shared__ uint8_t V[AM_CB];
-    __shared__ uint32_t wc[AM_CB_THREADS / AM_WAVE], wmax[AM_CB_THREADS / AM_WAVE];
+    __shared__ uint32_t wc[AM_CB_PER][AM_CB_THREADS / AM_WAVE], wmax[AM_CB_THREADS / AM_WAVE];
+    __shared__ uint32_t red[AM_CB_THREADS / AM_WAVE];
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t base = blockIdx.x * AM_CB;
     const uint32_t ent = (base < M) ? entry[blockIdx.x] : AM_CB_NONE;
-    if (ent == AM_CB_NONE) {                                  // uniform: the scan jumps over this block (or nothing here)
-        const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
-        for (int k = 0; k < AM_CB_PER; ++k) {
-            const uint32_t g = base + threadIdx.x + k * AM_CB_THREADS;
-            if (g < end) ea.emit[g] = 0;
-        }
-        if (threadIdx.x == 0) ea.blk_cnt[blockIdx.x] = 0;
-        return;
-    }
-    const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
-    const uint32_t n = end - base;
-    const uint16_t OUT = (uint16_t)AM_CB;                    // "leaves the block"
-    for (int k = 0; k < AM_CB_PER; ++k) {
-        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-        uint16_t t = OUT;
-        if (i < n) { const uint32_t j = jump0[base + i]; if (j < end) t = (uint16_t)(j - base); }
-        J[0][i] = t;
-        V[i] = (base + i == ent) ? 1 : 0;
-    }
-    __syncthreads();
-    for (int l = 1; l < AM_CB_LEVELS; ++l) {
-        for (int k = 0; k < AM_CB_PER; ++k) {
-            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-            const uint16_t t = J[l - 1][i];
-            J[l][i] = (t == OUT) ? OUT : J[l - 1][t];
-        }
-        __syncthreads();
-    }
-    // top-down: every marked node marks the node 2^l hops ahead (marks only ever land on the orbit)
-    for (int l = AM_CB_LEVELS - 1; l >= 0; --l) {
-        for (int k = 0; k < AM_CB_PER; ++k) {
-            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-            if (V[i]) { const uint16_t t = J[l][i]; if (t != OUT) V[t] = 1; }
-        }
-        __syncthreads();
-    }
-    // emit flags + their count (for the ordered compaction), and where the scan resumes after
-    // everything visited here: the largest target (only needed when the stream continues).
-    // Same-address atomics serialise (~11 ns each): one per workgroup.
     const int lane = threadIdx.x & (AM_WAVE - 1), w = threadIdx.x / AM_WAVE;
-    uint32_t cnt = 0, tmax = 0;
-    for (int k = 0; k < AM_CB_PER; ++k) {
-        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-        const uint32_t g = base + i;
-        const bool vis = i < n && V[i] != 0;
-        bool em = false;
-        if (vis) {
-            const uint32_t p = ea.pos[g];
-            em = ea.valid[g] && ea.e[g] <= ea.emit_max && p >= ea.own_lo && p < ea.own_hi;
-            if (ea.want_resume) { const uint32_t tg = ea.tgt[g]; tmax = tg > tmax ? tg : tmax; }
+    uint32_t embits = 0, tmax = 0;                            // bit k: node threadIdx.x + k * AM_CB_THREADS is a hit
+    if (ent != AM_CB_NONE) {                                  // (uniform; otherwise the scan jumps over this block or nothing is here)
+        const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
+        const uint32_t n = end - base;
+        const uint16_t OUT = (uint16_t)AM_CB;                // "leaves the block"
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            uint16_t t = OUT;
+            if (i < n) { const uint32_t j = jump0[base + i]; if (j < end) t = (uint16_t)(j - base); }
+            J[0][i] = t;
+            V[i] = (base + i == ent) ? 1 : 0;
         }
-        if (i < n) ea.emit[g] = em ? 1 : 0;
-        cnt += (uint32_t)__popcll(__ballot(em));
+        __syncthreads();
+        for (int l = 1; l < AM_CB_LEVELS; ++l) {
+            for (int k = 0; k < AM_CB_PER; ++k) {
+                const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+                const uint16_t t = J[l - 1][i];
+                J[l][i] = (t == OUT) ? OUT : J[l - 1][t];
+            }
+            __syncthreads();
+        }
+        // top-down: every marked node marks the node 2^l hops ahead (marks only ever land on the orbit)
+        for (int l = AM_CB_LEVELS - 1; l >= 0; --l) {
+            for (int k = 0; k < AM_CB_PER; ++k) {
+                const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+                if (V[i]) { const uint16_t t = J[l][i]; if (t != OUT) V[t] = 1; }
+            }
+            __syncthreads();
+        }
+        // which visited nodes are hits, and where the scan resumes after everything visited here: the largest
+        // target (only needed when the stream continues)
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            const uint32_t g = base + i;
+            const bool vis = i < n && V[i] != 0;
+            bool em = false;
+            if (vis) {
+                const uint32_t p = ea.pos[g];
+                em = ea.valid[g] && ea.e[g] <= ea.emit_max && p >= ea.own_lo && p < ea.own_hi;
+                if (ea.want_resume) { const uint32_t tg = ea.tgt[g]; tmax = tg > tmax ? tg : tmax; }
+            }
+            if (em) embits |= 1u << k;
+        }
+    }
+    // ordered compaction of the hits, in the same launch: counts per (round k, wave) -> this block's total -> the
+    // totals of the blocks before it (am_chain_prefix) -> every hit's index in emit_idx[].  Node order is
+    // (k, wave, lane).
+    for (int k = 0; k < AM_CB_PER; ++k) {
+        const unsigned long long m = __ballot((embits >> k) & 1u);
+        if (lane == 0) wc[k][w] = (uint32_t)__popcll(m);
     }
     for (int o = 32; o >= 1; o >>= 1) {
         const uint32_t other = (uint32_t)__shfl_xor((int)tmax, o, AM_WAVE);
         tmax = other > tmax ? other : tmax;
     }
-    if (lane == 0) { wc[w] = cnt; wmax[w] = tmax; }
+    if (lane == 0) wmax[w] = tmax;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0, m = 0;
-        for (int k = 0; k < AM_CB_THREADS / AM_WAVE; ++k) { tot += wc[k]; m = wmax[k] > m ? wmax[k] : m; }
-        ea.blk_cnt[blockIdx.x] = tot;
-        if (ea.want_resume && m) atomicMax(&ea.scalars[0], m);
+    uint32_t tot = 0;
+    for (int k = 0; k < AM_CB_PER; ++k)
+        for (int q = 0; q < AM_CB_THREADS / AM_WAVE; ++q) tot += wc[k][q];
+    // Same-address atomics serialise (~11 ns each): one per workgroup.
+    if (threadIdx.x == 0 && ea.want_resume) {
+        uint32_t m = 0;
+        for (int k = 0; k < AM_CB_THREADS / AM_WAVE; ++k) m = wmax[k] > m ? wmax[k] : m;
+        if (m) atomicMax(&ea.scalars[0], m);
     }
+    const uint32_t before = am_chain_prefix(ea.slots, blockIdx.x, ea.epoch, tot, red);
+    uint32_t off = before;
+    for (int k = 0; k < AM_CB_PER; ++k) {
+        const bool em = ((embits >> k) & 1u) != 0u;
+        const unsigned long long m = __ballot(em);
+        uint32_t o = off;
+        for (int q = 0; q < w; ++q) o += wc[k][q];
+        if (em) ea.emit_idx[o + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + threadIdx.x + (uint32_t)k * AM_CB_THREADS;
+        for (int q = 0; q < AM_CB_THREADS / AM_WAVE; ++q) off += wc[k][q];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *ea.n_out = before + tot;
 }
 
 // compute units of the current device (cached per device: a process may hold contexts on several)
@@ -1072,7 +1279,7 @@ static am_chain_layout am_chain_layout_of(uint32_t M)
     L.headw = am_chain_headw(L.nblk);
     L.off_last = (size_t)M + 1;                     // exitnode[M+1] | lastnode[M+1] | entry[nblk+8] | headexit
     L.off_entry = L.off_last + (size_t)M + 1;
-    L.off_head = L.off_entry + L.nblk + 8;
+    L.off_head = (L.off_entry + L.nblk + 8 + 3) & ~(size_t)3;     // (16-byte aligned: the walk copies it 16 bytes at a time)
     L.words = L.off_head + (size_t)L.nblk * L.headw + 8;
     return L;
 }
@@ -1086,7 +1293,7 @@ static hipError_t am_chain_walk_lds(const void *kernel, bool (&done)[64])
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
     hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((AM_CB_HEADCAP + 1) * sizeof(uint32_t)));
+                                        (int)(152 * 1024));
     if (rc == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return rc;
 }
@@ -1099,15 +1306,16 @@ hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uin
     const am_chain_layout L = am_chain_layout_of(M);
     hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M, jump0, Mp);
     hipLaunchKernelGGL(am_k_cblk_exit, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, M, L.headw, scratch,
-                       want_last ? scratch + L.off_last : nullptr, scratch + L.off_head, Mp);
+                       want_last ? scratch + L.off_last : nullptr, reinterpret_cast<uint16_t *>(scratch + L.off_head), Mp);
     return hipGetLastError();
 }
 
 // steps 2 + 3: which candidates the scan that starts at position cur0 visits, and what it does with them:
-// emit[] flags, hits per block of AM_CB candidates in blk_cnt[], scalars[0] = resume position
+// emit_idx[0 .. *n_out) = the hits in position order, scalars[0] = resume position
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
-                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint8_t *emit, uint32_t *blk_cnt,
+                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
+                                 unsigned long long *slots, uint32_t epoch,
                                  uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
@@ -1115,17 +1323,18 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     static bool attr_set[64] = {};
     if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_walk), attr_set); rc != hipSuccess)
         return rc;
-    const size_t lds = ((size_t)L.nblk * L.headw + L.nblk + 2) * sizeof(uint16_t);
-    hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, scratch + L.off_head, M, L.nblk,
+    const size_t ngrp = ((size_t)L.nblk + AM_CB_GROUP - 1) / AM_CB_GROUP;
+    const size_t lds = ((size_t)L.nblk * L.headw + 8 + L.nblk + ngrp * L.headw + ngrp + 2) * sizeof(uint16_t);
+    hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp);
     am_emit_args ea;
     ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.emit_max = emit_max; ea.own_lo = own_lo;
-    ea.own_hi = own_hi; ea.emit = emit; ea.blk_cnt = blk_cnt; ea.scalars = scalars; ea.want_resume = want_resume;
+    ea.own_hi = own_hi; ea.emit_idx = emit_idx; ea.n_out = n_out; ea.slots = slots; ea.epoch = epoch; ea.scalars = scalars;
+    ea.want_resume = want_resume;
     hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M, ea,
                        Mp);
     return hipGetLastError();
 }
-static_assert(AM_CB == AM_DET_PER_BLOCK, "blk_cnt[] of the chain and the flag compaction use the same blocks");
 
 // exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
@@ -1138,49 +1347,9 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
     if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_exit_table), attr_set);
         rc != hipSuccess)
         return rc;
-    const size_t lds = ((size_t)L.nblk * L.headw + 2) * sizeof(uint16_t);
+    const size_t lds = ((size_t)L.nblk * L.headw + 8) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
-                       scratch + L.off_head, M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Ordered compaction of a byte-flag array: per-block counts (am_k_cblk_mark) -> scan -> scatter.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(AM_DET_THREADS)
-am_k_flag_scatter(const uint8_t *__restrict__ flags, uint32_t Mcap, const uint32_t *__restrict__ blk_off,
-                  uint32_t *__restrict__ out_idx, const uint32_t *__restrict__ Mp)
-{
-    const uint32_t M = am_count(Mcap, Mp);
-    __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    const int w = threadIdx.x / AM_WAVE;
-    const uint32_t base = blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
-    uint32_t cnt = 0;
-    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
-        const uint32_t g = base + it * AM_WAVE + lane;
-        const bool c = g < M && flags[g] != 0;
-        cnt += (uint32_t)__popcll(__ballot(c));
-    }
-    if (lane == 0) wc[w] = cnt;
-    __syncthreads();
-    uint32_t off = blk_off[blockIdx.x];
-    for (int k = 0; k < w; ++k) off += wc[k];
-    for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
-        const uint32_t g = base + it * AM_WAVE + lane;
-        const bool c = g < M && flags[g] != 0;
-        const unsigned long long m = __ballot(c);
-        if (c) out_idx[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = g;
-        off += (uint32_t)__popcll(m);
-    }
-}
-
-hipError_t am_launch_flag_scatter(const uint8_t *flags, uint32_t M, const uint32_t *blk_off,
-                                  uint32_t *out_idx, hipStream_t s, const uint32_t *Mp)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_flag_scatter, dim3(am_grid(M, AM_DET_PER_BLOCK)), dim3(AM_DET_THREADS), 0, s, flags,
-                       M, blk_off, out_idx, Mp);
+                       reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
     return hipGetLastError();
 }
 

@@ -61,6 +61,7 @@ inline void __syncthreads() { hipemu::barrier(); }
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(p))
 // only used on values that are already the same in every lane of the wave
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #ifndef __clang__
