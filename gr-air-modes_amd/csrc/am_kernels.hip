@@ -543,6 +543,31 @@ __device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, u
     return tot;
 }
 
+// The workgroup's place in the chain.  Normally blockIdx.x: workgroups start in index order as long as all of them
+// fit on the chip at once, and a launch of this family is far below that (hundreds of workgroups).  Beyond
+// AM_CHAIN_TICKET_MIN workgroups (millions of candidates in one scan: pathological input) the order in which the
+// XCDs start their share is no longer a safe assumption, and a workgroup waiting for one that has not started could
+// wait for ever; then the place is a ticket drawn at the start (an atomic counter tagged with the launch's epoch),
+// so everything a workgroup waits for is already running.  Same-address atomics serialise (~11 ns each), hence
+// not the default.  All threads call it (it synchronises); tick = LDS scratch word.
+#ifndef AM_CHAIN_TICKET_MIN
+#define AM_CHAIN_TICKET_MIN 512
+#endif
+__device__ __forceinline__ uint32_t am_chain_place(unsigned long long *ticket, uint32_t epoch, uint32_t *tick)
+{
+    if (gridDim.x <= AM_CHAIN_TICKET_MIN) return blockIdx.x;                  // (uniform)
+    if (threadIdx.x == 0) {
+        unsigned long long old = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+        do {
+            want = ((uint32_t)(old >> 32) == epoch) ? old + 1ull : (((unsigned long long)epoch << 32) | 1ull);
+        } while (!__hip_atomic_compare_exchange_strong(ticket, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+        *tick = ((uint32_t)(old >> 32) == epoch) ? (uint32_t)old : 0u;
+    }
+    __syncthreads();
+    return *tick;
+}
+
 // exclusive scan of n counts in one launch: 2048 elements per workgroup, the offsets of the workgroups before it
 // through am_chain_prefix; *total_out = the sum of all counts
 __global__ void __launch_bounds__(256)
@@ -553,8 +578,10 @@ am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, u
     const uint32_t n = am_count(ncap, Mp);
     __shared__ uint32_t ws[256 / AM_WAVE];
     __shared__ uint32_t red[256 / AM_WAVE];
+    __shared__ uint32_t tick;
     const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
-    const uint32_t base = blockIdx.x * AM_SCAN_BLK + threadIdx.x * 8;
+    const uint32_t blk = am_chain_place(slots + gridDim.x + 2, epoch, &tick);   // (the slots array has 8 spare words)
+    const uint32_t base = blk * AM_SCAN_BLK + threadIdx.x * 8;
     uint32_t v[8], sum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
@@ -567,11 +594,11 @@ am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, u
     __syncthreads();
     uint32_t off = incl - sum, total = 0;
     for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) off += ws[k]; total += ws[k]; }
-    const uint32_t before = am_chain_prefix(slots, blockIdx.x, epoch, total, red);
+    const uint32_t before = am_chain_prefix(slots, blk, epoch, total, red);
     off += before;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = off; off += v[k]; }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = before + total;
+    if (blk == gridDim.x - 1 && threadIdx.x == 0) *total_out = before + total;
 }
 
 // block-local exclusive scan (2048 elements per workgroup) + block totals
@@ -835,7 +862,9 @@ am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ t
 #define AM_CB_THREADS 256
 #define AM_CB_PER (AM_CB / AM_CB_THREADS)
 #define AM_CB_LEVELS 11             /* 2^11 = AM_CB */
+#ifndef AM_CB_HEADW
 #define AM_CB_HEADW 256             /* head nodes per block the walk keeps in LDS (16-bit links) ... */
+#endif
 #define AM_CB_HEADCAP 65534         /* ... as long as all of them fit (slots are 16-bit, two values reserved; 128 KB of links + the group tables) */
 #define AM_CB_NONE 0xFFFFFFFFu
 #define AM_CB_END 0xFFFFu            /* link: the orbit leaves the candidate list */
@@ -1161,9 +1190,11 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
     __shared__ uint8_t V[AM_CB];
     __shared__ uint32_t wc[AM_CB_PER][AM_CB_THREADS / AM_WAVE], wmax[AM_CB_THREADS / AM_WAVE];
     __shared__ uint32_t red[AM_CB_THREADS / AM_WAVE];
+    __shared__ uint32_t tick;
     const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t base = blockIdx.x * AM_CB;
-    const uint32_t ent = (base < M) ? entry[blockIdx.x] : AM_CB_NONE;
+    const uint32_t blk = am_chain_place(ea.slots + gridDim.x + 2, ea.epoch, &tick);   // block of candidates = place in the chain
+    const uint32_t base = blk * AM_CB;
+    const uint32_t ent = (base < M) ? entry[blk] : AM_CB_NONE;
     const int lane = threadIdx.x & (AM_WAVE - 1), w = threadIdx.x / AM_WAVE;
     uint32_t embits = 0, tmax = 0;                            // bit k: node threadIdx.x + k * AM_CB_THREADS is a hit
     if (ent != AM_CB_NONE) {                                  // (uniform; otherwise the scan jumps over this block or nothing is here)
@@ -1231,7 +1262,7 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         for (int k = 0; k < AM_CB_THREADS / AM_WAVE; ++k) m = wmax[k] > m ? wmax[k] : m;
         if (m) atomicMax(&ea.scalars[0], m);
     }
-    const uint32_t before = am_chain_prefix(ea.slots, blockIdx.x, ea.epoch, tot, red);
+    const uint32_t before = am_chain_prefix(ea.slots, blk, ea.epoch, tot, red);
     uint32_t off = before;
     for (int k = 0; k < AM_CB_PER; ++k) {
         const bool em = ((embits >> k) & 1u) != 0u;
@@ -1241,7 +1272,7 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         if (em) ea.emit_idx[o + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + threadIdx.x + (uint32_t)k * AM_CB_THREADS;
         for (int q = 0; q < AM_CB_THREADS / AM_WAVE; ++q) off += wc[k][q];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *ea.n_out = before + tot;
+    if (blk == gridDim.x - 1 && threadIdx.x == 0) *ea.n_out = before + tot;
 }
 
 // compute units of the current device (cached per device: a process may hold contexts on several)

@@ -55,6 +55,15 @@ def emu_lib():
 
 
 @pytest.fixture(scope="session")
+def emu_lib_rare():
+    """Second emulated build (tests/emu/Makefile): 4-slot block heads and ticket-ordered chained scans, so that
+    the branches a normal capture hardly ever takes in the greedy chain run on every hop.  Test-only."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "libairmodes_emu_rare.so"])
+    from air_modes import _capi
+    return _capi.Library(os.path.join(ROOT, "tests", "emu", "libairmodes_emu_rare.so"))
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     """The real library on a real GPU.  Fails loudly (no fallback) when it is missing."""
     if not os.path.exists(HIP_LIB):

@@ -24,6 +24,7 @@ struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline void __threadfence_system() {}
+#define __builtin_readcyclecounter() 0ull
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
@@ -62,6 +63,8 @@ inline void __syncthreads() { hipemu::barrier(); }
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(p))
+// (fibers of one OS thread never interleave inside this)
+#define __hip_atomic_compare_exchange_strong(p, expected, desired, so, fo, scope) ((*(p) == *(expected)) ? (*(p) = (desired), true) : (*(expected) = *(p), false))
 // only used on values that are already the same in every lane of the wave
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #ifndef __clang__

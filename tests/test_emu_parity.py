@@ -118,6 +118,30 @@ def test_greedy_chain_many_blocks(emu_lib):
     assert pc.check_sharded(emu_lib, rate, iq, 3, want=want) == len(want)
 
 
+def test_greedy_chain_rare_branches(emu_lib_rare):
+    """The same dense capture through the build with 4-slot block heads and ticket-ordered chained scans: the block
+    walk then leaves the head table on almost every hop (links that land beyond a head, entry nodes beyond the
+    head: the global-memory hops and the plain hops between groups), and every chained scan draws its place from
+    the atomic ticket.  Single stream resumed at an odd cut, the 64 Msps streaming path, and time shards."""
+    from air_modes import _capi
+    rate = 8e6
+    iq, _ = synth.synth_capture(rate, 4000000, 20000.0, seed=606)
+    want = oracle.demod(iq, rate, 7.0, True)
+    ctx = _capi.Context(rate, 7.0, True, lib=emu_lib_rare)
+    got = [ctx.process_iq(iq[:2000001], flush=False)]
+    assert ctx.last_num_candidates() > 3 * 2048
+    got.append(ctx.process_iq(iq[2000001:], flush=True))
+    ctx.close()
+    assert np.array_equal(np.concatenate(got), want) and len(want) > 100
+    assert pc.check_sharded(emu_lib_rare, rate, iq, 3, want=want) == len(want)
+    iq64, _ = synth.synth_capture(64e6, 3000000, 20000.0, seed=607)
+    ctx = _capi.Context(64e6, 7.0, True, lib=emu_lib_rare)
+    pk = ctx.process_iq(iq64, flush=True)
+    assert ctx.last_num_candidates() > 2 * 2048
+    ctx.close()
+    assert np.array_equal(pk, oracle.demod(iq64, 64e6, 7.0, True)) and len(pk) > 20
+
+
 def test_speculative_capacity_overflow_is_redone(emu_lib, monkeypatch):
     """The streaming path launches a scan for a candidate capacity extrapolated from the previous
     scan.  Quiet stretch first, dense traffic next, no slack: the second scan overflows its capacity

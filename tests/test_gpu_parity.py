@@ -228,6 +228,33 @@ def test_chain_walk_beyond_64k_of_lds(lib):
     ctx.close()
 
 
+def test_greedy_chain_rare_branches_on_device():
+    """The test-only build with 4-slot block heads, groups of two blocks and ticket-ordered chained scans
+    (gr-air-modes_amd/csrc/Makefile, target `rare`): global-memory hops of the block walk, plain hops between groups, the
+    atomic ticket of am_chain_place -- on the device, against the oracle; one stream, the 64 Msps streaming path, shards."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_variants", "libairmodes_hip_rare.so")
+    if not os.path.exists(path):
+        pytest.fail("tests/gpu_variants/libairmodes_hip_rare.so is missing: python -c 'import __graft_entry__ as g; g.build()'")
+    rare = _capi.Library(path)
+    rate = 8e6
+    iq, _ = synth.synth_capture(rate, 12000000, 30000.0, seed=606)
+    want = oracle.demod(iq, rate, 5.0, True)
+    ctx = _capi.Context(rate, 5.0, True, lib=rare)
+    got = [ctx.process_iq(iq[:5000001], flush=False)]
+    assert ctx.last_num_candidates() > 8 * 2048, ctx.last_num_candidates()
+    got.append(ctx.process_iq(iq[5000001:], flush=True))
+    ctx.close()
+    assert np.array_equal(np.concatenate(got), want) and len(want) > 300
+    assert pc.check_sharded(rare, rate, iq, 3, thr=5.0, want=want) == len(want)
+    iq64, _ = synth.synth_capture(64e6, 16000000, 20000.0, seed=607)
+    ctx = _capi.Context(64e6, 7.0, True, lib=rare)
+    pk = ctx.process_iq(iq64, flush=True)
+    assert ctx.last_num_candidates() > 16 * 2048
+    ctx.close()
+    assert np.array_equal(pk, oracle.demod(iq64, 64e6, 7.0, True)) and len(pk) > 100
+
+
 def test_streaming_and_tile_front_ends_agree(lib, monkeypatch):
     """64 Msps: am_k_fe3 (default) and am_k_fe2 (AIRMODES_FE=2) give the oracle's packets -- also without the
     pulse-matched filter and with NaN / inf / denormal samples in INTERIOR tiles and steps (the EXEC-narrowing
