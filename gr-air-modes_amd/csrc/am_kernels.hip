@@ -305,6 +305,9 @@ __device__ __forceinline__ double am_energy_chip(const float *__restrict__ p, in
     return e;
 }
 
+// (Putting two pulses' loads in flight at once -- two memory round trips per energy instead of eight -- made
+// am_k_energy slower, 31 -> 37 us at the bench density: the kernel is bound by the 256 double-precision
+// convert + add instructions per position, and the extra registers cost occupancy.)
 __device__ __forceinline__ double am_preamble_energy(const float *__restrict__ p, int spc)
 {
     double e = 0.0;
@@ -330,6 +333,26 @@ __device__ __forceinline__ bool am_any_above(const float *__restrict__ z, int n,
     }
     for (; o < n; ++o) if (z[o] > thr) return true;
     return false;
+}
+
+// both quiet zones of a candidate (any sample above thr in z1[0..n1) or z2[0..n2)), 32 samples of each per memory
+// round trip while both last, then the rest: 6 round trips for the 97 + 161 samples at 32 samples per chip, not 18
+__device__ __forceinline__ bool am_any_above2(const float *__restrict__ z1, int n1, const float *__restrict__ z2, int n2,
+                                              float thr)
+{
+    int o = 0;
+    for (; o + 32 <= n1 && o + 32 <= n2; o += 32) {
+        am_f4u ta[8], tb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ta[k] = *reinterpret_cast<const am_f4u *>(z1 + o + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tb[k] = *reinterpret_cast<const am_f4u *>(z2 + o + 4 * k);
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) hit = hit || (ta[k >> 2].v[k & 3] > thr) || (tb[k >> 2].v[k & 3] > thr);
+        if (hit) return true;
+    }
+    return am_any_above(z1 + o, n1 - o, thr) || am_any_above(z2 + o, n2 - o, thr);
 }
 
 __global__ void __launch_bounds__(256)
@@ -759,8 +782,8 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     const float sthr = av + (avgpeak - av) / thr_lin;
     // (a wave-cooperative check of the survivors was tried: at the bench density too many candidates
     // survive the first samples of both zones, 86 us instead of 32)
-    const bool ok = live && !am_any_above(bb + e + 3 * spc, 3 * spc + 1, sthr) &&      // offsets 3spc .. 6spc
-                    !am_any_above(bb + e + 10 * spc, 5 * spc + 1, sthr);              // offsets 10spc .. 15spc
+    const bool ok = live && !am_any_above2(bb + e + 3 * spc, 3 * spc + 1,             // offsets 3spc .. 6spc
+                                           bb + e + 10 * spc, 5 * spc + 1, sthr);     // offsets 10spc .. 15spc
     if (!live) return;
     eo[g] = e;
     inavg[g] = av;
