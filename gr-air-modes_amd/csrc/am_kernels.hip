@@ -918,12 +918,24 @@ am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw
     __syncthreads();
     int cur = 0;
     for (int r = 0; r < AM_CB_LEVELS; ++r) {                 // successors strictly increase: <= 2^11 hops inside
+        // (the thread's eight nodes side by side: all first reads, then all dependent reads, then the stores -- written
+        // as one read-read-store per node the compiler keeps them in program order, LDS stores may alias LDS loads)
+        uint32_t t[AM_CB_PER], ne[AM_CB_PER], nl[AM_CB_PER];
+#pragma unroll
+        for (int k = 0; k < AM_CB_PER; ++k) t[k] = e[cur][threadIdx.x + k * AM_CB_THREADS];
+#pragma unroll
         for (int k = 0; k < AM_CB_PER; ++k) {
             const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-            const uint32_t t = e[cur][i];
-            const bool in = t < end;
-            e[cur ^ 1][i] = in ? e[cur][t - base] : t;
-            l[cur ^ 1][i] = in ? l[cur][t - base] : l[cur][i];
+            const bool in = t[k] < end;
+            const uint32_t j = in ? t[k] - base : i;
+            ne[k] = in ? e[cur][j] : t[k];
+            nl[k] = l[cur][j];                               // (not in: the node's own entry)
+        }
+#pragma unroll
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            e[cur ^ 1][i] = ne[k];
+            l[cur ^ 1][i] = nl[k];
         }
         cur ^= 1;
         __syncthreads();
@@ -1232,20 +1244,29 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
             V[i] = (base + i == ent) ? 1 : 0;
         }
         __syncthreads();
+        // (the thread's eight nodes side by side, as in am_k_cblk_exit: reads, dependent reads, stores)
         for (int l = 1; l < AM_CB_LEVELS; ++l) {
-            for (int k = 0; k < AM_CB_PER; ++k) {
-                const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-                const uint16_t t = J[l - 1][i];
-                J[l][i] = (t == OUT) ? OUT : J[l - 1][t];
-            }
+            uint16_t t[AM_CB_PER], u[AM_CB_PER];
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) t[k] = J[l - 1][threadIdx.x + k * AM_CB_THREADS];
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) u[k] = J[l - 1][(t[k] == OUT) ? 0 : t[k]];
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) J[l][threadIdx.x + k * AM_CB_THREADS] = (t[k] == OUT) ? OUT : u[k];
             __syncthreads();
         }
-        // top-down: every marked node marks the node 2^l hops ahead (marks only ever land on the orbit)
+        // top-down: every marked node marks the node 2^l hops ahead (marks only ever land on the orbit; a mark set
+        // during a level may or may not be seen by that level: either way it is a node of the orbit)
         for (int l = AM_CB_LEVELS - 1; l >= 0; --l) {
-            for (int k = 0; k < AM_CB_PER; ++k) {
-                const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-                if (V[i]) { const uint16_t t = J[l][i]; if (t != OUT) V[t] = 1; }
-            }
+            uint8_t v[AM_CB_PER];
+            uint16_t t[AM_CB_PER];
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) v[k] = V[threadIdx.x + k * AM_CB_THREADS];
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) t[k] = J[l][threadIdx.x + k * AM_CB_THREADS];
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k)
+                if (v[k] && t[k] != OUT) V[t[k]] = 1;
             __syncthreads();
         }
         // which visited nodes are hits, and where the scan resumes after everything visited here: the largest
