@@ -196,6 +196,19 @@ int ensure_slots(am_ctx *c, DevBuf &b, size_t n)
     return AM_OK;
 }
 
+// tag of the next chained-scan launch.  0 is what freshly zeroed slots hold, so it is never handed out; when the
+// 32-bit counter wraps, the slots are zeroed again (a slot beyond the recent grids could otherwise still carry the same
+// number from 2^32 launches ago)
+uint32_t next_epoch(am_ctx *c)
+{
+    if (++c->lb_epoch == 0) {
+        for (DevBuf *b : {&c->lb_seg, &c->lb_dc, &c->lb_mark})
+            if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, c->stream);
+        c->lb_epoch = 1;
+    }
+    return c->lb_epoch;
+}
+
 void release(DevBuf &b)
 {
     if (b.p) (void)hipFree(b.p);
@@ -340,7 +353,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->seg_base, ((size_t)nbs + 2) * sizeof(uint32_t));
         if (int rc = ensure_slots(c, c->lb_seg, nbs); rc != AM_OK) return rc;
         HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg,
-                                         (unsigned long long *)c->lb_seg.p, ++c->lb_epoch, (uint32_t *)c->seg_base.p + nbs,
+                                         (unsigned long long *)c->lb_seg.p, next_epoch(c), (uint32_t *)c->seg_base.p + nbs,
                                          c->stream));
         count_ptr = (const uint32_t *)c->seg_base.p + nbs;
     } else
@@ -384,7 +397,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             // compact index of each candidate's first energy: one chained scan of the counts (global offsets)
             if (int rc = ensure_slots(c, c->lb_dc, nb); rc != AM_OK) return rc;
             HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p, M,
-                                             (unsigned long long *)c->lb_dc.p, ++c->lb_epoch, (uint32_t *)c->blk_base2.p + nb,
+                                             (unsigned long long *)c->lb_dc.p, next_epoch(c), (uint32_t *)c->blk_base2.p + nb,
                                              c->stream, Mp));
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
                                        nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp));
@@ -579,7 +592,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
                                     (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
                                     own_hi, (uint32_t *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
-                                    ++c->lb_epoch, (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
+                                    next_epoch(c), (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
     if (keep_bursts) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
         if (c->pin_packets) (void)hipHostFree(c->pin_packets);

@@ -1336,11 +1336,20 @@ int am_device_cus(void)
 
 static inline unsigned am_grid(uint64_t n, unsigned block) { return (unsigned)((n + block - 1) / block); }
 
+#define AM_CB_WALK_LDS (152 * 1024)  /* dynamic LDS the walk kernels may use */
+// dynamic LDS of am_k_cblk_walk for nblk blocks with w-slot heads: links | entry index per block | group exits | group entries
+static size_t am_chain_walk_lds_bytes(uint64_t nblk, uint64_t w)
+{
+    const uint64_t ngrp = (nblk + AM_CB_GROUP - 1) / AM_CB_GROUP;
+    return (size_t)((nblk * w + 8 + nblk + ngrp * w + ngrp + 2) * sizeof(uint16_t));
+}
 static uint32_t am_chain_headw(uint32_t nblk)
 {
+    // the widest head (a power of two) whose table fits: slots are 16-bit with two values reserved, and the walk's
+    // other tables share the LDS;  0: every step of the walk reads global memory
     uint32_t w = AM_CB_HEADW;
-    while (w > 1 && (uint64_t)nblk * w > AM_CB_HEADCAP) w >>= 1;
-    return ((uint64_t)nblk * w > AM_CB_HEADCAP) ? 0u : w;       // 0: every step of the walk reads global memory
+    while (w >= 1 && ((uint64_t)nblk * w > AM_CB_HEADCAP || am_chain_walk_lds_bytes(nblk, w) > AM_CB_WALK_LDS)) w >>= 1;
+    return w;
 }
 
 struct am_chain_layout {
@@ -1368,7 +1377,7 @@ static hipError_t am_chain_walk_lds(const void *kernel, bool (&done)[64])
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
     hipError_t rc = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(152 * 1024));
+                                        (int)AM_CB_WALK_LDS);
     if (rc == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
     return rc;
 }
@@ -1398,8 +1407,8 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     static bool attr_set[64] = {};
     if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_walk), attr_set); rc != hipSuccess)
         return rc;
-    const size_t ngrp = ((size_t)L.nblk + AM_CB_GROUP - 1) / AM_CB_GROUP;
-    const size_t lds = ((size_t)L.nblk * L.headw + 8 + L.nblk + ngrp * L.headw + ngrp + 2) * sizeof(uint16_t);
+    const size_t lds = am_chain_walk_lds_bytes(L.nblk, L.headw);
+    if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;   // (more than ~75 000 blocks of 2048 candidates in one scan)
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp);
     am_emit_args ea;
