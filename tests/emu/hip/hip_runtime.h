@@ -52,11 +52,13 @@ namespace hipemu {
 void *dyn_smem();
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 void barrier();
+int barrier_or(int pred);
 unsigned long long ballot(int pred);
 uint64_t shuffle(uint64_t v, int src_lane_rel, int width, int mode);   // mode 0 idx, 1 down, 2 up, 3 xor
 } // namespace hipemu
 
 inline void __syncthreads() { hipemu::barrier(); }
+inline int __syncthreads_or(int pred) { return hipemu::barrier_or(pred); }
 // wave-level compiler fence in the product = a real rendezvous of the wave's fibers here
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)

@@ -80,15 +80,26 @@ WaveSlot &collective(uint64_t v)
 
 void *dyn_smem() { return g_smem.data(); }
 
+static int g_or_acc[2];      // __syncthreads_or: the OR of generation g collects in slot g & 1
+
 void barrier()
 {
     const int gen = g_bar_gen;
     if (++g_bar_arrived == g_nthreads) {
         g_bar_arrived = 0;
+        g_or_acc[(gen + 1) & 1] = 0;     // (the next generation's slot; everyone has read its previous use by now)
         g_bar_gen++;
         return;
     }
     while (g_bar_gen == gen) yield();
+}
+
+int barrier_or(int pred)
+{
+    const int gen = g_bar_gen, slot = gen & 1;
+    if (pred) g_or_acc[slot] = 1;
+    barrier();
+    return g_or_acc[slot];
 }
 
 unsigned long long ballot(int pred)
