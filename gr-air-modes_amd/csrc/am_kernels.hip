@@ -18,6 +18,13 @@
 
 #include "am_internal.h"
 
+// keeps a loaded value where it is in the program (the compiler otherwise sinks loads to their first use, behind branches)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AM_PIN_U32(x) asm volatile("" : "+v"(x))
+#else
+#define AM_PIN_U32(x) ((void)0)
+#endif
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -479,21 +486,23 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t seg = blockIdx.x * 4u + threadIdx.x / AM_WAVE;
     if (seg >= nseg) return;                                 // (wave-uniform; no workgroup barrier below)
-    const uint32_t cnt = seg_cnt[seg];
-    if (cnt == 0) return;
-    const uint32_t off = off_local[seg] + (blk_base ? blk_base[seg / AM_SCAN_BLK] : 0u);   // exclusive scan of seg_cnt (two-level, or global)
-    if (off >= M) return;
+    // every load the wave may need goes out at once (one memory round trip; written as count -> offset -> word ->
+    // the two words before, each behind the branch on the one before it, it was four -- which, measured, makes no
+    // difference to the kernel's 15 us: they go to its 10 400 workgroups of four single-segment waves)
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const uint32_t nw = 48u;                                 // words of a segment (one wave of the front end = one 48-chip block)
     const size_t w = (size_t)seg * 48u + (uint32_t)lane;
+    uint32_t cnt = seg_cnt[seg];
+    uint32_t off = off_local[seg] + (blk_base ? blk_base[seg / AM_SCAN_BLK] : 0u);   // exclusive scan of seg_cnt (two-level, or global)
     uint32_t word = 0, p1 = 0, p2 = 0;
     if ((uint32_t)lane < nw) {
         word = bits[w];
-        if (word) {
-            p1 = w >= 1 ? bits[w - 1] : 0u;
-            p2 = w >= 2 ? bits[w - 2] : 0u;
-        }
+        p1 = w >= 1 ? bits[w - 1] : 0u;
+        p2 = w >= 2 ? bits[w - 2] : 0u;
     }
+    AM_PIN_U32(cnt); AM_PIN_U32(off); AM_PIN_U32(word); AM_PIN_U32(p1); AM_PIN_U32(p2);
+    if (cnt == 0) return;
+    if (off >= M) return;
     const uint32_t c = (uint32_t)__popcll((unsigned long long)word);
     uint32_t incl = c;
     for (int d = 1; d < AM_WAVE; d <<= 1) {
@@ -664,7 +673,9 @@ __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_l
 // (256 + 10*spc samples, each sample up to 4*spc times): it is staged in LDS once and every lane
 // runs its own sequential double sum (pulse 0, 2, 7, 9; ascending within a pulse:
 // preamble_impl.cc:91-98) from there.
+#ifndef AM_ECB
 #define AM_ECB 64                   /* candidates per workgroup (about one 256-lane pass of positions) */
+#endif
 #define AM_ESTAGE 2048              /* floats of bb a pass may stage (8 KB) */
 
 __global__ void __launch_bounds__(256)
