@@ -1058,32 +1058,20 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
     const uint32_t lo = threadIdx.x * stride;
     const uint32_t hi = (lo + stride < M) ? lo + stride : M;
     uint32_t p_hi = 0, p_lo = 0;
-#if !(defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 1))
     if (stride && lo < M) { p_hi = pos[hi - 1u]; p_lo = lo ? pos[lo - 1u] : 0u; }
-#endif
     if (threadIdx.x == 0) { seg = M; root_s = M; scalars[0] = cur0; scalars[1] = 0u; }
-#if defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 1)
-    if (threadIdx.x == 0) root_s = 0;                         // (tuning builds: valid when the scan starts before the first candidate)
-#endif
-#if !(defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 2))
     am_cblk_load_links(lnk, headlink, total);
-#endif
     for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) ent[bb] = (uint16_t)AM_CB_END;
     for (uint32_t gg = threadIdx.x; gg < ngrp; gg += blockDim.x) gin[gg] = (uint16_t)AM_CB_END;
     __syncthreads();
     if (stride && lo < M && p_hi >= cur0 && (lo == 0 || p_lo < cur0)) seg = lo;
     __syncthreads();
-#if !(defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 1))
     for (uint32_t g = seg + threadIdx.x; g < M && g < seg + stride; g += blockDim.x)
         if (pos[g] >= cur0 && (g == 0 || pos[g - 1u] < cur0)) root_s = g;
-#endif
     const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
     AM_WALK_CLOCK(1);
     // (1) group exits: the slot reached from head slot h of group gi's first block once the orbit is past the group,
     // or the slot inside the group whose link is not a slot (END / OUT)
-#if defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 4)
-    if (false)
-#endif
     // (one walker at a time per thread: four side by side were tried, 50 % slower)
     for (uint32_t idx = threadIdx.x; idx < ngrp * headw; idx += blockDim.x) {
         const uint32_t gi = idx >> hs, h = idx & hm;
@@ -1100,11 +1088,7 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
     __syncthreads();
     AM_WALK_CLOCK(2);
     // (2) one lane, group to group
-#if defined(AM_WALK_ABLATE) && (AM_WALK_ABLATE & 12)
-    if (false) {
-#else
     if (threadIdx.x == 0) {
-#endif
         uint32_t g = root_s;                                 // node the orbit is at
         while (g < M) {
             const uint32_t kb = g / AM_CB, ki = g % AM_CB;

@@ -1,6 +1,14 @@
 # Tuning / profiling builds of the library (run here, before gpurun; build/var travels to the box).
 #   fe3prof : streaming front end with per-phase cycle stamps (-DFE3_PROFILE; prints on stderr, blocking)
 #   extra -D flags for an ad-hoc variant:  NAME=foo DEFS="-DFE3_X=1" bash tools/build_variants.sh
+# Compile-time knobs the sources understand (none of them exists in the default build):
+#   front end   -DFE3_PROFILE (phase clocks)  -DFE3_ABLATE=mask (results invalid)  -DFE3_NW -DFE3_WG_PER_CU -DFE3_LOAD_EARLY
+#               -DFE3_NT_LOADS -DFE3_NT_STORES -DFE3_FORCE_SPW=n (steps per workgroup)  -DFE2_PROFILING (tile kernel)
+#   extraction  -DAM_XPROF (phase clocks + per-workgroup lifetimes, printed when a context is destroyed)
+#   chain       -DAM_WALK_DEBUG (the block walk's lane 0 prints hop counts and cycles)  -DAM_CB_HEADW -DAM_CB_GROUP
+#               -DAM_CHAIN_TICKET_MIN (0: chained scans always draw tickets)
+#   refinement  -DAM_ECB (candidates per workgroup of the energy kernel)
+# Run every variant on the GPU box under `timeout`: a variant that computes garbage can loop for ever.
 set -e
 cd "$(dirname "$0")/../gr-air-modes_amd/csrc"
 mkdir -p ../../build/var
