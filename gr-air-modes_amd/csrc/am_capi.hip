@@ -129,6 +129,7 @@ struct am_ctx {
     uint64_t last_tags = 0;
     uint32_t last_M = 0;
     uint32_t chain_M = 0;               // records (or capacity) chain_prepare ran for
+    bool jump_ready = false;            // the refinement already wrote the chain's successor array (am_k_cand)
     const uint32_t *chain_Mp = nullptr; // device-side count when chain_M is a capacity
 
     // time-sharded mode: the chunk whose bb/avg are resident
@@ -344,6 +345,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
     *M_out = 0;
     c->spec_now = false;
     c->Mdev = nullptr;
+    c->jump_ready = false;
     if (nseg == 0) return AM_OK;
     const uint32_t *count_ptr = (const uint32_t *)c->blk_off.p + nseg;       // device-side total
     if (mode == 3) {
@@ -401,10 +403,12 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
                                              c->stream, Mp));
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
                                        nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp));
+            ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
             HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
                                      (uint32_t *)c->off_local.p, nullptr, (double *)c->energy.p, M,
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
-                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, c->stream, Mp));
+                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp));
+            c->jump_ready = true;
         } else
             HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
                                        (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p,
@@ -527,7 +531,7 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
     ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
     ENSURE(c, c->cscratch, am_chain_scratch_bytes(M));
     HIPCHK(c, am_launch_chain_prepare((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, (uint32_t *)c->jump.p,
-                                      (uint32_t *)c->cscratch.p, want_last ? 1 : 0, c->stream, Mp));
+                                      (uint32_t *)c->cscratch.p, want_last ? 1 : 0, c->stream, Mp, c->jump_ready ? 1 : 0));
     return AM_OK;
 }
 

@@ -72,7 +72,7 @@ hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, hipStream_t s, const uint32_t *Mp = nullptr);
+                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp = nullptr);
 /* exclusive scan of n counts in ONE launch (2048 per workgroup, chained through slots[]: am_chain_prefix);
  * slots: one 64-bit word per workgroup, zero at allocation; epoch: a value no earlier launch on these slots used */
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
@@ -124,7 +124,8 @@ hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float th
 /* greedy chain (am_kernels.hip): step 1 is independent of where the scan starts */
 size_t am_chain_scratch_bytes(uint32_t M);
 hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t *jump0,
-                                   uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp = nullptr);
+                                   uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp = nullptr,
+                                   int have_succ = 0);   /* have_succ: jump0[] was written by am_k_cand */
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,

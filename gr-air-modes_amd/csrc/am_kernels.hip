@@ -752,12 +752,27 @@ am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, cons
     }
 }
 
+__device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ pos, uint32_t lo,
+                                                   uint32_t hi, uint32_t key)
+{
+    // first index in [lo, hi) with pos[idx] >= key (hi if none); gallop then bisect
+    uint32_t stepw = 1, l = lo, h = lo;
+    while (h < hi && pos[h] < key) { l = h + 1; h = (h + stepw < hi) ? h + stepw : hi; stepw <<= 1; }
+    if (h > hi) h = hi;
+    while (l < h) {
+        const uint32_t mid = l + ((h - l) >> 1);
+        if (pos[mid] < key) l = mid + 1; else h = mid;
+    }
+    return l;
+}
+
 __global__ void __launch_bounds__(256)
 am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
           const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ off_local,
           const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t Mcap, int spc,
           float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
-          float *__restrict__ inavg, uint8_t *__restrict__ valid, const uint32_t *__restrict__ Mp)
+          float *__restrict__ inavg, uint8_t *__restrict__ valid, uint32_t *__restrict__ jump0,
+          const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -799,7 +814,14 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     eo[g] = e;
     inavg[g] = av;
     valid[g] = ok ? 1 : 0;
-    tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+    const uint32_t tg = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+    tgt[g] = tg;
+    if (jump0) {
+        // the greedy chain's successor (first candidate at or after the resume position; all positions are known by
+        // now), here instead of in a launch of its own (am_k_chain_succ: 7 us at the bench density)
+        jump0[g] = am_lower_bound(pos, g + 1u, M, tg);
+        if (g == M - 1u) jump0[M] = M;
+    }
 }
 
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
@@ -840,11 +862,11 @@ hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, hipStream_t s, const uint32_t *Mp)
+                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_cand, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg_sparse, pos, dcount, off_local,
-                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, Mp);
+                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp);
     return hipGetLastError();
 }
 
@@ -868,20 +890,6 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
 // depend on where the scan starts, so a time shard runs it before its entry position is known and
 // derives its exit table (am_k_cblk_exit_table) from the same arrays.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ pos, uint32_t lo,
-                                                   uint32_t hi, uint32_t key)
-{
-    // first index in [lo, hi) with pos[idx] >= key (hi if none); gallop then bisect
-    uint32_t stepw = 1, l = lo, h = lo;
-    while (h < hi && pos[h] < key) { l = h + 1; h = (h + stepw < hi) ? h + stepw : hi; stepw <<= 1; }
-    if (h > hi) h = hi;
-    while (l < h) {
-        const uint32_t mid = l + ((h - l) >> 1);
-        if (pos[mid] < key) l = mid + 1; else h = mid;
-    }
-    return l;
-}
-
 __global__ void __launch_bounds__(256)
 am_k_chain_succ(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ tgt, uint32_t Mcap,
                 uint32_t *__restrict__ jump0, const uint32_t *__restrict__ Mp)
@@ -1379,10 +1387,11 @@ static hipError_t am_chain_walk_lds(const void *kernel, bool (&done)[64])
 
 // step 1 (independent of where the scan starts): successor array + per-block exits
 hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t *jump0,
-                                   uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp)
+                                   uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp, int have_succ)
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
+    if (!have_succ)                                           // (am_k_cand already wrote the successors)
     hipLaunchKernelGGL(am_k_chain_succ, dim3(am_grid((uint64_t)M + 1, 256)), dim3(256), 0, s, pos, tgt, M, jump0, Mp);
     hipLaunchKernelGGL(am_k_cblk_exit, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, M, L.headw, scratch,
                        want_last ? scratch + L.off_last : nullptr, reinterpret_cast<uint16_t *>(scratch + L.off_head), Mp);
