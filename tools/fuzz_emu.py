@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign, CPU only: the product sources compiled against the fiber emulation (tests/emu,
+both builds: the plain one and the one with 4-slot block heads / ticket-ordered scans) against the oracle on random
+rates, burst densities, thresholds, filter settings, chunk cuts and shard counts.  Test infrastructure; prints one
+line per case and stops at the first disagreement.
+
+    python tools/fuzz_emu.py [--cases 40] [--seed 1]
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("gr-air-modes_amd", "tests", "oracle", "tools"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+
+import numpy as np  # noqa: E402
+
+import oracle  # noqa: E402
+import synth  # noqa: E402
+from air_modes import _capi  # noqa: E402
+
+
+def same(a, b):
+    """packet lists equal as bytes (a NaN reference level is equal to itself here)"""
+    return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
+
+
+def run_chunked(lib, rate, iq, edges, thr, pmf):
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    parts = [ctx.process_iq(iq[a:b], flush=(b == len(iq))) for a, b in zip(edges[:-1], edges[1:])]
+    ctx.close()
+    return np.concatenate(parts) if parts else np.zeros(0, _capi.PACKET_DTYPE)
+
+
+def run_sharded(lib, rate, iq, G, thr, pmf):
+    n = len(iq)
+    ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
+    hl, hr = ctxs[0].shard_halo()
+    bounds = [(g * n) // G for g in range(G + 1)]
+    tables = [ctxs[g].shard_scan(iq[max(0, bounds[g] - hl):min(n, bounds[g + 1] + hr)], bounds[g], bounds[g + 1], n)
+              for g in range(G)]
+    entry = _capi.shard_entries(lib, tables, bounds[:-1])
+    got = np.concatenate([ctxs[g].shard_resolve(int(entry[g])) for g in range(G)])
+    for c in ctxs:
+        c.close()
+    return got
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu])
+    subprocess.check_call(["make", "-s", "-C", emu, "libairmodes_emu_rare.so"])
+    libs = [_capi.Library(os.path.join(emu, "libairmodes_emu.so")), _capi.Library(os.path.join(emu, "libairmodes_emu_rare.so"))]
+    rng = np.random.default_rng(args.seed)
+    rates = (2e6, 4e6, 8e6, 10e6, 16e6, 20e6, 32e6, 64e6, 64e6, 64e6)
+    for case in range(args.cases):
+        rate = float(rng.choice(rates))
+        spc = int(rate / 2e6)
+        n = int(rng.integers(30000 * spc, 90000 * spc))
+        lam = float(rng.choice((300.0, 3000.0, 20000.0, 60000.0)))
+        thr = float(rng.choice((2.0, 5.0, 7.0, 10.0)))
+        pmf = bool(rng.integers(0, 4))
+        seed = int(rng.integers(1, 1 << 30))
+        iq, _ = synth.synth_capture(rate, n, lam, seed)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:                                        # some non-finite / tiny / huge samples
+            k = int(rng.integers(0, n - 600))
+            iq[k:k + 200] *= np.complex64(1e-22)
+            iq[k + 300] = np.complex64(complex(np.nan, 1.0))
+            iq[k + 400] = np.complex64(complex(np.inf, 0.0))
+            iq[k + 500:k + 520] *= np.complex64(1e18)
+        with np.errstate(all="ignore"):
+            want = oracle.demod(iq, rate, thr, pmf)
+        lib = libs[case % 2]
+        cuts = sorted(set(int(x) for x in rng.integers(1, n, int(rng.integers(0, 4)))))
+        edges = [0] + cuts + [n]
+        got = run_chunked(lib, rate, iq, edges, thr, pmf)
+        assert same(got, want), "case %d: chunked result differs (%d vs %d packets)" % (case, len(got), len(want))
+        G = int(rng.integers(2, 5))
+        halo = 244 * spc + 2
+        if n // G > halo:
+            got = run_sharded(lib, rate, iq, G, thr, pmf)
+            assert same(got, want), "case %d: sharded result differs (%d vs %d packets)" % (case, len(got), len(want))
+        print("case %3d ok: %5.0f Msps n=%8d lambda=%6.0f thr=%4.1f pmf=%d kind=%d cuts=%s shards=%d packets=%d (%s build)"
+              % (case, rate / 1e6, n, lam, thr, pmf, kind, cuts, G, len(want), "rare" if case % 2 else "plain"), flush=True)
+
+
+if __name__ == "__main__":
+    main()
