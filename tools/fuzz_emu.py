@@ -27,16 +27,16 @@ def same(a, b):
     return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
 
 
-def run_chunked(lib, rate, iq, edges, thr, pmf):
-    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+def run_chunked(lib, rate, iq, edges, thr, pmf, dc):
+    ctx = _capi.Context(rate, thr, pmf, use_dcblock=dc, lib=lib)
     parts = [ctx.process_iq(iq[a:b], flush=(b == len(iq))) for a, b in zip(edges[:-1], edges[1:])]
     ctx.close()
     return np.concatenate(parts) if parts else np.zeros(0, _capi.PACKET_DTYPE)
 
 
-def run_sharded(lib, rate, iq, G, thr, pmf):
+def run_sharded(lib, rate, iq, G, thr, pmf, dc):
     n = len(iq)
-    ctxs = [_capi.Context(rate, thr, pmf, lib=lib) for _ in range(G)]
+    ctxs = [_capi.Context(rate, thr, pmf, use_dcblock=dc, lib=lib) for _ in range(G)]
     hl, hr = ctxs[0].shard_halo()
     bounds = [(g * n) // G for g in range(G + 1)]
     tables = [ctxs[g].shard_scan(iq[max(0, bounds[g] - hl):min(n, bounds[g + 1] + hr)], bounds[g], bounds[g + 1], n)
@@ -66,6 +66,7 @@ def main():
         lam = float(rng.choice((300.0, 3000.0, 20000.0, 60000.0)))
         thr = float(rng.choice((2.0, 5.0, 7.0, 10.0)))
         pmf = bool(rng.integers(0, 4))
+        dc = bool(rng.integers(0, 5) == 0)                   # the optional DC blocker in front of the path
         seed = int(rng.integers(1, 1 << 30))
         iq, _ = synth.synth_capture(rate, n, lam, seed)
         kind = int(rng.integers(0, 4))
@@ -76,19 +77,19 @@ def main():
             iq[k + 400] = np.complex64(complex(np.inf, 0.0))
             iq[k + 500:k + 520] *= np.complex64(1e18)
         with np.errstate(all="ignore"):
-            want = oracle.demod(iq, rate, thr, pmf)
+            want = oracle.demod(iq, rate, thr, pmf, use_dcblock=dc)
         lib = libs[case % 2]
         cuts = sorted(set(int(x) for x in rng.integers(1, n, int(rng.integers(0, 4)))))
         edges = [0] + cuts + [n]
-        got = run_chunked(lib, rate, iq, edges, thr, pmf)
+        got = run_chunked(lib, rate, iq, edges, thr, pmf, dc)
         assert same(got, want), "case %d: chunked result differs (%d vs %d packets)" % (case, len(got), len(want))
         G = int(rng.integers(2, 5))
-        halo = 244 * spc + 2
+        halo = 244 * spc + 2 + (200 * spc if dc else 0)
         if n // G > halo:
-            got = run_sharded(lib, rate, iq, G, thr, pmf)
+            got = run_sharded(lib, rate, iq, G, thr, pmf, dc)
             assert same(got, want), "case %d: sharded result differs (%d vs %d packets)" % (case, len(got), len(want))
-        print("case %3d ok: %5.0f Msps n=%8d lambda=%6.0f thr=%4.1f pmf=%d kind=%d cuts=%s shards=%d packets=%d (%s build)"
-              % (case, rate / 1e6, n, lam, thr, pmf, kind, cuts, G, len(want), "rare" if case % 2 else "plain"), flush=True)
+        print("case %3d ok: %5.0f Msps n=%8d lambda=%6.0f thr=%4.1f pmf=%d dc=%d kind=%d cuts=%s shards=%d packets=%d (%s build)"
+              % (case, rate / 1e6, n, lam, thr, pmf, dc, kind, cuts, G, len(want), "rare" if case % 2 else "plain"), flush=True)
 
 
 if __name__ == "__main__":
