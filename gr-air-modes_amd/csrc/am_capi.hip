@@ -90,6 +90,8 @@ struct am_ctx {
         uint64_t out_abs0 = 0, P1 = 0;
         double T0 = 0.0;
     } pend;
+    bool keep_tags = false;       // AM_F_KEEP_TAGS of the call in progress: bursts + tags of its hits stay for am_fetch_tags
+    uint64_t rec_base = 0;        // absolute index of array coordinate 0 of the resident records (am_fetch_candidates)
     bool poison = false;          // AIRMODES_POISON=1 (tests): NaN-fill the sparse bb / reference-level arrays before every scan
     bool allow_fe3 = true;        // AIRMODES_FE=2 keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
@@ -116,7 +118,8 @@ struct am_ctx {
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
-        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y;
+        cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y, wgmax;
+    uint32_t fe3_vspan = 0, fe3_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
     DevBuf lb_seg, lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
 
@@ -381,33 +384,37 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
         ENSURE(c, c->valid, (size_t)M + 1);
         if (mode >= 2) {
-            // split refinement: positions -> energies once per reachable position -> per-candidate test
+            // split refinement: positions -> one verdict (streaming front end) or energy per reachable position -> per-candidate test
             const uint32_t nb = (M + 2047u) / 2048u;
             const uint64_t ebound = std::min<uint64_t>((uint64_t)M * (uint64_t)(c->spc + 1), (uint64_t)M + 0xFFFFFFFFull);
             ENSURE(c, c->dcount, ((size_t)M + 1) * sizeof(uint32_t));
             ENSURE(c, c->off_local, ((size_t)M + 1) * sizeof(uint32_t));
             ENSURE(c, c->blk_tot2, ((size_t)nb + 1) * sizeof(uint32_t));
             ENSURE(c, c->blk_base2, ((size_t)nb + 2) * sizeof(uint32_t));
-            ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
+            ENSURE(c, c->energy, (size_t)(ebound + 2) * (mode == 3 ? 1 : sizeof(double)));
             if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
                 HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p,
                                                 nullptr, nseg, M, c->spc, am_fe3_lag(),
                                                 (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             else
-                HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
-                                               c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
+            HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
+                                           c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             // compact index of each candidate's first energy: one chained scan of the counts (global offsets)
             if (int rc = ensure_slots(c, c->lb_dc, nb); rc != AM_OK) return rc;
             HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p, M,
                                              (unsigned long long *)c->lb_dc.p, next_epoch(c), (uint32_t *)c->blk_base2.p + nb,
                                              c->stream, Mp));
+            // behind the streaming front end the late-peak search's comparisons are decided from exact energy differences
+            // (one byte per position); behind the tile kernel the energies themselves are formed
+            uint8_t *late = mode == 3 ? (uint8_t *)c->energy.p : nullptr;
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
-                                       nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp));
+                                       nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp, late,
+                                       (const float *)c->wgmax.p, c->fe3_vspan, c->fe3_nv));
             ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
             HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
                                      (uint32_t *)c->off_local.p, nullptr, (double *)c->energy.p, M,
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
-                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp));
+                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp, late));
             c->jump_ready = true;
         } else
             HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
@@ -464,7 +471,8 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
         ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
-        unsigned nsteps = 0;
+        ENSURE(c, c->wgmax, ((size_t)ns + 8) * sizeof(float));
+        unsigned nsteps = 0, spw = 1;
         if (c->poison) {
             // test aid (AIRMODES_POISON=1): whatever the sparse arrays are read for must have been written by this scan
             HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
@@ -473,7 +481,9 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         HIPCHK(c, am_launch_fe3(src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
                                 (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
-                                (uint32_t *)c->blk_cnt.p, &nsteps, c->stream));
+                                (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream));
+        c->fe3_vspan = spw * am_fe3_tile();
+        c->fe3_nv = (nsteps + spw - 1) / spw;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         c->bb_sparse = true;
@@ -554,7 +564,7 @@ int chain_collect(am_ctx *c, uint32_t M, const uint32_t *Mp, uint32_t n_max, boo
             c->pending.push_back(c->pin_packets[i]);
             c->pending.back().reserved[0] = 0;
         }
-        return AM_OK;
+        if (!c->keep_tags) return AM_OK;
     }
     c->h_tags.assign(c->pin_tags, c->pin_tags + n_emit);
     if (n_emit) {
@@ -581,6 +591,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     c->h_bursts.clear();
     c->n_hits = 0;
     c->last_M = M;
+    c->rec_base = base_abs;
     *final_cur = cur0;
     if (M == 0) return AM_OK;
     const uint32_t nb = (uint32_t)(((uint64_t)M + AM_DET_PER_BLOCK - 1) / AM_DET_PER_BLOCK);
@@ -597,7 +608,8 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                     (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
                                     own_hi, (uint32_t *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
                                     next_epoch(c), (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
-    if (keep_bursts) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
+    const bool keep_dev = keep_bursts || c->keep_tags;       // the bursts and their tags leave the kernel
+    if (keep_dev) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
         if (c->pin_packets) (void)hipHostFree(c->pin_packets);
         if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -625,14 +637,15 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                              c->use_pmf, (float)(1.0 / (double)c->spc), (const float *)c->inavg.p, c->spc,
                                              (uint32_t *)c->emit_idx.p, n_ptr, n_max, (uint32_t *)c->pos.p,
                                              (uint32_t *)c->e.p, base_abs, c->rate_i, (const am_time_tag *)c->tt_dev.p,
-                                             (uint32_t)c->tt.size(), nullptr, nullptr, (uint32_t *)c->crc_pow.p,
+                                             (uint32_t)c->tt.size(), keep_dev ? (float *)c->bursts.p : nullptr,
+                                             keep_dev ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p,
                                              c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     else
     HIPCHK(c, am_launch_extract_slice(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                       (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
                                       (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(),
-                                      keep_bursts ? (float *)c->bursts.p : nullptr,
-                                      keep_bursts ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p, c->pin_packets,
+                                      keep_dev ? (float *)c->bursts.p : nullptr,
+                                      keep_dev ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p, c->pin_packets,
                                       (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     const uint32_t seq = ++c->ticket_seq;
     HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream));
@@ -792,7 +805,7 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->bits, &c->seg_tot, &c->seg_base, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->jump, &c->emit_idx,
                      &c->lb_seg, &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev};
+                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev, &c->wgmax};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -883,6 +896,9 @@ static int process_iq_core(am_ctx *c, const float *iq, uint64_t n, uint32_t flag
     c->last_tags = 0;
     const bool flush = (flags & AM_F_FLUSH) != 0;
     const bool dev_in = (flags & AM_F_DEVICE_IN) != 0;
+    c->keep_tags = (flags & AM_F_KEEP_TAGS) != 0;
+    c->h_tags.clear();
+    c->h_bursts.clear();
     const uint64_t S = (uint64_t)c->spc;
     const uint64_t L = (uint64_t)AM_CHIPS_AVG * S;
     const uint64_t LH = L + S;
@@ -1082,6 +1098,41 @@ int am_fetch_packets(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
 }
 
 uint64_t am_last_num_tags(const am_ctx *c) { return c ? c->last_tags : 0; }
+
+int am_fetch_tags(am_ctx *c, float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out)
+{
+    if (!c) return AM_EINVAL;
+    const uint64_t nt = c->h_tags.size();
+    if (n_out) *n_out = nt;
+    if (nt > cap) return fail(c, AM_ECAPACITY, "burst/tag arrays too small");
+    if (nt && bursts) memcpy(bursts, c->h_bursts.data(), nt * AM_BURST * sizeof(float));
+    if (nt && tags) memcpy(tags, c->h_tags.data(), nt * sizeof(am_tag));
+    return AM_OK;
+}
+
+int am_fetch_candidates(am_ctx *c, uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg, uint64_t cap,
+                        uint64_t *n_out)
+{
+    if (!c) return AM_EINVAL;
+    const uint64_t M = c->last_M;
+    if (n_out) *n_out = M;
+    if (M > cap) return fail(c, AM_ECAPACITY, "candidate arrays too small");
+    if (M == 0) return AM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> t(M);
+    if (pos) {
+        HIPCHK(c, hipMemcpy(t.data(), c->pos.p, M * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < M; i++) pos[i] = c->rec_base + t[i];
+    }
+    if (refined) {
+        HIPCHK(c, hipMemcpy(t.data(), c->e.p, M * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < M; i++) refined[i] = c->rec_base + t[i];
+    }
+    if (valid) HIPCHK(c, hipMemcpy(valid, c->valid.p, M, hipMemcpyDeviceToHost));
+    if (inavg) HIPCHK(c, hipMemcpy(inavg, c->inavg.p, M * sizeof(float), hipMemcpyDeviceToHost));
+    return AM_OK;
+}
 
 int am_frontend_work(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, float *bb, float *avg)
 {

@@ -2,23 +2,26 @@
 // (64 Msps), the rate BASELINE.json's metric is quoted on.  Same results as am_k_fe2 / the oracle
 // (canonical summation order), different machine mapping:
 //
-//   * PERSISTENT workgroups, three per CU (128 threads, ~50 KB of LDS each).  A workgroup owns a
-//     contiguous segment of the stream and walks it in steps of 96 chips (two 48-chip blocks,
-//     3072 samples).  What a step needs from the past -- the pulse-matched power bb of the last 57
-//     chips and their per-chip sums -- stays in LDS rings, so nothing is loaded twice (the tile
-//     kernel re-read a 49-chip halo per tile and could not shrink its tiles for that reason).
-//   * RAW IQ ARRIVES BY LDS-DMA (global_load_lds_dwordx4): the 24 KB of step k+1 are in flight while
-//     step k is processed; no VGPRs, no address arithmetic, no ds_write pass.  The DMA destination is
-//     lane-linear, so the 16-byte pieces are permuted on the SOURCE side: thread t then reads its own
-//     chip (16 pieces) from LDS without bank conflicts.
+//   * PERSISTENT workgroups, six per CU (128 threads = 2 waves, 26 KB of LDS, <= 168 VGPRs).  A workgroup owns a
+//     contiguous segment of the stream and walks it in steps of 96 chips (two 48-chip blocks, 3072 samples).  What a
+//     step needs from the past -- the pulse-matched power bb of the last 57 chips and their per-chip sums -- stays in
+//     LDS rings, so nothing is loaded twice (the tile kernel re-read a 49-chip halo per tile and could not shrink its
+//     tiles for that reason).
+//   * raw IQ arrives by plain coalesced 16-byte loads with the streaming (nt) policy, 12 per thread, issued back to
+//     back and waited for; |.|^2 goes straight into the ring slots of the step's chips.  No prefetch: while one
+//     workgroup waits for its loads the other five of the CU compute.  (LDS-DMA staging and register prefetch were
+//     built and measured in round 2 -- DESIGN.md 5.1: the staging buffer / the registers cost the occupancy this
+//     arithmetic needs; those variants are gone from the source.)
 //   * thread = one chip (32 samples in registers).  The chip before it belongs to lane-1: its in-chip
 //     suffix sums come over with DPP wave_shr:1 (no LDS traffic for the pulse-matched filter).
 //   * phase B (reference level + first-stage test) runs 9 chips BEHIND phase A, so the pulses 2, 7 and 9
 //     chips ahead are already in the ring: no right halo, no redundant arithmetic.
 //   * outputs are sparse: one candidate bit per position (a dense bitmap, 1/64 of the input bytes) and,
-//     only around candidates, the runs of bb (17 chips: what am_k_energy / am_k_cand read) and of the
-//     reference level (2 chips).  The dense 4 B/sample bb array of the tile kernel was a third of its HBM
+//     only around candidates, the runs of bb (17 chips: what am_k_cand_d reads) and of the reference level
+//     (2 chips).  The dense 4 B/sample bb array of the tile kernel was a third of its HBM
 //     traffic; burst extraction now recomputes its 240 chip-spaced samples from IQ (am_kernels.hip).
+//     Plus one number per workgroup: the largest bb of its segment (+inf if any is not finite), the bound the
+//     refinement's exact energy-difference test needs (am_k_cand_d).
 //
 // Reference: python/rx_path.py:38-54 (|.|^2, moving averages), lib/preamble_impl.cc:172-179 (test).
 #include "am_internal.h"
@@ -41,9 +44,6 @@
 #define FE3_WARM_J0 ((FE3_S - FE3_LAG - AM_CHIPS_AVG) / (FE3_NT / 16))
 #ifndef FE3_ABLATE
 #define FE3_ABLATE 0
-#endif
-#ifndef FE3_LOAD_EARLY
-#define FE3_LOAD_EARLY 2
 #endif
 #ifndef FE3_WPS
 #define FE3_WPS 3                         /* launch bound, waves per SIMD (<= 168 VGPRs)               */
@@ -73,6 +73,7 @@ struct am_fe3_args {
     uint32_t j0, j1;                      // positions whose preamble test is wanted
     uint32_t *bits;                       // [nsteps * 96] candidate words: bit b of word w = position w*32 + b - 288
     uint32_t *seg_cnt;                    // [nsteps * 2] candidates per (step, wave); wave w = words 48w .. 48w+47
+    float *wg_max;                        // [grid] largest bb a workgroup formed (+inf if one was not finite)
     unsigned nsteps;                      // steps (= bitmap tiles) of the whole launch
     unsigned steps_per_wg;
     // steps whose raw samples are all present and 16-byte aligned are loaded without guards: [raw_lo, raw_hi);
@@ -244,11 +245,11 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
 //   slot0    ring slot of this step's chip 0
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
 __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const int step, const bool test,
-                                         const int slot0, const int par, const bool edge, const bool load_next,
-                                         fe3_raw &nextraw, fe3_prof &PR)
+                                         const int slot0, const int par, const bool edge, const int tid, float &mxrun,
+                                         bool &badrun, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
-    const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
+    const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
     const bool chip_thread = lane < AM_CHIPS_AVG;
     const int t = wv * AM_CHIPS_AVG + (chip_thread ? lane : AM_CHIPS_AVG - 1);   // chip of the step (spare lanes shadow the last one, never write)
     const long long A0 = a.out_abs0 + (long long)step * FE3_T;      // absolute index of the step's first sample
@@ -325,8 +326,9 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         // chip totals in both directions (canonical level-1 sums); spare lanes contribute zeros to the scans
         float f = 0.0f, b = 0.0f;
 #pragma unroll
-        for (int i = 0; i < SPC; ++i) { f = f + bb[i]; b = b + bb[SPC - 1 - i]; }
+        for (int i = 0; i < SPC; ++i) { f = f + bb[i]; b = b + bb[SPC - 1 - i]; mxrun = fmaxf(mxrun, bb[i]); }
         if (!chip_thread) f = 0.0f;
+        badrun = badrun || !(f < __builtin_inff());                   // a sample that is not finite makes its chip's total so (all terms >= 0 or NaN)
         // exclusive prefix / suffix of the 48 chip totals of this wave's block, strictly sequential (canonical
         // order): x <- x(lane-1) + f repeated 47 times leaves lane j with ((f0 + f1) + ...) + fj (a lane's value is
         // final after j rounds and is recomputed identically afterwards); the same right->left from lane 47
@@ -356,10 +358,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     FE3_STAMP(1);
     fe3_barrier();                                                    // B3: ring, totals and scans of this step complete
     FE3_STAMP(2);
-    if (!test) {                                                      // (uniform) ring rebuild only
-        if (load_next && FE3_LOAD_EARLY != 2) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
-        return;
-    }
+    if (!test) return;                                                // (uniform) ring rebuild only
 
     // ---- phase B on chip q = (this thread's phase-A chip) - 9: reference level (a4) + first-stage test (a6) --------
     const int slotB = fe3_wrap_dn(slotA - FE3_LAG);
@@ -491,7 +490,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     if (lane == 0) a.seg_cnt[(size_t)step * FE3_NW + wv] = cnt;
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
     FE3_STAMP(3);
-    if (FE3_ABLATE & 1) { if (load_next && FE3_LOAD_EARLY != 2) fe3_load_step(a, A0 + FE3_T, tid, nextraw); return; }
+    if (FE3_ABLATE & 1) return;
     // ---- sparse outputs ---------------------------------------------------------------------------------------------
     // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
     // always).  The values exist only in registers: the flagged lanes park them in a small LDS buffer, four chips at
@@ -536,11 +535,6 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             __builtin_amdgcn_wave_barrier();
         }
     }
-#if FE3_LOAD_EARLY == 1
-    // raw IQ of the next step (the reference-level registers are free now): in flight under the bb copy and the wait at
-    // the step's last barrier
-    if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
-#endif
     // bb: the 17 chips from a candidate's chip on, copied from the ring (phase A is 9 chips ahead: chips up to test index
     // 104 are there) with fully coalesced stores: the flagged chips are ranked, and every wave-instruction moves eight of
     // them, 8 lanes x 16 bytes = one 128-byte line each.  (A lane storing its own chip's 128 bytes from registers issues
@@ -583,10 +577,6 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             }
         }
     }
-#if FE3_LOAD_EARLY == 0
-    // raw IQ of the next step: in flight during the wait at the step's last barrier
-    if (load_next) fe3_load_step(a, A0 + FE3_T, tid, nextraw);
-#endif
 }
 
 __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
@@ -603,15 +593,15 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     L.ST = L.PT + FE3_CR;
     L.CARRY = reinterpret_cast<uint32_t *>(L.ST + FE3_CR);
     L.TAB = L.CARRY + 2;
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const int sb = (int)(blockIdx.x * a.steps_per_wg);
     if (sb >= (int)a.nsteps) return;
     const int se = (sb + (int)a.steps_per_wg < (int)a.nsteps) ? sb + (int)a.steps_per_wg : (int)a.nsteps;
 
     // rings start empty; the first step's chip 0 has no predecessor (its bb is never used); the bb of the first 16
     // chips of a segment is always written (the candidates of the previous segment's tail are not known here)
-    for (int i = tid; i < FE3_CR * FE3_XS + 64 + 32 * (FE3_NW - 1) + FE3_NW * 4 * FE3_XS + 3 * FE3_CR; i += FE3_NT) L.X[i] = 0.0f;
-    if (tid < 2) L.CARRY[tid] = 0xFFFFu;
+    for (int i = tid0; i < FE3_CR * FE3_XS + 64 + 32 * (FE3_NW - 1) + FE3_NW * 4 * FE3_XS + 3 * FE3_CR; i += FE3_NT) L.X[i] = 0.0f;
+    if (tid0 < 2) L.CARRY[tid0] = 0xFFFFu;
     fe3_barrier();                                                    // (the first step stages into the ring right away)
 
     int slot0 = 0, par = 0;
@@ -620,41 +610,50 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     for (int k = 0; k < 12; ++k) PR.acc[k] = 0;
     PR.last = (long long)__builtin_readcyclecounter();
 #endif
-    fe3_raw raw;
-    bool have = (sb - 1) >= a.raw_lo && (sb - 1) < a.raw_hi;          // the step's raw samples are in `raw`
-#if FE3_LOAD_EARLY != 2
-    if (have) fe3_load_step(a, a.out_abs0 + (long long)(sb - 1) * FE3_T, tid, raw);
-#endif
+    float mxrun = 0.0f;                                               // largest bb this thread has formed
+    bool badrun = false;                                              // ... or one that is not finite
     for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
+        const bool have = step >= a.raw_lo && step < a.raw_hi;        // the step's raw samples are all present and 16-byte aligned
         const bool edge = !have || (test && !(step >= a.test_lo && step < a.test_hi));
-        const bool next_fast = step + 1 < se && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
+        int tid = tid0;                                               // (nothing that follows from the thread index is to live across iterations:
+#if defined(__HIP_DEVICE_COMPILE__)                                   //  hoisted out of the loop those values cost 15 VGPRs of 168)
+        asm volatile("" : "+v"(tid));
+#endif
         FE3_STAMP(4);
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
-#if FE3_LOAD_EARLY == 2
-        // no prefetch: load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is
-        // chip FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
+        // load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is chip
+        // FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
         if (have) {
             if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
             else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
-        }
-#else
-        if (have) fe3_store_step(L, slot0, tid, raw);
-#endif
-        else fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+        } else
+            fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
         FE3_STAMP(5);
         fe3_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
-        fe3_step(a, L, step, test, slot0, par, edge, next_fast, raw, PR);
-        have = next_fast;
+        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, PR);
         slot0 = fe3_wrap_up(slot0 + FE3_S);
         par ^= 1;
         FE3_STAMP(6);
         fe3_barrier();                                                // B5: every ring read of this step done
     }
+    // the largest sample of the segment (with the chips the ring rebuild went through): +inf if one was not finite
+    {
+        float wmx = mxrun;
+        for (int o = 32; o >= 1; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, AM_WAVE));
+        const bool bad = __ballot(badrun) != 0ull;
+        if ((tid0 & (AM_WAVE - 1)) == 0) L.SB0[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
+        fe3_barrier();
+        if (tid0 == 0) {
+            float v = L.SB0[0];
+            for (int w = 1; w < FE3_NW; ++w) v = fmaxf(v, L.SB0[w]);
+            a.wg_max[blockIdx.x] = v;
+        }
+    }
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    if (a.prof && (tid & (AM_WAVE - 1)) == 0)
-        for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * FE3_NW + tid / AM_WAVE) * 12 + k] = PR.acc[k];
+    if (a.prof && (tid0 & (AM_WAVE - 1)) == 0)
+        for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * FE3_NW + tid0 / AM_WAVE) * 12 + k] = PR.acc[k];
 #endif
 }
 
@@ -672,14 +671,16 @@ static int fe3_wgs_for_device() { return FE3_WG_PER_CU * am_device_cus(); }   //
 
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, unsigned *nsteps, hipStream_t s)
+                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps, unsigned *steps_per_wg,
+                         hipStream_t s)
 {
     am_fe3_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
-    a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.seg_cnt = seg_cnt;
+    a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.seg_cnt = seg_cnt; a.wg_max = wg_max;
     a.use_pmf = (use_pmf && FE3_SPC > 1) ? 1 : 0; a.s1 = s1; a.sL = sL; a.thr_lin = thr_lin;
     a.nsteps = am_fe3_steps(out_n);
     *nsteps = a.nsteps;
+    *steps_per_wg = 1;
     if (a.nsteps == 0) return hipSuccess;
     // steps served by DMA: samples [out_abs0 + k T, + T) inside [src_abs0, src_abs1), source 16-byte aligned (the
     // parity of the offset is the same for every step: T is even)
@@ -701,6 +702,7 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     spw = FE3_FORCE_SPW;                                              // tuning builds
 #endif
     a.steps_per_wg = spw;
+    *steps_per_wg = spw;
     const unsigned grid = (a.nsteps + spw - 1) / spw;
     static std::atomic<bool> attr_done[64];
     int dev = 0;

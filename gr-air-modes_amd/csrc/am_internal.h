@@ -43,9 +43,11 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
                          float sL, float thr_lin, uint32_t *seg_pos, float *avg_sparse, uint32_t *blk_cnt,
                          unsigned *ntiles, unsigned *tile_len, hipStream_t s);
-/* streaming fused front end (am_fe3.hip; 32 samples per chip): persistent workgroups, LDS-DMA staging, sparse
- * outputs.  Candidates leave as a bitmap: bit b of word w = array coordinate w*32 + b - am_fe3_lag(); seg_cnt holds
- * the number of candidates per (step, wave): wave w = words 48w .. 48w+47 of a step's 96. */
+/* streaming fused front end (am_fe3.hip; 32 samples per chip): persistent workgroups, LDS rings, sparse outputs.
+ * Candidates leave as a bitmap: bit b of word w = array coordinate w*32 + b - am_fe3_lag(); seg_cnt holds the number of
+ * candidates per (step, wave): wave w = words 48w .. 48w+47 of a step's 96.  wg_max[g] (nsteps + 8 floats are enough)
+ * = the largest bb workgroup g formed, +inf if one was not finite; workgroup g formed the bb of the array coordinates
+ * [g * steps_per_wg * tile, (g + 1) * steps_per_wg * tile) (and some before them). */
 int am_fe3_supported(int spc);
 unsigned am_fe3_tile(void);                 /* positions per step (3072) */
 unsigned am_fe3_lag(void);                  /* 288 */
@@ -53,7 +55,8 @@ unsigned am_fe3_waves(void);                /* segments (waves, 48 chips = 48 bi
 unsigned am_fe3_steps(long long out_n);
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, unsigned *nsteps, hipStream_t s);
+                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps,
+                         unsigned *steps_per_wg, hipStream_t s);
 /* flat candidate positions + dcount from the bitmap; off_local / blk_base = two-level exclusive scan of seg_cnt
  * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals; 2 segments per step) */
 hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
@@ -66,13 +69,18 @@ hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, co
                                 hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
                                    hipStream_t s, const uint32_t *Mp = nullptr);
+/* late != null (behind the streaming front end): one byte per compact index instead of one energy --
+ * late[k] = E(q+1) > E(q), decided from the exact difference of the two sums wherever that is safe (am_k_energy);
+ * vmax[array coordinate / vspan] (nv entries) bounds the samples */
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s, const uint32_t *Mp = nullptr);
+                            double *energy, hipStream_t s, const uint32_t *Mp = nullptr, uint8_t *late = nullptr,
+                            const float *vmax = nullptr, uint32_t vspan = 0, uint32_t nv = 0);
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp = nullptr);
+                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp = nullptr,
+                          const uint8_t *late = nullptr);
 /* exclusive scan of n counts in ONE launch (2048 per workgroup, chained through slots[]: am_chain_prefix);
  * slots: one 64-bit word per workgroup, zero at allocation; epoch: a value no earlier launch on these slots used */
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,

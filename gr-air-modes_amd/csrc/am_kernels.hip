@@ -678,10 +678,21 @@ __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_l
 #endif
 #define AM_ESTAGE 2048              /* floats of bb a pass may stage (8 KB) */
 
+// LATE MODE (late != null; behind the streaming front end, round 3): instead of E(q) the kernel writes one byte per
+// compact index, late[k] = (E(q+1) > E(q)), which is all the late-peak search asks (preamble_impl.cc:184-192) -- and
+// decides it from the EXACT difference of the two sums: they share all but eight samples,
+// D = sum over the four pulses of bb[q + c spc + spc] - bb[q + c spc].  Both reference sums have non-negative terms
+// not above V, so each carries a rounding error below (4 spc - 1) 2^-53 * 4 spc V <= 2^-39 V for spc <= 32; D is formed
+// here in double precision with an error below 2^-47 V.  Hence whenever |D| > 2^-36 V the sign of D IS the reference's
+// comparison; only closer calls (exact ties of quantised or constant input; non-finite samples: V = +inf) repeat the
+// reference's two sequential sums.  V comes from the front end: the largest bb of the workgroup segments the samples
+// lie in (vmax[array coordinate / vspan], am_fe3.hip).  Eight loads and a dozen operations per position instead of
+// 256 convert + add instructions: 31 -> 9 us at the bench density.
 __global__ void __launch_bounds__(256)
 am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,
             const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t Mcap, int spc,
-            double *__restrict__ energy, const uint32_t *__restrict__ Mp)
+            double *__restrict__ energy, const uint32_t *__restrict__ Mp, uint8_t *__restrict__ late,
+            const float *__restrict__ vmax, uint32_t vspan, uint32_t nv)
 {
     const uint32_t M = am_count(Mcap, Mp);
     __shared__ uint32_t coff[AM_ECB + 1];   // compact offset of each candidate of this group (+ end)
@@ -720,8 +731,31 @@ am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, cons
         }
         __syncthreads();
         const uint32_t w0 = qr[0] & ~3u;                     // 16-byte aligned start of the window
-        const uint32_t wn = qr[1] + 10u * (uint32_t)spc - w0;   // samples q .. q + 10*spc - 1 of every lane
-        if (wn <= AM_ESTAGE) {
+        const uint32_t wn = qr[1] + 10u * (uint32_t)spc + (late ? 1u : 0u) - w0;   // samples q .. q + 10*spc - 1 of every lane (late mode: one more)
+        if (late) {
+            // staged or not, the eight samples of D come from W or from memory; a close call goes to memory for both sums
+            const bool staged = wn <= AM_ESTAGE;               // (uniform)
+            if (staged) {
+                for (uint32_t i = 4u * threadIdx.x; i < wn; i += 4u * blockDim.x) {
+                    const float4 t = *reinterpret_cast<const float4 *>(bb + w0 + i);   // (arrays are padded)
+                    *reinterpret_cast<float4 *>(&W[i]) = t;
+                }
+                __syncthreads();
+            }
+            if (k < kend) {
+                const float *p = staged ? W + (q - w0) : bb + q;
+                const uint32_t v0 = q / vspan, v1 = (q + 11u * (uint32_t)spc + 1u) / vspan;
+                const float vb = fmaxf(vmax[v0 < nv ? v0 : nv - 1u], vmax[v1 < nv ? v1 : nv - 1u]);
+                const double bound = (double)vb * 0x1p-36;     // (+inf when a sample is not finite: nothing is decided by D)
+                double d = (double)p[spc] - (double)p[0];
+                d = d + ((double)p[3 * spc] - (double)p[2 * spc]);
+                d = d + ((double)p[8 * spc] - (double)p[7 * spc]);
+                d = d + ((double)p[10 * spc] - (double)p[9 * spc]);
+                bool lt = d > 0.0;
+                if (!(fabs(d) > bound)) lt = am_preamble_energy(bb + q + 1u, spc) > am_preamble_energy(bb + q, spc);
+                late[k] = lt ? 1 : 0;
+            }
+        } else if (wn <= AM_ESTAGE) {
             for (uint32_t i = 4u * threadIdx.x; i < wn; i += 4u * blockDim.x) {
                 const float4 t = *reinterpret_cast<const float4 *>(bb + w0 + i);   // (arrays are padded)
                 *reinterpret_cast<float4 *>(&W[i]) = t;
@@ -772,7 +806,7 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
           const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t Mcap, int spc,
           float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
           float *__restrict__ inavg, uint8_t *__restrict__ valid, uint32_t *__restrict__ jump0,
-          const uint32_t *__restrict__ Mp)
+          const uint32_t *__restrict__ Mp, const uint8_t *__restrict__ late)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -781,19 +815,36 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     if (M == 0) return;
     const uint32_t j = pos[gi];
     // late-peak search (preamble_impl.cc:184-192) over the precomputed energies
-    const double *E = energy + (am_off_at(off_local, blk_base, gi) + dcount[gi] - 1u - (uint32_t)spc);
+    const uint32_t e_first = am_off_at(off_local, blk_base, gi) + dcount[gi] - 1u - (uint32_t)spc;   // compact index of position j
     // (8 energies per round trip: a lane that slides all spc steps would otherwise hold its whole wave
     // for spc dependent loads)
     int how_late = 0;
     bool rising = true;
-    for (int k0 = 0; k0 < spc && rising; k0 += 8) {
-        double ev[9];
+    if (late) {
+        // late mode (am_k_energy): one byte per position says whether the search moves on from it
+        const uint8_t *Lb = late + e_first;
+        for (int k0 = 0; k0 < spc && rising; k0 += 8) {
+            uint8_t lv[8];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) ev[k] = E[(k0 + k <= spc) ? k0 + k : spc];
+            for (int k = 0; k < 8; ++k) lv[k] = Lb[(k0 + k < spc) ? k0 + k : spc - 1];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (rising && k0 + k < spc) {
-                if (ev[k + 1] > ev[k]) how_late++; else rising = false;
+            for (int k = 0; k < 8; ++k) {
+                if (rising && k0 + k < spc) {
+                    if (lv[k]) how_late++; else rising = false;
+                }
+            }
+        }
+    } else {
+        const double *E = energy + e_first;
+        for (int k0 = 0; k0 < spc && rising; k0 += 8) {
+            double ev[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ev[k] = E[(k0 + k <= spc) ? k0 + k : spc];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (rising && k0 + k < spc) {
+                    if (ev[k + 1] > ev[k]) how_late++; else rising = false;
+                }
             }
         }
     }
@@ -851,22 +902,24 @@ hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n,
 }
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s, const uint32_t *Mp)
+                            double *energy, hipStream_t s, const uint32_t *Mp, uint8_t *late, const float *vmax,
+                            uint32_t vspan, uint32_t nv)
 {
     if (M == 0) return hipSuccess;
+    if (late && (spc > 32 || !vmax || vspan == 0 || nv == 0)) return hipErrorInvalidValue;   // (the rounding bound is stated for 4 spc <= 128 terms)
     const unsigned grid = (unsigned)(((uint64_t)M + AM_ECB - 1) / AM_ECB);
     hipLaunchKernelGGL(am_k_energy, dim3(grid), dim3(256), 0, s, bb, pos, dcount, off_local, blk_base, M, spc,
-                       energy, Mp);
+                       energy, Mp, late, vmax, vspan, nv);
     return hipGetLastError();
 }
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp)
+                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp, const uint8_t *late)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_cand, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg_sparse, pos, dcount, off_local,
-                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp);
+                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp, late);
     return hipGetLastError();
 }
 

@@ -39,6 +39,9 @@ extern "C" {
 #define AM_F_FLUSH      0x2u  /* end of stream: examine the tail under the reference's
                                  end-of-buffer rule (preamble_impl.cc:150,212)              */
 #define AM_F_DEVICE_OUT 0x4u  /* am_frontend_work only: bb/avg are device pointers          */
+#define AM_F_KEEP_TAGS  0x8u  /* am_process_iq / am_submit_iq: also keep what the preamble block hands the slicer for
+                                 this call's hits -- 240-float bursts + "preamble_found" tags (lib/preamble_impl.cc:
+                                 219-232) -- for am_fetch_tags                                  */
 
 /* One accepted Mode-S reply: what slicer_impl.cc:186-194 serialises into its text message
  * (data, crc, reference_level, timestamp) plus the integer sample count behind the
@@ -168,6 +171,11 @@ int am_process_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t fla
 int am_fetch_packets(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
 /* preamble hits (tags) seen by the last am_process_iq call, accepted or not */
 uint64_t am_last_num_tags(const am_ctx *ctx);
+/* The inter-block stream of the last am_process_iq / am_collect call that ran with AM_F_KEEP_TAGS: one 240-float burst
+ * and one tag per preamble hit, in stream order, exactly what gr::air_modes::preamble would have produced for the
+ * slicer (lib/preamble_impl.cc:219-232), from the SAME kernels that produced the call's packets.  bursts: cap*240
+ * floats; tags: cap entries; either may be NULL to skip it.  AM_ECAPACITY (*n_out = needed) if cap is too small. */
+int am_fetch_tags(am_ctx *ctx, float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out);
 
 /* ---- block-level entry points (for block-by-block parity tests) -------------------------
  * am_frontend_work: the three third-party blocks in front of the preamble detector
@@ -249,10 +257,18 @@ int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
  * the last scan refined and chained.  Negative error code on a null context. */
 long long am_last_num_candidates(const am_ctx *ctx);
 
-/* Diagnostic: which front-end kernel the last scan ran -- 3 = streaming kernel (am_k_fe3: LDS-DMA staging,
- * sparse bb), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan yet.  Results do
- * not depend on it (the environment variable AIRMODES_FE=2 keeps the tile kernel; tests compare both). */
+/* Diagnostic: which front-end kernel the last scan ran -- 3 = streaming kernel (am_k_fe3: persistent workgroups, LDS
+ * rings, sparse bb around candidates), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan
+ * yet.  Results do not depend on it (test builds can keep the tile kernel; tests compare both). */
 int am_last_frontend(const am_ctx *ctx);
+
+/* Diagnostic (stage-level parity tests): the refined record of EVERY first-stage candidate of the last scan, in
+ * position order -- absolute stream index of the position the first-stage test fired at (preamble_impl.cc:172-179), of
+ * the position after the late-peak search (:182-192), the outcome of the quiet-zone test there (:198-209) and, for a
+ * candidate, the reference level at that position (what :220 subtracts).  Any pointer may be NULL.  AM_ECAPACITY
+ * (*n_out = needed) if cap is too small. */
+int am_fetch_candidates(am_ctx *ctx, uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg, uint64_t cap,
+                        uint64_t *n_out);
 
 #ifdef __cplusplus
 }
