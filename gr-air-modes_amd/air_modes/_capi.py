@@ -15,6 +15,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libairmodes_hip.so")
 AM_F_DEVICE_IN = 0x1
 AM_F_FLUSH = 0x2
 AM_F_DEVICE_OUT = 0x4
+AM_F_KEEP_TAGS = 0x8
 
 AM_OK, AM_EINVAL, AM_ENODEV, AM_ENOMEM, AM_EHIP, AM_ECAPACITY, AM_ENOTSUP = 0, -1, -2, -3, -4, -5, -6
 
@@ -116,6 +117,8 @@ class Library(object):
         L.am_pipe_last_error.argtypes = [vp]
         L.am_pipe_last_kernel_ms.restype = C.c_float
         L.am_pipe_last_kernel_ms.argtypes = [vp]
+        L.am_fetch_tags.argtypes = [vp, vp, vp, u64, pu64]
+        L.am_fetch_candidates.argtypes = [vp, vp, vp, vp, vp, u64, pu64]
         L.am_last_frontend.restype = C.c_int
         L.am_last_frontend.argtypes = [vp]
         self.L = L
@@ -236,15 +239,49 @@ class Context(object):
         self._chk(self.lib.L.am_fetch_packets(self._h, out.ctypes.data, need, C.byref(n)))
         return out[:n.value]
 
-    def process_iq(self, iq, flush=False, capacity=None):
-        """Host IQ (complex64 or interleaved float32) -> accepted packets of this chunk."""
+    def process_iq(self, iq, flush=False, capacity=None, keep_tags=False):
+        """Host IQ (complex64 or interleaved float32) -> accepted packets of this chunk.  keep_tags: the bursts and
+        tags of the chunk's preamble hits stay available for fetch_tags()."""
         f = _iq_f32(iq)
         n = f.size // 2
-        return self._process(f.ctypes.data if n else None, n, AM_F_FLUSH if flush else 0, capacity)
+        return self._process(f.ctypes.data if n else None, n,
+                             (AM_F_FLUSH if flush else 0) | (AM_F_KEEP_TAGS if keep_tags else 0), capacity)
 
-    def process_iq_device(self, dev_ptr, n_complex, flush=False, capacity=None):
+    def process_iq_device(self, dev_ptr, n_complex, flush=False, capacity=None, keep_tags=False):
         """Device-resident interleaved float32 IQ (e.g. torch tensor .data_ptr())."""
-        return self._process(int(dev_ptr), int(n_complex), AM_F_DEVICE_IN | (AM_F_FLUSH if flush else 0), capacity)
+        return self._process(int(dev_ptr), int(n_complex), AM_F_DEVICE_IN | (AM_F_FLUSH if flush else 0) |
+                             (AM_F_KEEP_TAGS if keep_tags else 0), capacity)
+
+    def fetch_tags(self):
+        """(bursts [n, 240] float32, tags) of the last process_iq(..., keep_tags=True) call: what the preamble block
+        hands the slicer (lib/preamble_impl.cc:219-232), from the kernels that produced the call's packets."""
+        n = C.c_uint64(0)
+        rc = self.lib.L.am_fetch_tags(self._h, None, None, 0, C.byref(n))
+        if rc != AM_ECAPACITY:
+            self._chk(rc)
+        m = int(n.value)
+        bursts = np.zeros((m, 240), np.float32)
+        tags = np.zeros(m, TAG_DTYPE)
+        if m:
+            self._chk(self.lib.L.am_fetch_tags(self._h, bursts.ctypes.data, tags.ctypes.data, m, C.byref(n)))
+        return bursts, tags
+
+    def fetch_candidates(self):
+        """(pos, refined, valid, inavg) of EVERY first-stage candidate of the last scan, absolute stream indices
+        (diagnostic, stage-level parity tests)."""
+        n = C.c_uint64(0)
+        rc = self.lib.L.am_fetch_candidates(self._h, None, None, None, None, 0, C.byref(n))
+        if rc != AM_ECAPACITY:
+            self._chk(rc)
+        m = int(n.value)
+        pos = np.zeros(m, np.uint64)
+        ref = np.zeros(m, np.uint64)
+        val = np.zeros(m, np.uint8)
+        iav = np.zeros(m, np.float32)
+        if m:
+            self._chk(self.lib.L.am_fetch_candidates(self._h, pos.ctypes.data, ref.ctypes.data, val.ctypes.data,
+                                                     iav.ctypes.data, m, C.byref(n)))
+        return pos, ref, val, iav
 
     def _process(self, ptr, n, flags, capacity):
         cap = int(capacity) if capacity is not None else max(64, n // 2000 + 64)

@@ -345,6 +345,68 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
     return hits;
 }
 
+/* Every position that passes the first-stage test (preamble_impl.cc:172-179), refined on its own: what the
+ * late-peak search (:182-192) and the quiet-zone test (:198-209) make of it if the scan gets there -- independent
+ * of the greedy order in which the reference visits candidates (stage-level parity of the GPU's candidate
+ * records; the records of the candidates amo_preamble_scan does visit must agree with its tags).
+ * Coordinates are item counts k of the preamble block (stream index + history, like amo_tag.sample); only
+ * positions k < k_limit are reported.  Returns the number found (may exceed cap: then only cap are stored). */
+uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, float thr_db, uint64_t k_limit,
+                        uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg_out, uint64_t cap)
+{
+    if (spc < 1 || n == 0) return 0;
+    const uint64_t S = (uint64_t)spc;
+    const uint64_t hist = 2 * S - 1;
+    const uint64_t K = n + hist;
+    const uint64_t pad = 260 * S;
+    float *in = (float *)calloc(K + pad, sizeof(float));
+    float *inavg = (float *)calloc(K + pad, sizeof(float));
+    if (!in || !inavg) { free(in); free(inavg); return 0; }
+    memcpy(in + hist, bb, n * sizeof(float));
+    memcpy(inavg + hist, avg, n * sizeof(float));
+    const float T = amo_threshold_lin(thr_db);
+    uint64_t ninputs = (K - K % S > S) ? K - K % S - S : 0;
+    if (ninputs > k_limit) ninputs = k_limit;
+    const uint64_t o1 = 2 * S, o2 = 7 * S, o3 = 9 * S;
+    uint64_t found = 0;
+    for (uint64_t k0 = 0; k0 < ninputs; k0++) {
+        float thr = inavg[k0] * T;
+        if (!(in[k0] > thr)) continue;
+        if (in[k0 + 1] > in[k0]) continue;
+        if (in[k0 + o1] < thr) continue;
+        if (in[k0 + o2] < thr) continue;
+        if (in[k0 + o3] < thr) continue;
+        uint64_t k = k0;
+        uint32_t how_late = 0;
+        for (;;) {
+            double now = preamble_energy(in + k, spc);
+            double nxt = preamble_energy(in + k + 1, spc);
+            int late = nxt > now;
+            if (late) { k++; how_late++; }
+            if (!(late && how_late < (uint32_t)spc)) break;
+        }
+        float peaksum = in[k] + in[k + o1];
+        peaksum = peaksum + in[k + o2];
+        peaksum = peaksum + in[k + o3];
+        float avgpeak = (float)((double)peaksum / 4.0);
+        float space_thr = inavg[k] + (avgpeak - inavg[k]) / T;
+        int ok = 1;
+        for (uint64_t j = 3 * S; j <= 6 * S; j++)
+            if (in[k + j] > space_thr) ok = 0;
+        for (uint64_t j = 10 * S; j <= 15 * S; j++)
+            if (in[k + j] > space_thr) ok = 0;
+        if (found < cap) {
+            pos[found] = k0;
+            refined[found] = k;
+            valid[found] = (uint8_t)ok;
+            inavg_out[found] = inavg[k];
+        }
+        found++;
+    }
+    free(in); free(inavg);
+    return found;
+}
+
 /* ---------------------------------------------------------------- a12 ---- */
 /* CRC-24, generator 0xFFF409 (x^24 + ... ), zero initial value, MSB first.
  * Stated bit-serially: the register holds msg(x)*x^24 mod G(x). */

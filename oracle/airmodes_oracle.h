@@ -81,6 +81,11 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
                            int spc, float thr_db, uint64_t rate,
                            float *bursts, amo_tag *tags, uint64_t cap);
 
+/* every first-stage candidate (preamble_impl.cc:172-179) refined on its own (:182-209), independent of the scan
+ * order; coordinates are item counts incl. the block's history (like amo_tag.sample), positions k < k_limit */
+uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, float thr_db, uint64_t k_limit,
+                        uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg_out, uint64_t cap);
+
 /* a10-a12: slice one 240-chip burst.  Returns 1 if the packet is accepted
  * (the reference would post a message), 0 if it is dropped. */
 int amo_slice(const float *burst, const amo_tag *tag, amo_packet *out);

@@ -53,6 +53,9 @@ def lib():
         L.amo_preamble_scan.restype = C.c_uint64
         L.amo_preamble_scan.argtypes = [_f32p, _f32p, C.c_uint64, C.c_int, C.c_float, C.c_uint64,
                                         _f32p, C.c_void_p, C.c_uint64]
+        L.amo_candidates.restype = C.c_uint64
+        L.amo_candidates.argtypes = [_f32p, _f32p, C.c_uint64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_uint64]
         L.amo_slice.argtypes = [_f32p, C.c_void_p, C.c_void_p]
         L.amo_crc24.restype = C.c_uint32
         L.amo_crc24.argtypes = [_u8p, C.c_int]
@@ -161,6 +164,26 @@ def preamble_scan(bb, avg, spc, thr_db, rate, rx_time=None):
                                    n, spc, thr_db, int(rate), bursts.reshape(-1), tags.ctypes.data, cap)
     assert hits <= cap
     return bursts[:hits], restamp(tags[:hits], rate, rx_time)
+
+
+def candidates(bb, avg, spc, thr_db, k_limit=None):
+    """Every first-stage candidate refined on its own: (pos, refined, valid, inavg) in item counts of the preamble
+    block (stream index + 2*spc - 1), positions below k_limit."""
+    n = bb.size
+    bb = np.ascontiguousarray(bb, np.float32)
+    avg = np.ascontiguousarray(avg, np.float32)
+    lim = (1 << 62) if k_limit is None else int(k_limit)
+    cap = 1 << 16
+    while True:
+        pos = np.zeros(cap, np.uint64)
+        ref_ = np.zeros(cap, np.uint64)
+        val = np.zeros(cap, np.uint8)
+        iav = np.zeros(cap, np.float32)
+        m = lib().amo_candidates(bb, avg, n, spc, thr_db, lim, pos.ctypes.data, ref_.ctypes.data, val.ctypes.data,
+                                 iav.ctypes.data, cap)
+        if m <= cap:
+            return pos[:m], ref_[:m], val[:m], iav[:m]
+        cap = int(m)
 
 
 def slice_bursts(bursts, tags):

@@ -53,6 +53,60 @@ def check_golden(lib, path):
     ctx.close()
 
 
+def check_production_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True, want_fe=None, iq=None, with_ref=False, chunks=None):
+    """Stage-level parity of the kernels am_process_iq really runs: the record of EVERY
+    first-stage candidate (position = the first-stage bitmap, refined position, quiet-zone outcome, reference level) against
+    the oracle's refinement of every position that passes the first-stage test; the bursts + tags the scan hands its slicer
+    (AM_F_KEEP_TAGS) against the oracle's preamble scan and, where oracle/_ref exists, the reference's own C++."""
+    spc = int(rate / 2e6)
+    if iq is None:
+        iq, _ = synth.synth_capture(rate, n, lam, seed)
+    n = len(iq)
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    if chunks:
+        got_b, got_t, pk = [], [], []
+        cuts = [0] + list(chunks) + [n]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            pk.append(ctx.process_iq(iq[a:b], flush=(b == n), keep_tags=True))
+            bb_, tt_ = ctx.fetch_tags()
+            got_b.append(bb_); got_t.append(tt_)
+        bursts, tags, whole = np.concatenate(got_b), np.concatenate(got_t), np.concatenate(pk)
+    else:
+        whole = ctx.process_iq(iq, flush=True, keep_tags=True)
+        bursts, tags = ctx.fetch_tags()
+    if want_fe is not None:
+        assert ctx.last_frontend() == want_fe, "front end %d ran, expected %d" % (ctx.last_frontend(), want_fe)
+    obb, oavg = oracle.frontend(iq, spc, pmf)
+    ob, ot = oracle.preamble_scan(obb, oavg, spc, thr, rate)
+    assert len(tags) == len(ot), "tag count differs: %d vs %d" % (len(tags), len(ot))
+    assert np.array_equal(tags, ot), "tags differ"
+    assert np.array_equal(u32(bursts), u32(ob)), "bursts differ"
+    want, ntags = oracle.demod(iq, rate, thr, pmf, return_tags=True)
+    assert ntags == len(tags)
+    assert np.array_equal(whole, want), "packets differ"
+    if with_ref and oracle.have_ref():
+        rb, rt, _, keep = oracle.ref_preamble_slicer(obb, oavg, spc, thr, rate)
+        rb, rt = rb[keep], rt[keep]
+        assert np.array_equal(tags["sample"], rt["sample"]) and np.array_equal(tags["secs"], rt["secs"])
+        assert np.array_equal(tags["frac"], rt["frac"]) and np.array_equal(u32(bursts), u32(rb)), "differs from the reference's C++"
+    if not chunks:
+        # every first-stage candidate of the (single) scan.  The GPU tests positions up to the last one a burst can
+        # start at (end-of-stream rule, preamble_impl.cc:150,212): item counts k <= ninputs - 240 spc
+        hist = 2 * spc - 1
+        K = n + hist
+        ninputs = K - K % spc - spc
+        pos, ref_, val, iav = ctx.fetch_candidates()
+        opos, oref, oval, oiav = oracle.candidates(obb, oavg, spc, thr, k_limit=ninputs - 240 * spc + 1)
+        assert len(pos) == len(opos), "candidate count differs: %d vs %d" % (len(pos), len(opos))
+        assert np.array_equal(pos + np.uint64(hist), opos), "first-stage positions differ"
+        assert np.array_equal(ref_ + np.uint64(hist), oref), "refined positions differ"
+        assert np.array_equal(val, oval), "quiet-zone outcomes differ"
+        ok = oval == 1
+        assert np.array_equal(u32(iav[ok]), u32(oiav[ok])), "reference levels at valid candidates differ"
+    ctx.close()
+    return len(tags)
+
+
 def check_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True, dcblock=False, dc_offset=0.0):
     """Stage-by-stage and end-to-end, product path vs oracle, on a seeded capture."""
     spc = int(rate / 2e6)

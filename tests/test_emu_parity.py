@@ -293,3 +293,13 @@ def test_batches_in_flight_single_host_thread(emu_lib):
     assert np.array_equal(out, want[0])
     assert np.array_equal(ctx.process_iq(batches[1], flush=True), want[1])     # the context is usable as before
     ctx.close()
+
+
+@pytest.mark.parametrize("rate,n,lam,pmf,chunks", [(64e6, 900000, 20000.0, True, None), (64e6, 700000, 20000.0, False, None),
+                                                    (64e6, 900000, 20000.0, True, [250001, 600000]),
+                                                    (20e6, 500000, 5000.0, True, None), (2e6, 200000, 2000.0, True, None)])
+def test_production_stages(emu_lib, rate, n, lam, pmf, chunks):
+    """Candidate records, bursts and tags of the kernels am_process_iq runs (streaming front end at 64 Msps, tile kernel
+    elsewhere) against the oracle and, where built, the reference's own C++."""
+    assert pc.check_production_stages(emu_lib, rate, n, lam, 77, pmf=pmf, with_ref=True, chunks=chunks,
+                                      want_fe=3 if rate == 64e6 else 2) > 0

@@ -293,3 +293,17 @@ def test_batches_in_flight_single_host_thread(lib):
         got.append(pipe.collect())
     assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
     pipe.close()
+
+
+@pytest.mark.parametrize("rate,n,lam,fe", [(64e6, 64_000_000, 20000.0, 3), (64e6, 16_000_000, 2000.0, 3),
+                                            (20e6, 20_000_000, 5000.0, 2), (2e6, 20_000_000, 500.0, 2)])
+def test_production_stages_full_size(lib, rate, n, lam, fe):
+    """stage-level parity of the kernels that actually run -- at the BASELINE sizes the
+    record of every first-stage candidate (bitmap position, refined position, quiet-zone outcome, reference level), the
+    bursts and tags handed to the slicer, the tag count and the packets, against the oracle and the reference's own C++."""
+    assert pc.check_production_stages(lib, rate, n, lam, 6400, with_ref=True, want_fe=fe) > 0
+
+
+def test_production_stages_chunked_and_no_pmf(lib):
+    assert pc.check_production_stages(lib, 64e6, 9_000_000, 20000.0, 11, chunks=[2_000_001, 5_500_000], want_fe=3) > 0
+    assert pc.check_production_stages(lib, 64e6, 6_000_000, 20000.0, 12, pmf=False, want_fe=3) > 0
