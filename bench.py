@@ -12,7 +12,7 @@ N = 1  workload "64msps" (BASELINE.json configs[2]: synthetic 64 Msps IQ, Poisso
        rate (20 000 /s, 87 % airtime) is a stress density; `realistic_density` repeats the measurement at
        2 000 bursts/s in the same run.
 N > 1  configs[3]: one 64 Msps stream time-sharded over the N GPUs, one process per GPU (torch.distributed
-       over RCCL): neighbours' boundary samples travel in one all-gather of fixed-size halo slabs, every rank
+       over RCCL): neighbours' boundary samples travel as point-to-point sends / receives (KB scale), every rank
        scans its chunk, the scan's exit tables are all-gathered, every rank slices its own hits.  Per-GPU
        work is fixed as N grows ("weak").  `python bench.py --gpus N` launches the N ranks itself when it is
        not already running under torch.distributed.run.  `parity` for N > 1: a short stream through the same
@@ -334,9 +334,19 @@ def main():
         if mode == "single" and os.path.exists(tj) and not args.emu:
             with open(tj) as f:
                 t = json.load(f)
+            # the counters belong to ONE version of the kernel: the file carries the hash of the kernel's source it was
+            # measured on, and a kernel that changed since reports no traffic rather than somebody else's
+            import hashlib
+            with open(os.path.join(ROOT, "gr-air-modes_amd", "csrc", t.get("kernel_source", "am_fe3.hip")), "rb") as kf:
+                sha = hashlib.sha256(kf.read()).hexdigest()[:16]
             if t.get("workload") == workload and args.seconds is None and args.lam is None and t.get("kernel", "") in kernel_name:
-                traffic = t["traffic_bytes"]
-                traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                if t.get("kernel_source_sha16") == sha:
+                    traffic = t["traffic_bytes"]
+                    traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; %s sha %s)" % (
+                        t.get("kernel_source", "am_fe3.hip"), sha)
+                else:
+                    traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
+                        t.get("kernel_source", "am_fe3.hip"), t.get("kernel_source_sha16"), sha)
         par = {"single": "single GPU", "replicas": "%d independent receivers, one per GPU, no collective" % world,
                "sharded": "time-chunk shards x%d, RCCL halo exchange + scan exit-table all-gather" % world}[mode]
         res = {

@@ -4,6 +4,7 @@ This is the thin host-language shim north_star asks for: Python calls the HIP pa
 the C ABI and nothing else.  There is NO CPU fallback here: if the library is missing or no
 HIP device is usable, loading / context creation raises.
 """
+import collections
 import ctypes as C
 import os
 
@@ -104,6 +105,7 @@ class Library(object):
         L.am_last_num_candidates.restype = C.c_longlong
         L.am_last_num_candidates.argtypes = [vp]
         L.am_set_stream.argtypes = [vp, vp]
+        L.am_wait_for_stream.argtypes = [vp, vp]
         L.am_submit_iq.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
         L.am_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
         L.am_pipe_create.restype = vp
@@ -216,6 +218,10 @@ class Context(object):
         """Device work of this context goes to the caller's HIP stream (raw handle, e.g.
         torch.cuda.current_stream().cuda_stream); None / 0: the context's own stream again."""
         self._chk(self.lib.L.am_set_stream(self._h, C.c_void_p(int(hip_stream or 0))))
+
+    def wait_for_stream(self, hip_stream):
+        """The context's stream waits (on the device) for what is enqueued on hip_stream so far (0 / None: the default stream)."""
+        self._chk(self.lib.L.am_wait_for_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
 
     def last_frontend(self):
         """3 = streaming kernel, 2 = tile kernel, 1 = rate-generic kernels, 0 = no scan yet (diagnostic)."""
@@ -391,6 +397,7 @@ class Pipe(object):
         if not self._h:
             raise AirModesError(err.value, self.lib.L.am_last_error(None).decode())
         self._out = np.zeros(4096, PACKET_DTYPE)
+        self._held = collections.deque()      # host batches in flight
 
     def close(self):
         if getattr(self, "_h", None):
@@ -414,12 +421,15 @@ class Pipe(object):
             raise AirModesError(rc, self.lib.L.am_pipe_last_error(self._h).decode())
 
     def submit(self, iq):
-        """A batch in host memory (kept alive by the caller until it is collected)."""
+        """A batch in host memory.  The samples must stay valid until the batch is collected: the (possibly converted)
+        array is kept referenced here until then."""
         f = _iq_f32(iq)
         self._chk(self.lib.L.am_pipe_submit(self._h, f.ctypes.data if f.size else None, f.size // 2, AM_F_FLUSH))
+        self._held.append(f)
 
     def submit_device(self, ptr, n):
         self._chk(self.lib.L.am_pipe_submit(self._h, int(ptr), int(n), AM_F_FLUSH | AM_F_DEVICE_IN))
+        self._held.append(None)
 
     def collect(self):
         got = C.c_uint64(0)
@@ -427,6 +437,9 @@ class Pipe(object):
         if rc == AM_ECAPACITY:
             self._out = np.zeros(int(got.value) + 1024, PACKET_DTYPE)
             rc = self.lib.L.am_pipe_collect(self._h, self._out.ctypes.data, len(self._out), C.byref(got))
+        if rc != AM_EINVAL or self.in_flight() != len(self._held):   # (the oldest batch left the pipe, done or failed)
+            if self._held:
+                self._held.popleft()
         self._chk(rc)
         return self._out[:int(got.value)].copy()
 

@@ -50,8 +50,8 @@ def main(argv=None, out=None):
     queue = msg_queue()
     rx_rate, resampler = args.rate, None
     if args.rate < 4e6 and not args.no_resample:                      # radio.py:49-53
-        from .resample import arb_resampler
-        rx_rate, resampler = 4e6, arb_resampler(4e6 / args.rate)
+        from . import resample
+        rx_rate, resampler = 4e6, resample.arb_resampler(4e6 / args.rate)
     rx = rx_path(rx_rate, args.threshold, queue, use_pmf=args.pmf, use_dcblock=args.dcblock)
     publisher = pubsub()
     feed = make_parser(publisher)
@@ -74,6 +74,8 @@ def main(argv=None, out=None):
                     last = raw.size < 2 * args.chunk
                     iq = raw[: raw.size // 2 * 2].view(np.complex64)
                     if resampler is not None:
+                        if last:      # drain: the interpolator holds its last outputs back until it has seen what follows them
+                            iq = np.concatenate([iq, np.zeros(resample.TAPS_PER_PHASE, np.complex64)])
                         iq = resampler.work(iq)
                     chunks.put((iq, last))
                     if last:

@@ -9,8 +9,9 @@ samples into the next chunk.  Per step:
   1. halo exchange   every rank sends its first `right` samples to the rank before it and its last `left`
                      samples to the rank after it (two point-to-point pairs over xGMI, KB-scale: latency
                      bound, far below the 153 GB/s of a link), received straight into the halo regions of
-                     the chunk buffer; the context's kernels run on the same PyTorch stream the receives
-                     are ordered on, so no host synchronisation separates the exchange from the scan;
+                     the chunk buffer; the context's own stream then waits ON THE DEVICE for the stream the
+                     receives are ordered on (an event: am_wait_for_stream), so no host synchronisation
+                     separates the exchange from the scan, whatever PyTorch's current stream is at step();
   2. local scan      am_shard_scan: front end, detection, refinement, the successor array and block exits of the
                      chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan
                      could enter the chunk at (those in its first 241*spc samples), where the
@@ -59,9 +60,6 @@ class ShardedReceiver(object):
         t = self.torch
         hl, hr, n = self.left, self.right, self.n
         self._buf = t.zeros((hl + n + hr) * 2, dtype=t.float32, device=dev)
-        if self._buf.is_cuda:
-            # the library's launches go to the stream the collectives are ordered on
-            self.ctx.set_stream(t.cuda.current_stream(self._buf.device).cuda_stream)
         # exit table message: [count, pos0, exit0, pos1, exit1, ...] as int64, in two sizes
         self._msg = t.zeros(1 + 2 * self.tab_cap, dtype=t.int64, device=dev)
         self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
@@ -96,6 +94,10 @@ class ShardedReceiver(object):
                 ops.append(dist.P2POp(dist.irecv, buf[(hl + n) * 2:], rank + 1, self.group))
             for req in dist.batch_isend_irecv(ops):
                 req.wait()              # (RCCL: orders the current stream behind the transfer, the host does not block)
+            if on_gpu:
+                # ... and the scan behind the current stream: the context keeps its own stream, whatever stream is
+                # current when step() is called (a stream captured once at construction raced)
+                self.ctx.wait_for_stream(t.cuda.current_stream(buf.device).cuda_stream)
         lo = max(0, self.a0 - hl)
         off = (hl - (self.a0 - lo)) * 2                      # floats to skip at the stream start
         L = self.ctx.lib.L

@@ -55,7 +55,7 @@ struct am_ctx {
     // launches for a capacity extrapolated from the previous scan (spec_cap) and lets the kernels clip
     // to the device-side count (Mdev); the real count comes back with the results, and a scan whose
     // count exceeded the capacity is redone with the exact count.
-    bool allow_spec = true;       // AIRMODES_NO_SPEC=1 disables
+    bool allow_spec = true;       // (test builds: AIRMODES_NO_SPEC=1 disables)
     bool spec_now = false;        // this scan was launched for a capacity
     const uint32_t *Mdev = nullptr;
     double spec_density = 0.0;    // candidates per position, previous scan
@@ -78,7 +78,7 @@ struct am_ctx {
     // waits on, and the whole-call time is formed on request (am_last_timing).
     bool total_pending = false;
     bool tail_synced = false;     // the stream is idle since the last scan's result synchronisation
-    bool force_generic = false;   // AIRMODES_GENERIC=1: use the rate-generic kernels only
+    bool force_generic = false;   // (test builds: AIRMODES_GENERIC=1) use the rate-generic kernels only
     // am_submit_iq / am_collect: the scan of an independent batch is enqueued by one call and completed by the other,
     // so that one host thread can keep several contexts busy (am_pipe below)
     bool defer = false;           // set while am_submit_iq runs: chain_finish enqueues and returns AM_DEFERRED
@@ -92,8 +92,8 @@ struct am_ctx {
     } pend;
     bool keep_tags = false;       // AM_F_KEEP_TAGS of the call in progress: bursts + tags of its hits stay for am_fetch_tags
     uint64_t rec_base = 0;        // absolute index of array coordinate 0 of the resident records (am_fetch_candidates)
-    bool poison = false;          // AIRMODES_POISON=1 (tests): NaN-fill the sparse bb / reference-level arrays before every scan
-    bool allow_fe3 = true;        // AIRMODES_FE=2 keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
+    bool poison = false;          // (test builds: AIRMODES_POISON=1) NaN-fill the sparse bb / reference-level arrays before every scan
+    bool allow_fe3 = true;        // (test builds: AIRMODES_FE=2) keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
     // extraction recomputes from these samples (they must stay valid until the scan's hits are sliced)
     bool bb_sparse = false;
@@ -148,6 +148,7 @@ struct am_ctx {
     uint32_t pin_exit_cap = 0;
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_wait = nullptr;     // am_wait_for_stream
     float last_total_ms = 0.0f, last_dom_ms = 0.0f;
 };
 
@@ -753,7 +754,10 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
         for (int i = 0; i < 4; i++) (void)hipEventCreateWithFlags(&c->ev[i], hipEventDisableSystemFence);
         c->use_pmf = use_pmf ? 1 : 0;
         c->use_dcblock = use_dcblock ? 1 : 0;
+#if defined(AM_TEST_KNOBS)
         {
+            // TEST BUILDS ONLY (tests/emu, tests/gpu_variants: -DAM_TEST_KNOBS): which kernels run, NaN-filled work arrays,
+            // capacity launches.  The product library reads nothing from the environment.
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
             const char *fe = getenv("AIRMODES_FE");
@@ -764,6 +768,7 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->allow_spec = !(sp && sp[0] == '1');
             if (const char *sf = getenv("AIRMODES_SPEC_FLOOR")) c->spec_floor = atof(sf);
         }
+#endif
         if ((code = configure_rate(c, rate)) != AM_OK) {
             snprintf(g_create_err, sizeof(g_create_err), "%s", c->err);
             break;
@@ -797,9 +802,11 @@ void am_destroy(am_ctx *c)
     }
 #endif
     if (!c) return;
+#if defined(AM_TEST_KNOBS)
     if (getenv("AIRMODES_HOST_TRACE") && c->ht_n)
         fprintf(stderr, "airmodes host trace over %u calls (us/call): setup %.1f, front end + refinement enqueue %.1f, chain + tail incl. sync %.1f (of which waiting %.1f), timing + hand-over %.1f, whole call %.1f, event-not-ready %.0f\n",
                 c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
+#endif
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->bits, &c->seg_tot, &c->seg_base, &c->blk_cnt, &c->blk_off,
@@ -812,6 +819,7 @@ void am_destroy(am_ctx *c)
     if (c->pin_scalars) (void)hipHostFree(c->pin_scalars);
     if (c->pin_exit) (void)hipHostFree(c->pin_exit);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -865,6 +873,19 @@ int am_set_stream(am_ctx *c, void *hip_stream)
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));               // nothing of ours is left on the old one
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return AM_OK;
+}
+
+// Order the context's stream behind everything enqueued so far on another stream of the same device (hip_stream = NULL:
+// the legacy default stream, which is PyTorch's "current stream" unless the caller changed it): an event recorded
+// there, waited for here; the host does not block.  For inputs produced by somebody else's stream (an RCCL receive).
+int am_wait_for_stream(am_ctx *c, void *hip_stream)
+{
+    if (!c) return AM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->ev_wait) HIPCHK(c, hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_wait, (hipStream_t)hip_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wait, 0));
     return AM_OK;
 }
 
@@ -986,7 +1007,9 @@ static int process_iq_core(am_ctx *c, const float *iq, uint64_t n, uint32_t flag
             return AM_OK;
         }
         if (rc == AM_RETRY_EXACT) {
+#if defined(AM_TEST_KNOBS)
             if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: capacity %u < %u candidates, scan redone\n", M, c->last_M);
+#endif
             // more candidates than the capacity this scan was launched for: redo the refinement and
             // the chain with the exact count (the fused kernel's outputs are still in place)
             rc = run_refine(c, c->ref_bb, c->ref_avg, c->ref_nseg, c->ref_stride, c->ref_mode, &M, c->ref_endj, 0);
@@ -1078,10 +1101,14 @@ int am_collect(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
                                          P.max_hits);
             }
         }
-        if (rc != AM_OK) { P.active = false; P.scanned = false; return rc; }
+        if (rc != AM_OK) { P.active = false; P.scanned = false; reset_stream(c); return rc; }
         c->spec_density = (P.j1 > P.j0) ? (double)c->last_M / (double)(P.j1 - P.j0) : 0.0;
         c->last_tags = c->n_hits;
     }
+    else
+        // nothing was scanned (a batch shorter than a burst): the copy of the caller's samples may still be in flight, and
+        // the contract says they must stay valid only until am_collect returns
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     P.active = false;
     P.scanned = false;
     reset_stream(c);                                                  // (submitted batches end their stream: AM_F_FLUSH)
@@ -1387,7 +1414,9 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
         actual = c->pin_scalars[3];
         if (!Mp || actual <= M) { c->last_M = actual; break; }
         // more candidates than the capacity this scan was launched for: once more with the exact count
+#if defined(AM_TEST_KNOBS)
         if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: shard capacity %u < %u candidates, scan redone\n", M, actual);
+#endif
         rc = run_refine(c, c->ref_bb, c->ref_avg, c->ref_nseg, c->ref_stride, c->ref_mode, &M, c->ref_endj, 0);
         if (rc != AM_OK) return rc;
     }
@@ -1455,6 +1484,8 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
 struct am_pipe {
     std::vector<am_ctx *> sub;
     size_t head = 0, inflight = 0;
+    const am_ctx *last_fail = nullptr;   // the sub-context whose call failed last (am_pipe_last_error)
+    char err[128] = "";                  // ... or the pipe's own message
 };
 
 am_pipe *am_pipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err)
@@ -1484,10 +1515,15 @@ int am_pipe_in_flight(const am_pipe *p) { return p ? (int)p->inflight : AM_EINVA
 int am_pipe_submit(am_pipe *p, const float *iq, uint64_t n, uint32_t flags)
 {
     if (!p) return AM_EINVAL;
-    if (p->inflight == p->sub.size()) return AM_ECAPACITY;          // collect the oldest batch first
+    if (p->inflight == p->sub.size()) {
+        p->last_fail = nullptr;
+        snprintf(p->err, sizeof(p->err), "every context of the pipe has a batch in flight: collect the oldest one first");
+        return AM_ECAPACITY;
+    }
     am_ctx *c = p->sub[(p->head + p->inflight) % p->sub.size()];
     const int rc = am_submit_iq(c, iq, n, flags | AM_F_FLUSH);
     if (rc == AM_OK) p->inflight++;
+    else p->last_fail = c;
     return rc;
 }
 
@@ -1495,9 +1531,14 @@ int am_pipe_collect(am_pipe *p, am_packet *out, uint64_t cap, uint64_t *n_out)
 {
     if (!p) return AM_EINVAL;
     if (n_out) *n_out = 0;
-    if (p->inflight == 0) return AM_EINVAL;
+    if (p->inflight == 0) {
+        p->last_fail = nullptr;
+        snprintf(p->err, sizeof(p->err), "no batch in flight");
+        return AM_EINVAL;
+    }
     am_ctx *c = p->sub[p->head];
     const int rc = am_collect(c, out, cap, n_out);
+    if (rc != AM_OK) p->last_fail = c;
     if (rc == AM_ECAPACITY) return rc;                              // the packets stay: call again with a larger array
     p->head = (p->head + 1) % p->sub.size();
     p->inflight--;
@@ -1507,7 +1548,7 @@ int am_pipe_collect(am_pipe *p, am_packet *out, uint64_t cap, uint64_t *n_out)
 const char *am_pipe_last_error(const am_pipe *p)
 {
     if (!p || p->sub.empty()) return g_create_err;
-    return p->sub[(p->head + (p->inflight ? p->inflight - 1 : 0)) % p->sub.size()]->err;
+    return p->last_fail ? p->last_fail->err : p->err;              // the message of whatever failed last
 }
 
 float am_pipe_last_kernel_ms(const am_pipe *p)

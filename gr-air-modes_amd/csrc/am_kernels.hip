@@ -550,6 +550,9 @@ hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, 
 // All threads of the workgroup call it (it synchronises); red = LDS scratch, one word per wave.
 // What it replaces: a one-workgroup scan launch between producer and consumer, 4.7 us each, three per scan.
 // ------------------------------------------------------------------------------------------
+#ifndef AM_CHAIN_SPIN_MAX
+#define AM_CHAIN_SPIN_MAX (1u << 25)
+#endif
 __device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, uint32_t b, uint32_t epoch, uint32_t mine,
                                                     uint32_t *red)
 {
@@ -559,7 +562,10 @@ __device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, u
     uint32_t acc = 0;
     for (uint32_t k = threadIdx.x; k < b; k += blockDim.x) {
         unsigned long long v = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((uint32_t)(v >> 32) != epoch) {
+        for (unsigned spins = 0; (uint32_t)(v >> 32) != epoch; ++spins) {
+            // a predecessor that never publishes would hang the queue: after ~2 s of waiting the launch is aborted instead
+            // (the host then sees a failed launch and returns AM_EHIP) -- see am_chain_place for why it cannot happen
+            if (spins == AM_CHAIN_SPIN_MAX) __builtin_trap();
             __builtin_amdgcn_s_sleep(1);
             v = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -575,13 +581,19 @@ __device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, u
     return tot;
 }
 
-// The workgroup's place in the chain.  Normally blockIdx.x: workgroups start in index order as long as all of them
-// fit on the chip at once, and a launch of this family is far below that (hundreds of workgroups).  Beyond
-// AM_CHAIN_TICKET_MIN workgroups (millions of candidates in one scan: pathological input) the order in which the
-// XCDs start their share is no longer a safe assumption, and a workgroup waiting for one that has not started could
-// wait for ever; then the place is a ticket drawn at the start (an atomic counter tagged with the launch's epoch),
-// so everything a workgroup waits for is already running.  Same-address atomics serialise (~11 ns each), hence
-// not the default.  All threads call it (it synchronises); tick = LDS scratch word.
+// The workgroup's place in the chain.  Normally blockIdx.x.  Why waiting for lower indices cannot deadlock: a 1-D
+// grid is dealt to the 8 XCDs round robin (workgroup i to XCD i mod 8) and EACH XCD starts its share in index order.
+// A workgroup waits only for lower indices; the lowest one that has not started is the next in its own XCD's queue, and
+// what occupies that XCD is either other kernels (this library's all terminate: the persistent front end walks a
+// finite segment) or workgroups of this launch with lower indices still -- by induction one of them can always run.
+// That holds with several contexts in flight (am_pipe) as long as the launch fits the chip at once -- a launch of this
+// family has hundreds of workgroups; the chip holds thousands of them.  Beyond AM_CHAIN_TICKET_MIN workgroups (millions
+// of candidates in one scan: pathological input) resident slots can run out, and a workgroup waiting for one that has
+// not started could wait for ever; then the place is a ticket drawn at the start (an atomic counter tagged with the
+// launch's epoch), so everything a workgroup waits for is already running.  Same-address atomics serialise (~11 ns
+// each), hence not the default.  Should the argument above ever fail, am_chain_prefix gives up after
+// AM_CHAIN_SPIN_MAX polls (~2 s) and aborts the launch: an error at the C ABI, not a hang.
+// All threads call it (it synchronises); tick = LDS scratch word.
 #ifndef AM_CHAIN_TICKET_MIN
 #define AM_CHAIN_TICKET_MIN 512
 #endif
@@ -1427,7 +1439,7 @@ size_t am_chain_scratch_bytes(uint32_t M) { return am_chain_layout_of(M).words *
 
 // the walk kernels may need more than the default 64 KB of dynamic LDS: raised once per device and kernel
 // (`done` is the caller's per-kernel table; a process may hold contexts on several devices)
-static hipError_t am_chain_walk_lds(const void *kernel, bool (&done)[64])
+static hipError_t am_chain_walk_lds(const void *kernel, std::atomic<bool> (&done)[64])
 {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1461,7 +1473,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_walk), attr_set); rc != hipSuccess)
         return rc;
     const size_t lds = am_chain_walk_lds_bytes(L.nblk, L.headw);
@@ -1484,7 +1496,7 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 {
     if (n == 0 || M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_exit_table), attr_set);
         rc != hipSuccess)
         return rc;

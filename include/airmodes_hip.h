@@ -149,6 +149,11 @@ float am_pipe_last_kernel_ms(const am_pipe *pipe);   /* dominant-kernel time of 
  * synchronisation.  The stream must outlive the context or be replaced before it is destroyed.  (No counterpart in
  * the reference: GNU Radio blocks have no device streams.) */
 int am_set_stream(am_ctx *ctx, void *hip_stream);
+/* Order the context's stream behind everything enqueued so far on another stream of the same device (NULL = the legacy
+ * default stream, PyTorch's current stream unless the caller changed it): an event recorded there and waited for here,
+ * the host does not block.  For inputs another stream produces -- e.g. boundary samples an RCCL receive is still
+ * writing (air_modes/sharded.py). */
+int am_wait_for_stream(am_ctx *ctx, void *hip_stream);
 
 /* start a new stream: sample counter, carry-over samples and greedy-scan state are cleared */
 int    am_reset(am_ctx *ctx);

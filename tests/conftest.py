@@ -70,3 +70,15 @@ def hip_lib():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gr-air-modes_amd", "csrc")])
     from air_modes import _capi
     return _capi.Library(HIP_LIB)
+
+
+@pytest.fixture(scope="session")
+def hip_knobs_lib():
+    """TEST-ONLY build of the product configuration with the environment knobs compiled in (-DAM_TEST_KNOBS): the tests
+    that steer which kernels run (AIRMODES_FE / AIRMODES_GENERIC) or NaN-fill work arrays (AIRMODES_POISON) load this one;
+    the product library reads nothing from the environment."""
+    path = os.path.join(ROOT, "tests", "gpu_variants", "libairmodes_hip_knobs.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "gr-air-modes_amd", "csrc"), "knobs"])
+    from air_modes import _capi
+    return _capi.Library(path)

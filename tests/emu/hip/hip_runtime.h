@@ -124,6 +124,8 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
 #define hipEventDisableSystemFence 0x20000000
+#define hipEventDisableTiming 0x2
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }

@@ -22,6 +22,14 @@ def lib(hip_lib):
     return hip_lib
 
 
+@pytest.fixture(scope="module")
+def klib(hip_knobs_lib):
+    """test-only build with the environment knobs (conftest.hip_knobs_lib): for the tests that steer kernels"""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return hip_knobs_lib
+
+
 @pytest.mark.parametrize("path", pc.golden_cases(), ids=lambda p: os.path.basename(p)[:-4])
 def test_golden(lib, path):
     pc.check_golden(lib, path)
@@ -42,7 +50,8 @@ def test_tiled_fused_kernel_still_matches(lib, monkeypatch):
         assert pc.check_stages(lib, rate, n, 6000.0, 51) > 3
 
 
-def test_generic_kernels_still_match(lib, monkeypatch):
+def test_generic_kernels_still_match(klib, monkeypatch):
+    lib = klib
     monkeypatch.setenv("AIRMODES_GENERIC", "1")
     for rate, n in ((2e6, 1000000), (20e6, 2000000), (64e6, 4000000)):
         assert pc.check_stages(lib, rate, n, 6000.0, 41) > 3
@@ -256,10 +265,11 @@ def test_greedy_chain_rare_branches_on_device():
     assert np.array_equal(pk, oracle.demod(iq64, 64e6, 7.0, True)) and len(pk) > 100
 
 
-def test_streaming_and_tile_front_ends_agree(lib, monkeypatch):
+def test_streaming_and_tile_front_ends_agree(klib, monkeypatch):
     """64 Msps: am_k_fe3 (default) and am_k_fe2 (AIRMODES_FE=2) give the oracle's packets -- also without the
     pulse-matched filter and with NaN / inf / denormal samples in INTERIOR tiles and steps (the EXEC-narrowing
     compares of the fast bodies only exist on the device)."""
+    lib = klib
     iq, _ = synth.synth_capture(64e6, 6000000, 20000.0, 77)
     assert pc.check_front_ends_agree(lib, 64e6, iq, monkeypatch) > 50
     assert pc.check_front_ends_agree(lib, 64e6, iq[:3000000], monkeypatch, thr=5.0, pmf=False) > 20
@@ -269,7 +279,8 @@ def test_streaming_and_tile_front_ends_agree(lib, monkeypatch):
         pc.check_front_ends_agree(lib, rate, pc.nonfinite_stream(rate, 1500000), monkeypatch, expect_streaming=False)
 
 
-def test_streaming_front_end_unaligned_and_short_inputs(lib, monkeypatch):
+def test_streaming_front_end_unaligned_and_short_inputs(klib, monkeypatch):
+    lib = klib
     monkeypatch.setenv("AIRMODES_POISON", "1")     # NaN-fill the sparse arrays before every scan: no stale value can help
     iq, _ = synth.synth_capture(64e6, 5000000, 20000.0, 78)
     want = oracle.demod(iq, 64e6)

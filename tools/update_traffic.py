@@ -3,7 +3,9 @@
     python tools/update_traffic.py profiles/<round>/summary.txt 64msps
 FETCH_SIZE is doubled (gfx950 reports half the bytes of a wide coalesced read: MI355X_MICROARCH.md,
 HBM section); WRITE_SIZE is taken as reported."""
+import hashlib
 import json
+import os
 import re
 import sys
 
@@ -22,7 +24,10 @@ def mean_of(section):
 
 kernel, fetch = mean_of("FETCH_SIZE")
 _, write = mean_of("WRITE_SIZE")
-doc = {"workload": workload, "kernel": kernel, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
+ksrc = "am_fe3.hip" if kernel.startswith("am_k_fe3") else "am_fe2.hip"
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gr-air-modes_amd", "csrc", ksrc), "rb") as kf:
+    ksha = hashlib.sha256(kf.read()).hexdigest()[:16]
+doc = {"workload": workload, "kernel": kernel, "kernel_source": ksrc, "kernel_source_sha16": ksha, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
        "fetch_bytes_corrected": int(fetch * 1024 * 2), "write_bytes": int(write * 1024),
        "traffic_bytes": int(fetch * 1024 * 2 + write * 1024), "source": sys.argv[1],
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `python bench.py --steps 2 "
