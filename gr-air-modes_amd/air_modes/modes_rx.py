@@ -51,7 +51,8 @@ def main(argv=None, out=None):
     rx_rate, resampler = args.rate, None
     if args.rate < 4e6 and not args.no_resample:                      # radio.py:49-53
         from . import resample
-        rx_rate, resampler = 4e6, resample.arb_resampler(4e6 / args.rate)
+        # on the GPU, bit-identical to resample.arb_resampler (its definition); the output stays on the device
+        rx_rate, resampler = 4e6, resample.gpu_resampler(4e6 / args.rate)
     rx = rx_path(rx_rate, args.threshold, queue, use_pmf=args.pmf, use_dcblock=args.dcblock)
     publisher = pubsub()
     feed = make_parser(publisher)
@@ -61,7 +62,7 @@ def main(argv=None, out=None):
     print("Using file source %s" % args.source, file=sys.stderr)
     print("Rate is %i" % int(args.rate), file=sys.stderr)
 
-    # reader: one chunk ahead of the GPU (disk read + resampling overlap the previous chunk's GPU call)
+    # reader: one chunk ahead of the GPU (the disk read overlaps the previous chunk's GPU calls)
     import queue as _queue
     import threading
     chunks = _queue.Queue(maxsize=2)
@@ -73,10 +74,9 @@ def main(argv=None, out=None):
                     raw = np.fromfile(f, dtype=np.float32, count=2 * args.chunk)
                     last = raw.size < 2 * args.chunk
                     iq = raw[: raw.size // 2 * 2].view(np.complex64)
-                    if resampler is not None:
-                        if last:      # drain: the interpolator holds its last outputs back until it has seen what follows them
-                            iq = np.concatenate([iq, np.zeros(resample.TAPS_PER_PHASE, np.complex64)])
-                        iq = resampler.work(iq)
+                    if resampler is not None and last:
+                        # drain: the interpolator holds its last outputs back until it has seen what follows them
+                        iq = np.concatenate([iq, np.zeros(resample.TAPS_PER_PHASE, np.complex64)])
                     chunks.put((iq, last))
                     if last:
                         return
@@ -89,7 +89,11 @@ def main(argv=None, out=None):
         iq, last = chunks.get()
         if isinstance(iq, Exception):
             raise iq
-        rx.work(iq, flush=last)
+        if resampler is not None:
+            ptr, m = resampler.work_device(iq)                        # (python/radio.py:49-53) 2 -> 4 Msps on the GPU
+            rx.work_device(ptr, m, flush=last)
+        else:
+            rx.work(iq, flush=last)
         while not queue.empty_p():
             text = queue.delete_head().to_string()
             if args.raw:

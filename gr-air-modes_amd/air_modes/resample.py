@@ -2,9 +2,12 @@
 
 The reference's radio front end resamples anything slower than 4 Msps to 4 Msps before rx_path
 (python/radio.py:49-53: pfb.arb_resampler_ccf(4e6 / rate), GNU Radio's polyphase arbitrary resampler with
-its default taps).  GNU Radio is not part of this tree, its tap design is not reproducible here, and this
-stage sits in front of the hot path at a few Msps: it runs on the host (numpy), with documented taps of its
-own.  PARITY UNPINNED by construction -- tests compare packet recall, not bits.
+its default taps).  GNU Radio is not part of this tree and its tap design is not reproducible here: PARITY UNPINNED by
+construction -- against the reference this stage is compared by packet recall, not bits.  This module is the
+DEFINITION of the stage: `arb_resampler` (numpy) writes the arithmetic out operation by operation, in a fixed order,
+one IEEE double rounding each; `gpu_resampler` is the same thing on the GPU (csrc/am_resample.hip, C ABI
+am_resampler_*), bit for bit (tests/test_resample.py), and what modes_rx uses: its output stays on the device and goes
+straight into the receive path.
 
 Design: 32-phase polyphase interpolator, prototype = Kaiser-windowed sinc (beta 5.0, 8 taps per phase,
 cut-off at 0.6 of the input rate: a Mode-S pulse at 2 Msps is ONE sample wide, its spectrum reaches the input's
@@ -67,16 +70,87 @@ class arb_resampler(object):
             frac = (t - i0) * NPHASE
             p = np.minimum(np.floor(frac).astype(np.int64), NPHASE - 1)
             a = frac - p
-            q = np.arange(T)[None, :]
-            win0 = buf[(T + i0)[:, None] - q]
-            y0 = np.einsum("mq,mq->m", win0, self.taps[p])
             wrap = (p + 1) >= NPHASE
-            win1 = buf[(T + i0 + wrap)[:, None] - q]
-            y1 = np.einsum("mq,mq->m", win1, self.taps[np.where(wrap, 0, p + 1)])
-            y = ((1.0 - a) * y0 + a * y1).astype(np.complex64)
+            p1 = np.where(wrap, 0, p + 1)
+            re, im = np.ascontiguousarray(buf.real), np.ascontiguousarray(buf.imag)
+            y0r = np.zeros(m_cnt); y0i = np.zeros(m_cnt); y1r = np.zeros(m_cnt); y1i = np.zeros(m_cnt)
+            for q in range(T):                                 # tap by tap, in this order: product, then sum (two roundings)
+                k0 = T + i0 - q
+                k1 = k0 + wrap
+                c0, c1 = self.taps[p, q], self.taps[p1, q]
+                y0r = y0r + re[k0] * c0
+                y0i = y0i + im[k0] * c0
+                y1r = y1r + re[k1] * c1
+                y1i = y1i + im[k1] * c1
+            b = 1.0 - a
+            y = np.empty(m_cnt, np.complex64)
+            y.real = (b * y0r + a * y1r).astype(np.float32)
+            y.imag = (b * y0i + a * y1i).astype(np.float32)
             self._pos = t[-1] + step - n_in
         else:
             y = np.zeros(0, np.complex64)
             self._pos -= n_in
         self._hist = buf[-T:]
         return y
+
+
+class gpu_resampler(object):
+    """arb_resampler on the GPU (csrc/am_resample.hip), bit-identical to it.  work() returns host samples;
+    work_device() leaves them on the device: (device pointer to interleaved float32 I,Q, number of complex samples),
+    valid until the next call -- what rx_path.work_device / am_process_iq(AM_F_DEVICE_IN) take."""
+
+    def __init__(self, ratio, device=-1, lib=None):
+        import ctypes as C
+        from . import _capi
+        self._C, self._capi = C, _capi
+        self.lib = lib or _capi.default_library()
+        L = self.lib.L
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.am_resampler_create.restype = vp
+        L.am_resampler_create.argtypes = [C.c_int, C.c_double, vp, C.POINTER(C.c_int)]
+        L.am_resampler_destroy.argtypes = [vp]
+        L.am_resampler_reset.argtypes = [vp]
+        L.am_resampler_work.argtypes = [vp, vp, u64, C.c_uint32, vp, u64, C.POINTER(u64)]
+        L.am_resampler_device_output.restype = vp
+        L.am_resampler_device_output.argtypes = [vp]
+        L.am_resampler_last_error.restype = C.c_char_p
+        L.am_resampler_last_error.argtypes = [vp]
+        self.ratio = float(ratio)
+        self.taps = design_taps()
+        self.delay = (NPHASE * TAPS_PER_PHASE - 1) / (2.0 * NPHASE)
+        err = C.c_int(0)
+        self._h = L.am_resampler_create(int(device), self.ratio, self.taps.ctypes.data, C.byref(err))
+        if not self._h:
+            raise _capi.AirModesError(err.value, "am_resampler_create failed (no HIP device?)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.am_resampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise self._capi.AirModesError(rc, self.lib.L.am_resampler_last_error(self._h).decode())
+
+    def _run(self, x, out_ptr, cap):
+        f = self._capi._iq_f32(x)
+        n = f.size // 2
+        got = self._C.c_uint64(0)
+        self._chk(self.lib.L.am_resampler_work(self._h, f.ctypes.data if n else None, n, 0, out_ptr, cap, self._C.byref(got)))
+        return int(got.value)
+
+    def work(self, x):
+        n = np.asarray(x).size
+        out = np.zeros(int(n * self.ratio) + 16, np.complex64)
+        m = self._run(x, out.ctypes.data, out.size)
+        return out[:m].copy()
+
+    def work_device(self, x):
+        m = self._run(x, None, 0)
+        return int(self.lib.L.am_resampler_device_output(self._h) or 0), m

@@ -248,6 +248,24 @@ int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, c
                    uint32_t nranks, uint64_t *entry);
 int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out);
 
+/* ---- resampling in front of the path (python/radio.py:49-53) ------------------------------------------------
+ * modes_radio resamples anything slower than 4 Msps to 4 Msps with pfb.arb_resampler_ccf before rx_path.  GNU Radio's
+ * block and tap design are not in the reference tree (parity unpinned); this is the package's own 32-phase x 8-tap
+ * polyphase interpolator, DEFINED operation by operation in air_modes/resample.py and repeated bit for bit on the GPU.
+ * taps: 32 x 8 doubles [phase][tap] (air_modes.resample.design_taps).  ratio = f_out / f_in >= 1.
+ * am_resampler_work: n complex input samples (host, or device with AM_F_DEVICE_IN) -> *n_out complex output samples,
+ *   copied to `out` (host, or device with AM_F_DEVICE_OUT; cap complex samples) or, when out is NULL, left in the
+ *   handle's device buffer (am_resampler_device_output, valid until the next call: hand it to am_process_iq with
+ *   AM_F_DEVICE_IN).  The read position and the last 8 input samples carry over from call to call. */
+typedef struct am_resampler am_resampler;
+am_resampler *am_resampler_create(int device, double ratio, const double *taps, int *err);
+void am_resampler_destroy(am_resampler *h);
+int am_resampler_reset(am_resampler *h);
+int am_resampler_work(am_resampler *h, const float *iq, uint64_t n_complex, uint32_t flags, float *out, uint64_t cap,
+                      uint64_t *n_out);
+const float *am_resampler_device_output(const am_resampler *h);
+const char *am_resampler_last_error(const am_resampler *h);
+
 /* last error text of the context (or of am_create when ctx == NULL) */
 const char *am_last_error(const am_ctx *ctx);
 
