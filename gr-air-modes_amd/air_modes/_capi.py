@@ -447,6 +447,59 @@ class Pipe(object):
         return float(self.lib.L.am_pipe_last_kernel_ms(self._h))
 
 
+class Uploader(object):
+    """am_uploader wrapper: `nslots` pinned host buffers with device twins and a copy stream.  buffer(slot) is a numpy
+    float32 view of the pinned memory (fill it -- e.g. file.readinto -- then start(slot, n)); wait(slot) blocks until the
+    samples are on the device and returns the device pointer.  The copy of one chunk overlaps the scan of the one before."""
+
+    def __init__(self, capacity_complex, nslots=2, device=-1, lib=None):
+        self.lib = lib or default_library()
+        L = self.lib.L
+        L.am_uploader_create.restype = C.c_void_p
+        L.am_uploader_create.argtypes = [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_int)]
+        L.am_uploader_destroy.argtypes = [C.c_void_p]
+        L.am_uploader_host.restype = C.c_void_p
+        L.am_uploader_host.argtypes = [C.c_void_p, C.c_int]
+        L.am_uploader_start.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.am_uploader_wait.restype = C.c_void_p
+        L.am_uploader_wait.argtypes = [C.c_void_p, C.c_int]
+        err = C.c_int(0)
+        self.capacity, self.nslots = int(capacity_complex), int(nslots)
+        self._h = L.am_uploader_create(int(device), self.capacity, self.nslots, C.byref(err))
+        if not self._h:
+            raise AirModesError(err.value, "am_uploader_create failed")
+        self._views = []
+        for k in range(self.nslots):
+            ptr = L.am_uploader_host(self._h, k)
+            self._views.append(np.ctypeslib.as_array((C.c_float * (2 * self.capacity)).from_address(ptr)))
+
+    def buffer(self, slot):
+        return self._views[slot]
+
+    def start(self, slot, n_complex):
+        rc = self.lib.L.am_uploader_start(self._h, int(slot), int(n_complex))
+        if rc != AM_OK:
+            raise AirModesError(rc, "am_uploader_start failed")
+
+    def wait(self, slot):
+        ptr = self.lib.L.am_uploader_wait(self._h, int(slot))
+        if not ptr:
+            raise AirModesError(AM_EHIP, "am_uploader_wait failed")
+        return int(ptr)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._views = []
+            self.lib.L.am_uploader_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_entries(lib, tables, starts):
     """am_shard_entry: scan entry position of every chunk from the chunks' exit tables."""
     n = len(tables)

@@ -22,6 +22,8 @@ import sys
 
 import numpy as np
 
+from . import resample
+
 
 def build_parser():
     ap = argparse.ArgumentParser(prog="modes_rx", description=__doc__.split("\n\n")[0])
@@ -50,7 +52,6 @@ def main(argv=None, out=None):
     queue = msg_queue()
     rx_rate, resampler = args.rate, None
     if args.rate < 4e6 and not args.no_resample:                      # radio.py:49-53
-        from . import resample
         # on the GPU, bit-identical to resample.arb_resampler (its definition); the output stays on the device
         rx_rate, resampler = 4e6, resample.gpu_resampler(4e6 / args.rate)
     rx = rx_path(rx_rate, args.threshold, queue, use_pmf=args.pmf, use_dcblock=args.dcblock)
@@ -62,38 +63,53 @@ def main(argv=None, out=None):
     print("Using file source %s" % args.source, file=sys.stderr)
     print("Rate is %i" % int(args.rate), file=sys.stderr)
 
-    # reader: one chunk ahead of the GPU (the disk read overlaps the previous chunk's GPU calls)
+    # File -> pinned host buffer -> device, two buffers in flight (python/radio.py:221-234's file source): the reader thread
+    # fills one pinned buffer from the file and starts its copy to the device while the GPU still works on the chunk before
+    # it; the receive path (and the interpolator in front of it) take device pointers, so a sample crosses PCIe once and
+    # never comes back.
     import queue as _queue
     import threading
-    chunks = _queue.Queue(maxsize=2)
+    from . import _capi
+    nslots = 2
+    drain = resample.TAPS_PER_PHASE if resampler is not None else 0
+    up = _capi.Uploader(args.chunk + drain, nslots=nslots)
+    ready = _queue.Queue()                    # (slot, samples, last) in stream order, or an exception
+    free = _queue.Queue()
+    for k in range(nslots):
+        free.put(k)
 
     def reader():
         try:
             with open(args.source, "rb") as f:
                 while True:
-                    raw = np.fromfile(f, dtype=np.float32, count=2 * args.chunk)
-                    last = raw.size < 2 * args.chunk
-                    iq = raw[: raw.size // 2 * 2].view(np.complex64)
-                    if resampler is not None and last:
+                    slot = free.get()
+                    buf = up.buffer(slot)
+                    want = 8 * args.chunk
+                    got = f.readinto(memoryview(buf).cast("B")[:want])
+                    n = got // 8                                      # whole complex samples
+                    last = got < want
+                    if last and drain:
                         # drain: the interpolator holds its last outputs back until it has seen what follows them
-                        iq = np.concatenate([iq, np.zeros(resample.TAPS_PER_PHASE, np.complex64)])
-                    chunks.put((iq, last))
+                        buf[2 * n:2 * (n + drain)] = 0.0
+                        n += drain
+                    up.start(slot, n)
+                    ready.put((slot, n, last))
                     if last:
                         return
         except Exception as err:                                      # surfaces in the consumer
-            chunks.put((err, True))
+            ready.put((err, 0, True))
 
     th = threading.Thread(target=reader, daemon=True)
     th.start()
     while True:
-        iq, last = chunks.get()
-        if isinstance(iq, Exception):
-            raise iq
+        slot, n, last = ready.get()
+        if isinstance(slot, Exception):
+            raise slot
+        ptr = up.wait(slot)
         if resampler is not None:
-            ptr, m = resampler.work_device(iq)                        # (python/radio.py:49-53) 2 -> 4 Msps on the GPU
-            rx.work_device(ptr, m, flush=last)
-        else:
-            rx.work(iq, flush=last)
+            ptr, n = resampler.work_device_in(ptr, n)                 # (python/radio.py:49-53) 2 -> 4 Msps on the GPU
+        rx.work_device(ptr, n, flush=last)
+        free.put(slot)                                                # (the call returned: the device is done with the slot)
         while not queue.empty_p():
             text = queue.delete_head().to_string()
             if args.raw:
@@ -110,6 +126,7 @@ def main(argv=None, out=None):
         if last:
             break
     th.join()
+    up.close()
     print("%d samples, %d packets" % (rx.samples, rx.packets), file=sys.stderr)
     return 0
 

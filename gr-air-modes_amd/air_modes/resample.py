@@ -154,3 +154,10 @@ class gpu_resampler(object):
     def work_device(self, x):
         m = self._run(x, None, 0)
         return int(self.lib.L.am_resampler_device_output(self._h) or 0), m
+
+    def work_device_in(self, dev_ptr, n_complex):
+        """Input already on the device (interleaved float32 at dev_ptr); output left on the device as in work_device."""
+        got = self._C.c_uint64(0)
+        self._chk(self.lib.L.am_resampler_work(self._h, int(dev_ptr) if n_complex else None, int(n_complex),
+                                               self._capi.AM_F_DEVICE_IN, None, 0, self._C.byref(got)))
+        return int(self.lib.L.am_resampler_device_output(self._h) or 0), int(got.value)

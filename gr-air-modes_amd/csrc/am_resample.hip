@@ -210,3 +210,79 @@ int am_resampler_work(am_resampler *h, const float *iq, uint64_t n, uint32_t fla
 }
 
 } // extern "C"
+
+/* ---- pinned staging: host samples on their way to the device, several buffers in flight --------------------------
+ * A file (or socket) reader fills slot k's pinned buffer and starts its copy while the receive path still works on
+ * slot k-1's samples on the device: the PCIe transfer of one chunk overlaps the scan of the one before it. */
+#define AM_UP_MAXSLOTS 8
+struct am_uploader {
+    int device = 0, nslots = 0;
+    uint64_t cap = 0;                     // complex samples per slot
+    float *host[AM_UP_MAXSLOTS] = {};
+    float *dev[AM_UP_MAXSLOTS] = {};
+    hipEvent_t done[AM_UP_MAXSLOTS] = {};
+    hipStream_t stream = nullptr;
+};
+
+extern "C" {
+
+am_uploader *am_uploader_create(int device, uint64_t capacity_complex, int nslots, int *err)
+{
+    int code = AM_OK;
+    am_uploader *u = nullptr;
+    do {
+        if (nslots < 1 || nslots > AM_UP_MAXSLOTS || capacity_complex == 0) { code = AM_EINVAL; break; }
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { code = AM_ENODEV; break; }
+        u = new (std::nothrow) am_uploader();
+        if (!u) { code = AM_ENOMEM; break; }
+        if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+        if (device >= ndev) { code = AM_ENODEV; break; }
+        u->device = device; u->nslots = nslots; u->cap = capacity_complex;
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&u->stream) != hipSuccess) { code = AM_EHIP; break; }
+        const size_t bytes = (size_t)capacity_complex * 2 * sizeof(float);
+        for (int k = 0; k < nslots && code == AM_OK; ++k) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&u->host[k]), bytes, hipHostMallocDefault) != hipSuccess) code = AM_ENOMEM;
+            else if (hipMalloc(reinterpret_cast<void **>(&u->dev[k]), bytes) != hipSuccess) code = AM_ENOMEM;
+            else if (hipEventCreateWithFlags(&u->done[k], hipEventDisableTiming) != hipSuccess) code = AM_EHIP;
+        }
+    } while (0);
+    if (code != AM_OK && u) { am_uploader_destroy(u); u = nullptr; }
+    if (err) *err = code;
+    return u;
+}
+
+void am_uploader_destroy(am_uploader *u)
+{
+    if (!u) return;
+    (void)hipSetDevice(u->device);
+    if (u->stream) (void)hipStreamSynchronize(u->stream);
+    for (int k = 0; k < AM_UP_MAXSLOTS; ++k) {
+        if (u->host[k]) (void)hipHostFree(u->host[k]);
+        if (u->dev[k]) (void)hipFree(u->dev[k]);
+        if (u->done[k]) (void)hipEventDestroy(u->done[k]);
+    }
+    if (u->stream) (void)hipStreamDestroy(u->stream);
+    delete u;
+}
+
+float *am_uploader_host(am_uploader *u, int slot) { return (u && slot >= 0 && slot < u->nslots) ? u->host[slot] : nullptr; }
+
+int am_uploader_start(am_uploader *u, int slot, uint64_t n_complex)
+{
+    if (!u || slot < 0 || slot >= u->nslots || n_complex > u->cap) return AM_EINVAL;
+    if (hipSetDevice(u->device) != hipSuccess) return AM_EHIP;
+    if (n_complex && hipMemcpyAsync(u->dev[slot], u->host[slot], (size_t)n_complex * 2 * sizeof(float), hipMemcpyHostToDevice,
+                                    u->stream) != hipSuccess)
+        return AM_EHIP;
+    return hipEventRecord(u->done[slot], u->stream) == hipSuccess ? AM_OK : AM_EHIP;
+}
+
+const float *am_uploader_wait(am_uploader *u, int slot)
+{
+    if (!u || slot < 0 || slot >= u->nslots) return nullptr;
+    if (hipSetDevice(u->device) != hipSuccess || hipEventSynchronize(u->done[slot]) != hipSuccess) return nullptr;
+    return u->dev[slot];
+}
+
+} // extern "C"

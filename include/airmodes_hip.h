@@ -266,6 +266,19 @@ int am_resampler_work(am_resampler *h, const float *iq, uint64_t n_complex, uint
 const float *am_resampler_device_output(const am_resampler *h);
 const char *am_resampler_last_error(const am_resampler *h);
 
+/* ---- pinned staging for a host source (apps/modes_rx's file source, python/radio.py:221-234) --------------------
+ * nslots pinned host buffers of capacity_complex samples each, with a device twin and a copy stream: the reader fills
+ * am_uploader_host(slot), am_uploader_start begins the copy and returns, am_uploader_wait blocks until that slot's
+ * samples are on the device and returns the device pointer (for am_process_iq / am_resampler_work with
+ * AM_F_DEVICE_IN) -- the transfer of chunk k+1 overlaps the scan of chunk k.  start and wait may be called from
+ * different threads (one producer, one consumer); a slot is reused only after its consumer is done with it. */
+typedef struct am_uploader am_uploader;
+am_uploader *am_uploader_create(int device, uint64_t capacity_complex, int nslots, int *err);
+void am_uploader_destroy(am_uploader *u);
+float *am_uploader_host(am_uploader *u, int slot);
+int am_uploader_start(am_uploader *u, int slot, uint64_t n_complex);
+const float *am_uploader_wait(am_uploader *u, int slot);
+
 /* last error text of the context (or of am_create when ctx == NULL) */
 const char *am_last_error(const am_ctx *ctx);
 
