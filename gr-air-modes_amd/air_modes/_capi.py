@@ -106,6 +106,9 @@ class Library(object):
         L.am_last_num_candidates.argtypes = [vp]
         L.am_set_stream.argtypes = [vp, vp]
         L.am_wait_for_stream.argtypes = [vp, vp]
+        L.am_signal_stream.argtypes = [vp, vp]
+        L.am_shard_scan_async.argtypes = [vp, vp, u64, u64, u64, u32, vp, u64]
+        L.am_shard_resolve_async.argtypes = [vp, vp, u32, u32, u64, vp, u64, pu64, C.POINTER(ci)]
         L.am_submit_iq.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
         L.am_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
         L.am_pipe_create.restype = vp
@@ -222,6 +225,25 @@ class Context(object):
     def wait_for_stream(self, hip_stream):
         """The context's stream waits (on the device) for what is enqueued on hip_stream so far (0 / None: the default stream)."""
         self._chk(self.lib.L.am_wait_for_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def signal_stream(self, hip_stream):
+        """hip_stream (0 / None: the default stream) waits, on the device, for what the context has enqueued so far."""
+        self._chk(self.lib.L.am_signal_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
+
+    def shard_scan_async(self, dev_ptr, abs_start, abs_end, total_n, msg_ptr, msg_cap, device_in=True):
+        self._chk(self.lib.L.am_shard_scan_async(self._h, C.c_void_p(int(dev_ptr)), int(abs_start), int(abs_end), int(total_n),
+                                                 AM_F_DEVICE_IN if device_in else 0, C.c_void_p(int(msg_ptr)), int(msg_cap)))
+
+    def shard_resolve_async(self, msgs_ptr, world, rank, msg_cap, capacity=4096):
+        """-> (packets, redo).  redo: nothing was delivered, repeat the step on the synchronous path."""
+        out = self._receive_buffer(int(capacity))
+        got, redo = C.c_uint64(0), C.c_int(0)
+        rc = self.lib.L.am_shard_resolve_async(self._h, C.c_void_p(int(msgs_ptr)), int(world), int(rank), int(msg_cap),
+                                               out.ctypes.data, len(out), C.byref(got), C.byref(redo))
+        if rc == AM_ECAPACITY:
+            return self._fetch(int(got.value)), False
+        self._chk(rc)
+        return self._received(out, got.value), bool(redo.value)
 
     def last_frontend(self):
         """3 = streaming kernel, 2 = tile kernel, 1 = rate-generic kernels, 0 = no scan yet (diagnostic)."""

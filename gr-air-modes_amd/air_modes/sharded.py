@@ -12,14 +12,20 @@ samples into the next chunk.  Per step:
                      the chunk buffer; the context's own stream then waits ON THE DEVICE for the stream the
                      receives are ordered on (an event: am_wait_for_stream), so no host synchronisation
                      separates the exchange from the scan, whatever PyTorch's current stream is at step();
-  2. local scan      am_shard_scan: front end, detection, refinement, the successor array and block exits of the
-                     chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan
-                     could enter the chunk at (those in its first 241*spc samples), where the
-                     scan would leave the chunk;
-  3. table exchange  one all_gather of fixed-size exit tables (16 bytes per entry; a short message of 512
-                     entries, and the full 241*spc-entry one only if some rank's table does not fit);
-                     every rank composes them (am_shard_entry) -> scan entry of its own chunk;
-  4. resolve         am_shard_resolve(entry): mark the chain from that entry, extract + slice.
+  2. local scan      am_shard_scan_async: front end, detection, refinement, the successor array and block exits of
+                     the chunk's own greedy chain, plus an EXIT TABLE: for every candidate the scan could enter the
+                     chunk at (those in its first 241*spc samples), where the scan would leave the chunk.  All of it
+                     is only enqueued; the table lands in a device message;
+  3. table exchange  one all_gather of the fixed-size messages (count + 512 entries of 16 bytes), device to device,
+                     ordered behind the scan and in front of the next step by events (am_signal_stream /
+                     am_wait_for_stream): no host copy;
+  4. resolve         am_shard_resolve_async: the entry position of the own chunk is composed from all tables by a
+                     kernel, the chain is marked from there, hits are extracted and sliced.  ONE completion wait
+                     per step (round 2: two waits and a host round trip for the tables between them).
+  A step whose table does not fit the message, or whose scan met more candidates than the capacity it was launched for
+  (every rank sees the same flag / its own count), is repeated on the synchronous path of round 2 (am_shard_scan ->
+  host tables -> am_shard_entry -> am_shard_resolve; `sync_steps` counts them; the first step of a receiver, which has
+  no candidate-density estimate yet, reads one count back).
 
 Packets of all ranks, concatenated in rank order, equal the single-GPU (and the reference's)
 packet list for the whole stream; the per-rank work does not grow with the number of ranks.
@@ -36,7 +42,7 @@ class ShardedReceiver(object):
     """`chunk` is this rank's 2*n float32 I,Q samples (a view into the halo'd device buffer:
     write the samples there once, no per-step copy); step() runs one pass."""
 
-    def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None, small_table=512):
+    def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None, small_table=512, host_free=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -53,6 +59,8 @@ class ShardedReceiver(object):
         # (every rank sees every count) the full-size message follows
         self.small_cap = max(1, min(int(small_table), self.tab_cap))
         self.full_exchanges = 0                           # steps that needed the full-size message
+        self.host_free = bool(host_free)                  # the device-side table exchange (False: round 2's synchronous step)
+        self.sync_steps = 0                               # steps the host-free path had to repeat synchronously
         self._alloc(device if device is not None else "cpu")
         self.chunk = self._buf[self.left * 2:(self.left + self.n) * 2]
 
@@ -66,6 +74,10 @@ class ShardedReceiver(object):
         self._msg_s = t.zeros(1 + 2 * self.small_cap, dtype=t.int64, device=dev)
         self._msgs_s = [t.empty_like(self._msg_s) for _ in range(self.world)]
         self._host_tab = np.zeros(self.tab_cap, _capi.EXIT_DTYPE)
+        # host-free step: this rank's message {count, -} + small_cap entries of (pos, exit), and everybody's
+        self._amsg = t.zeros(2 * (1 + self.small_cap), dtype=t.int64, device=dev)
+        self._agath = t.zeros(self.world * 2 * (1 + self.small_cap), dtype=t.int64, device=dev)
+        self._agath_list = list(self._agath.chunk(self.world))
 
     def _exchange(self, m, cap, msg_dev, msgs_dev):
         """all_gather of [count | first min(count, cap) table entries]; returns the gathered rows (host)."""
@@ -100,9 +112,33 @@ class ShardedReceiver(object):
                 self.ctx.wait_for_stream(t.cuda.current_stream(buf.device).cuda_stream)
         lo = max(0, self.a0 - hl)
         off = (hl - (self.a0 - lo)) * 2                      # floats to skip at the stream start
+        ptr = buf.data_ptr() + off * 4
+        cap_pk = max(64, n // 2000 + 64)
+        if self.host_free:
+            cur = t.cuda.current_stream(buf.device).cuda_stream if on_gpu else 0
+            self.ctx.shard_scan_async(ptr, self.a0, self.a1, self.total, self._amsg.data_ptr(), self.small_cap,
+                                      device_in=on_gpu)
+            if world > 1:
+                if on_gpu:
+                    self.ctx.signal_stream(cur)              # the collective waits (on the device) for the table
+                dist.all_gather(self._agath_list, self._amsg, group=self.group)
+                if on_gpu:
+                    self.ctx.wait_for_stream(cur)            # ... and the resolve step for the collective
+                msgs = self._agath
+            else:
+                msgs = self._amsg
+            pk, redo = self.ctx.shard_resolve_async(msgs.data_ptr(), world, rank, self.small_cap, capacity=cap_pk)
+            if world > 1:
+                # every rank must take the same path: a capacity overflow is a rank's private matter (a table overflow is not)
+                flag = t.tensor([1 if redo else 0], dtype=t.int32, device=buf.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+                redo = bool(int(flag.item()))
+            if not redo:
+                return pk
+            self.sync_steps += 1
         L = self.ctx.lib.L
         got = C.c_uint64(0)
-        rc = L.am_shard_scan(self.ctx._h, buf.data_ptr() + off * 4, self.a0, self.a1, self.total,
+        rc = L.am_shard_scan(self.ctx._h, ptr, self.a0, self.a1, self.total,
                              _capi.AM_F_DEVICE_IN if on_gpu else 0, self._host_tab.ctypes.data, self.tab_cap,
                              C.byref(got))
         self.ctx._chk(rc)
@@ -117,4 +153,4 @@ class ShardedReceiver(object):
             cur_in = int(entry[rank])
         else:
             cur_in = 0
-        return self.ctx.shard_resolve(cur_in, capacity=max(64, n // 2000 + 64))
+        return self.ctx.shard_resolve(cur_in, capacity=cap_pk)

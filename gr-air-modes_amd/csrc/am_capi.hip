@@ -138,6 +138,8 @@ struct am_ctx {
     // time-sharded mode: the chunk whose bb/avg are resident
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
     bool shard_ready = false;
+    const uint32_t *cur0_dev = nullptr; // set around chain_finish: the scan's start position is read on the device (time shards)
+    const uint32_t *flag_src = nullptr; // ... and this device word is handed to the host with the completion ticket (pin_scalars[4])
 
     // pinned host memory the tail kernels write into directly
     am_packet *pin_packets = nullptr;
@@ -608,7 +610,8 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
                                     (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
                                     own_hi, (uint32_t *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
-                                    next_epoch(c), (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp));
+                                    next_epoch(c), (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp,
+                                    c->cur0_dev));
     const bool keep_dev = keep_bursts || c->keep_tags;       // the bursts and their tags leave the kernel
     if (keep_dev) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
@@ -649,7 +652,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                       keep_dev ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p, c->pin_packets,
                                       (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     const uint32_t seq = ++c->ticket_seq;
-    HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream));
+    HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, c->flag_src, c->flag_src ? c->pin_scalars + 4 : nullptr));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan (behind the ticket)
     c->total_pending = true;
     if (c->defer && !keep_bursts) {
@@ -886,6 +889,18 @@ int am_wait_for_stream(am_ctx *c, void *hip_stream)
     if (!c->ev_wait) HIPCHK(c, hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->ev_wait, (hipStream_t)hip_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_wait, 0));
+    return AM_OK;
+}
+
+// The other way round: another stream of the same device (NULL: the legacy default stream) waits, on the device, for what
+// the context has enqueued so far -- e.g. a collective that sends what the context's kernels are still writing.
+int am_signal_stream(am_ctx *c, void *hip_stream)
+{
+    if (!c) return AM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->ev_wait) HIPCHK(c, hipEventCreateWithFlags(&c->ev_wait, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_wait, c->stream));
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_wait, 0));
     return AM_OK;
 }
 
@@ -1315,8 +1330,12 @@ int am_shard_halo(const am_ctx *c, uint64_t *left, uint64_t *right)
     return AM_OK;
 }
 
-int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
-                  uint32_t flags, am_shard_exit *table, uint64_t cap, uint64_t *n_table)
+// am_shard_scan, or (msg_dev != null) its host-free form: everything is enqueued, the exit table goes to the DEVICE
+// message msg_dev = {count, -} + msg_cap entries, nothing is waited for (a first step without a candidate-density
+// estimate still reads the count back once).
+static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
+                           uint32_t flags, am_shard_exit *table, uint64_t cap, uint64_t *n_table, am_shard_exit *msg_dev,
+                           uint64_t msg_cap)
 {
     if (!c) return AM_EINVAL;
     if (n_table) *n_table = 0;
@@ -1380,6 +1399,22 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     const uint64_t lead = (uint64_t)(AM_BURST + 1) * S + 1;
     const uint64_t lead_end = abs_start + lead;                 // absolute, exclusive
     uint32_t n_dev = 0;
+    if (msg_dev) {
+        // host-free: the table (what fits the message) and its count go to the device message; whether the capacity
+        // this scan was launched for sufficed comes back with the resolve step's completion ticket
+        const uint32_t *Mp = c->spec_now ? c->Mdev : nullptr;
+        int rc = chain_prepare(c, M, true, Mp);
+        if (rc != AM_OK) return rc;
+        HIPCHK(c, hipMemsetAsync(msg_dev, 0, sizeof(am_shard_exit), c->stream));       // (no candidate: count 0)
+        n_dev = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(M, lead + 1), msg_cap);
+        if (n_dev)
+            HIPCHK(c, am_launch_chain_exit_table((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, n_dev,
+                                                 (uint32_t)std::min<uint64_t>(lead_end - out_abs0, 0xFFFFFFFFull),
+                                                 (uint32_t *)c->cscratch.p, out_abs0, msg_dev + 1, c->stream, Mp, msg_dev));
+        c->last_M = M;
+        c->shard_ready = true;
+        return AM_OK;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         const uint32_t *Mp = c->spec_now ? c->Mdev : nullptr;
         int rc = chain_prepare(c, M, true, Mp);
@@ -1441,6 +1476,19 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     return AM_OK;
 }
 
+int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
+                  uint32_t flags, am_shard_exit *table, uint64_t cap, uint64_t *n_table)
+{
+    return shard_scan_core(c, iq, abs_start, abs_end, total_n, flags, table, cap, n_table, nullptr, 0);
+}
+
+int am_shard_scan_async(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
+                        uint32_t flags, am_shard_exit *msg_dev, uint64_t msg_cap)
+{
+    if (!c || !msg_dev || msg_cap == 0) return AM_EINVAL;
+    return shard_scan_core(c, iq, abs_start, abs_end, total_n, flags, nullptr, 0, nullptr, msg_dev, msg_cap);
+}
+
 int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, const uint64_t *starts,
                    uint32_t nranks, uint64_t *entry)
 {
@@ -1476,6 +1524,47 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
     int rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits);
     if (rc != AM_OK) return rc;
+    c->last_tags = c->n_hits;
+    return hand_out(c, out, cap, n_out);
+}
+
+int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t world, uint32_t rank, uint64_t msg_cap,
+                           am_packet *out, uint64_t cap, uint64_t *n_out, int *redo)
+{
+    if (!c || !redo || (world && !msgs_dev) || rank >= world) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    *redo = 0;
+    if (!c->shard_ready) return fail(c, AM_EINVAL, "am_shard_scan_async has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->pending.clear();
+    c->last_tags = 0;
+    uint64_t em = 0;
+    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    uint32_t *cur0_dev = (uint32_t *)c->scalars.p + 4, *flag_dev = (uint32_t *)c->scalars.p + 5;
+    // the entry position of this chunk, composed from everybody's exit tables on the device
+    HIPCHK(c, hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev, c->stream));
+    if (c->chain_M == 0 || !flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base) {
+        // nothing to slice here; the other ranks must still learn whether a table overflowed: it did so on every rank alike
+        uint32_t f = 0;
+        HIPCHK(c, hipMemcpyAsync(&f, flag_dev, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *redo = f ? 1 : 0;
+        return AM_OK;
+    }
+    const uint32_t emax = (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
+    uint32_t fin = 0;
+    const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
+                                         ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
+    c->cur0_dev = cur0_dev;
+    c->flag_src = flag_dev;
+    int rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
+    c->cur0_dev = nullptr;
+    c->flag_src = nullptr;
+    if (rc == AM_RETRY_EXACT) { c->pending.clear(); *redo = 1; return AM_OK; }   // more candidates than the capacity the scan was launched for
+    if (rc != AM_OK) return rc;
+    if (c->pin_scalars[4]) { c->pending.clear(); *redo = 1; return AM_OK; }       // a table did not fit its message
+    c->spec_density = (c->shard_end > c->shard_start) ? (double)c->last_M / (double)(c->shard_end - c->shard_start) : 0.0;
     c->last_tags = c->n_hits;
     return hand_out(c, out, cap, n_out);
 }

@@ -138,11 +138,15 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch, uint32_t *scalars, int want_resume,
-                                 hipStream_t s, const uint32_t *Mp = nullptr);
+                                 hipStream_t s, const uint32_t *Mp = nullptr, const uint32_t *cur0_dev = nullptr);
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
-                                      hipStream_t s, const uint32_t *Mp = nullptr);
+                                      hipStream_t s, const uint32_t *Mp = nullptr, am_shard_exit *header = nullptr);
+/* device-side am_shard_entry: `world` messages of 1 + cap entries (entry 0: {count, -}); writes the array coordinate at
+ * which the scan enters chunk `rank` and sets flags[0] if some table did not fit */
+hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
+                                 uint32_t *cur0_out, uint32_t *flags, hipStream_t s);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
 /* "rx_time" stream tag (lib/preamble_impl.cc:165-170): from item `offset` on, time = (secs, frac) +

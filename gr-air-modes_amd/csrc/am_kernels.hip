@@ -1108,10 +1108,12 @@ __device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint16_t
 // unusually long head (ki >= headw): those go hop by hop in step (2).
 __global__ void __launch_bounds__(1024)
 am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
-               const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0,
-               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp)
+               const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0_host,
+               uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp,
+               const uint32_t *__restrict__ cur0_dev)
 {
     const uint32_t M = am_count(Mcap, Mp);
+    const uint32_t cur0 = cur0_dev ? *cur0_dev : cur0_host;   // (time shards: the entry position was composed on the device)
 #if defined(AM_WALK_DEBUG)
     int wdbg[5] = {0, 0, 0, 0, 0};
     long long wclk[5] = {0, 0, 0, 0, 0};
@@ -1231,9 +1233,23 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
                      const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ lastnode,
                      const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t n,
                      uint32_t lead_end, uint64_t base_abs, am_shard_exit *__restrict__ table,
-                     const uint32_t *__restrict__ Mp)
+                     const uint32_t *__restrict__ Mp, am_shard_exit *__restrict__ header)
 {
     const uint32_t M = am_count(Mcap, Mp);
+    // header (device-side exchange of the tables): pos = number of entries = up to and including the first candidate at or
+    // past lead_end, all min(n, M) of them if there is none.  Positions ascend: exactly one thread qualifies.
+    if (header) {
+        const uint32_t nr = M < n ? M : n;
+        if (nr == 0) {
+            if (threadIdx.x == 0) { header->pos = 0; header->exit = 0; }
+        } else
+            for (uint32_t i = threadIdx.x; i < nr; i += blockDim.x) {
+                const bool term = pos[i] >= lead_end && (i == 0 || pos[i - 1u] < lead_end);
+                const bool tail = i == nr - 1u && pos[i] < lead_end;
+                // (tail with candidates left beyond the table's n entries: the table does not fit -- count n + 1 says so)
+                if (term || tail) { header->pos = term ? i + 1u : (M > n ? n + 1u : nr); header->exit = 0; }
+            }
+    }
     HIP_DYNAMIC_SHARED(uint16_t, lnk);
     am_cblk_load_links(lnk, headlink, nblk * headw);
     __syncthreads();
@@ -1469,7 +1485,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch,
-                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp)
+                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const uint32_t *cur0_dev)
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -1479,7 +1495,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     const size_t lds = am_chain_walk_lds_bytes(L.nblk, L.headw);
     if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;   // (more than ~75 000 blocks of 2048 candidates in one scan)
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
-                       L.headw, cur0, scratch + L.off_entry, scalars, Mp);
+                       L.headw, cur0, scratch + L.off_entry, scalars, Mp, cur0_dev);
     am_emit_args ea;
     ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.emit_max = emit_max; ea.own_lo = own_lo;
     ea.own_hi = own_hi; ea.emit_idx = emit_idx; ea.n_out = n_out; ea.slots = slots; ea.epoch = epoch; ea.scalars = scalars;
@@ -1492,7 +1508,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
 // exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
-                                      hipStream_t s, const uint32_t *Mp)
+                                      hipStream_t s, const uint32_t *Mp, am_shard_exit *header)
 {
     if (n == 0 || M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -1502,7 +1518,42 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
         return rc;
     const size_t lds = ((size_t)L.nblk * L.headw + 8) * sizeof(uint16_t);
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
-                       reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp);
+                       reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp, header);
+    return hipGetLastError();
+}
+
+// Time shards, device-side composition of the exit tables (am_shard_entry on the host does the same): msgs = `world`
+// messages of 1 + cap entries each, entry 0 = header {count, -}, then the table.  The scan starts at sample 0; chunk r is
+// entered at `cur`; the first candidate of chunk r at or after cur says where the scan leaves the chunk.  Writes the
+// array coordinate at which the scan enters chunk `rank` (cur0_out) and flags[0] |= 1 if some table did not fit its
+// message (the caller then repeats the step with full-size tables).
+__global__ void am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
+                                 uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t cur = 0;
+    uint32_t bad = 0;
+    for (uint32_t r = 0; r < rank; ++r) {
+        const am_shard_exit *m = msgs + (size_t)r * (cap + 1u);
+        const uint64_t n = m[0].pos;
+        if (n > cap) { bad = 1; break; }
+        const am_shard_exit *t = m + 1;
+        uint64_t i = 0;
+        while (i < n && t[i].pos < cur) ++i;
+        if (i < n) cur = t[i].exit > cur ? t[i].exit : cur;  // no candidate left: the scan passes through
+    }
+    for (uint32_t r = rank; r < world && !bad; ++r)           // (every rank must take the same decision)
+        if (msgs[(size_t)r * (cap + 1u)].pos > cap) bad = 1;
+    uint64_t rel = cur > base_abs ? cur - base_abs : 0;
+    if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
+    *cur0_out = (uint32_t)rel;
+    if (bad) flags[0] = 1u;
+}
+
+hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
+                                 uint32_t *cur0_out, uint32_t *flags, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(1), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags);
     return hipGetLastError();
 }
 

@@ -318,3 +318,48 @@ def test_production_stages_full_size(lib, rate, n, lam, fe):
 def test_production_stages_chunked_and_no_pmf(lib):
     assert pc.check_production_stages(lib, 64e6, 9_000_000, 20000.0, 11, chunks=[2_000_001, 5_500_000], want_fe=3) > 0
     assert pc.check_production_stages(lib, 64e6, 6_000_000, 20000.0, 12, pmf=False, want_fe=3) > 0
+
+
+def test_host_free_sharded_step_on_device(lib):
+    """The host-free time-shard step (am_shard_scan_async -> device-side entry composition -> am_shard_resolve_async) on the
+    device: one chunk = the whole stream (world 1: no collective), three steps, none falls back to the synchronous path, and
+    the device-side composition over several chunks' tables (all on one GPU) gives the single-stream packets."""
+    import torch
+    from air_modes.sharded import ShardedReceiver
+    rate, n = 64e6, 8_000_000
+    iq, _ = synth.synth_capture(rate, n, 20000.0, 4242)
+    want = oracle.demod(iq, rate)
+    ctx = _capi.Context(rate, 7.0, True, lib=lib)
+    rx = ShardedReceiver(ctx, 0, 1, n, device="cuda:0")
+    rx.chunk.copy_(torch.from_numpy(iq.view(np.float32)))
+    torch.cuda.synchronize()
+    for _ in range(3):
+        assert np.array_equal(rx.step(), want)
+    assert rx.sync_steps == 0
+    ctx.close()
+    # four chunks on one GPU, tables gathered by hand: what the all_gather delivers
+    G, cap = 4, 512
+    ctxs = [_capi.Context(rate, 7.0, True, lib=lib) for _ in range(G)]
+    hl, hr = ctxs[0].shard_halo()
+    dev = torch.device("cuda:0")
+    msgs = torch.zeros(G * 2 * (1 + cap), dtype=torch.int64, device=dev)
+    bufs = []
+    m = n // G
+    got = None
+    for rep in range(2):               # (the second pass launches for a capacity: no read-back at all)
+        for g in range(G):
+            a, b = g * m, (g + 1) * m
+            lo, hi = max(0, a - hl), min(n, b + hr)
+            t = torch.from_numpy(iq[lo:hi].view(np.float32)).to(dev)
+            bufs.append(t)
+            ctxs[g].shard_scan_async(t.data_ptr(), a, b, n, msgs[g * 2 * (1 + cap):].data_ptr(), cap)
+        torch.cuda.synchronize()
+        parts = []
+        for g in range(G):
+            pk, redo = ctxs[g].shard_resolve_async(msgs.data_ptr(), G, g, cap)
+            assert not redo
+            parts.append(pk)
+        got = np.concatenate(parts)
+        assert np.array_equal(got, want)
+    for c in ctxs:
+        c.close()

@@ -16,7 +16,7 @@ RATE = 20e6
 N_PER_RANK = 150000
 
 
-def _worker(rank, world, port, ret, small_table=512):
+def _worker(rank, world, port, ret, small_table=512, host_free=True):
     for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -30,29 +30,41 @@ def _worker(rank, world, port, ret, small_table=512):
         own = torch.from_numpy(iq[rank * N_PER_RANK:(rank + 1) * N_PER_RANK].copy().view(np.float32))
         lib = _capi.Library(conftest.EMU_LIB)
         ctx = _capi.Context(RATE, 7.0, True, lib=lib)
-        rx = ShardedReceiver(ctx, rank, world, N_PER_RANK, small_table=small_table)
+        rx = ShardedReceiver(ctx, rank, world, N_PER_RANK, small_table=small_table, host_free=host_free)
         rx.chunk.copy_(own)
         pk = rx.step()
         pk2 = rx.step()                        # a second step reuses every buffer
         assert np.array_equal(pk, pk2)
         ret[rank] = pk.tobytes()
+        pk3 = rx.step()
+        assert np.array_equal(pk, pk3)
         ret["full_%d" % rank] = rx.full_exchanges
+        ret["sync_%d" % rank] = rx.sync_steps
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,small_table", [(2, 512), (3, 512), (2, 1)])
-def test_time_sharded_matches_single_stream(emu_lib, oracle_mod, world, small_table):
-    """small_table=1: the short exit-table message overflows, so the full-size exchange follows."""
+@pytest.mark.parametrize("world,small_table,host_free", [(2, 512, True), (3, 512, True), (4, 512, True), (2, 1, True),
+                                                         (2, 512, False), (2, 1, False)])
+def test_time_sharded_matches_single_stream(emu_lib, oracle_mod, world, small_table, host_free):
+    """host_free: the exit tables are exchanged and composed on the device side, one completion wait per step (three steps:
+    none of them may fall back to the synchronous path).  small_table=1: the table does not fit the short message -- the
+    host-free step notices on every rank and repeats itself synchronously, where the full-size exchange follows."""
     import synth
     from air_modes import _capi
-    port = 29511 + world + (7 if small_table == 1 else 0)
+    port = 29511 + world + (7 if small_table == 1 else 0) + (20 if not host_free else 0)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, port, ret, small_table), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, ret, small_table, host_free), nprocs=world, join=True)
     got = np.concatenate([np.frombuffer(ret[r], _capi.PACKET_DTYPE) for r in range(world)])
     full = [ret["full_%d" % r] for r in range(world)]
-    assert len(set(full)) == 1 and (full[0] == 2) == (small_table == 1), full
+    syncs = [ret["sync_%d" % r] for r in range(world)]
+    assert len(set(full)) == 1 and len(set(syncs)) == 1, (full, syncs)
+    if host_free:
+        assert syncs[0] == (3 if small_table == 1 else 0), syncs
+        assert full[0] == (3 if small_table == 1 else 0), full
+    else:
+        assert syncs[0] == 0 and (full[0] == 3) == (small_table == 1), (full, syncs)
     iq, _ = synth.synth_capture(RATE, world * N_PER_RANK, 8000.0, seed=314)
     want = oracle_mod.demod(iq, RATE)
     assert len(want) > 20
