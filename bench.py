@@ -234,15 +234,15 @@ def main():
             up = _c.Uploader(n, nslots=2, lib=lib)
             hb = [b.view(np.float32) for b in host_batches]
             ksteps = 4
-            up.buffer(0)[:2 * n] = hb[0]
+            for k in range(2):                                   # (the source has written its samples into the pinned buffers:
+                up.buffer(k)[:2 * n] = hb[k % len(hb)]            #  a file reader does readinto() there, modes_rx.py)
             up.start(0, n)
             sync()
             th = time.perf_counter()
             for k in range(ksteps):
                 ptr = up.wait(k % 2)
                 if k + 1 < ksteps:
-                    up.buffer((k + 1) % 2)[:2 * n] = hb[(k + 1) % len(hb)]   # (the source fills the other pinned buffer)
-                    up.start((k + 1) % 2, n)
+                    up.start((k + 1) % 2, n)                      # the next batch crosses PCIe while this one is scanned
                 pkh = ctx.process_iq_device(ptr, n, flush=True)
             sync()
             dth = (time.perf_counter() - th) / ksteps
@@ -255,8 +255,8 @@ def main():
             sync()
             dtp = (time.perf_counter() - tp) / 2
             extra["host_input"] = {"value": n / dth, "unit": "samples/s", "ms_per_step": dth * 1e3,
-                                   "what": "host source -> pinned buffer -> device -> packets, two buffers in flight (am_uploader), %d steps; "
-                                           "includes the source filling the pinned buffer (a 512 MB host copy per step)" % ksteps,
+                                   "what": "pinned host buffer -> device -> packets, two buffers in flight (am_uploader): the PCIe copy of "
+                                           "batch k+1 overlaps the scan of batch k, %d steps" % ksteps,
                                    "packets_last_step": int(len(pkh)),
                                    "pageable": {"value": n / dtp, "ms_per_step": dtp * 1e3,
                                                 "what": "am_process_iq on a pageable host pointer (one synchronous copy inside the call)"}}
