@@ -120,6 +120,7 @@ struct am_ctx {
         jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y, wgmax;
     uint32_t fe3_vspan = 0, fe3_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
+    uint32_t fe_lag = 0, fe_wbits = 32;  // ... its bitmap: positions behind (lag) and per word
     DevBuf lb_seg, lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
 
@@ -397,8 +398,8 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             ENSURE(c, c->energy, (size_t)(ebound + 2) * (mode == 3 ? 1 : sizeof(double)));
             if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
                 HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p,
-                                                nullptr, nseg, M, c->spc, am_fe3_lag(),
-                                                (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
+                                                nullptr, nseg, M, c->spc, c->fe_lag,
+                                                (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp, c->fe_wbits));
             else
             HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
                                            c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
@@ -466,6 +467,42 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         return run_candidates(c, bb, avg, j0, j1, M_out);
     }
     c->scan_src = src; c->scan_src_abs0 = src_abs0; c->scan_src_abs1 = src_abs1;
+    if (!avg && c->allow_fe3 && am_fe4_supported(c->spc)) {
+        // streaming kernel for the rates below 64 Msps (several chips per lane): same outputs as am_k_fe3 below
+        const unsigned ns = am_fe4_steps((long long)out_n, c->spc);
+        const unsigned nwv = 2;
+        ENSURE(c, c->bits, ((size_t)ns * 48 * nwv + 64) * sizeof(uint32_t));
+        ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
+        ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
+        ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
+        ENSURE(c, c->wgmax, ((size_t)ns + 8) * sizeof(float));
+        unsigned nsteps = 0, spw = 1;
+        if (c->poison) {
+            HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->avg.p, 0xFF, out_n * sizeof(float), c->stream));
+        }
+        HIPCHK(c, am_launch_fe4(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
+                                (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
+                                (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
+                                (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream));
+        c->fe3_vspan = spw * am_fe4_tile(c->spc);
+        c->fe3_nv = (nsteps + spw - 1) / spw;
+        c->fe_lag = am_fe4_lag(c->spc);
+        c->fe_wbits = am_fe4_unit(c->spc);
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        c->dom_timed = true;
+        c->bb_sparse = true;
+        c->last_fe = 3;
+        const uint64_t endj3 = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
+        uint32_t cap3 = 0;
+        if (may_speculate && c->allow_spec && c->spec_density > 0.0) {
+            const double npos = (double)(j1 - j0);
+            const double want = c->spec_density * npos * 1.25 + c->spec_floor;
+            cap3 = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
+        }
+        return run_refine(c, bb, (const float *)c->avg.p, nsteps * nwv, 0, 3, M_out,
+                          (uint32_t)std::min<uint64_t>(endj3, 0xFFFFFFFFull), cap3);
+    }
     if (!avg && c->allow_fe3 && am_fe3_supported(c->spc)) {
         // streaming kernel: candidate bitmap + per-(step, wave) counts; bb and the reference level only around candidates
         const unsigned ns = am_fe3_steps((long long)out_n);
@@ -487,6 +524,8 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                                 (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream));
         c->fe3_vspan = spw * am_fe3_tile();
         c->fe3_nv = (nsteps + spw - 1) / spw;
+        c->fe_lag = am_fe3_lag();
+        c->fe_wbits = 32;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         c->bb_sparse = true;

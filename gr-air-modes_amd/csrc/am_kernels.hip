@@ -475,13 +475,14 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 
 // Flat candidate positions from the streaming front end's bitmap (am_fe3.hip): one wave per (step, wave) segment,
 // four segments per workgroup.
-// Word w, bit b = array coordinate 32*w + b - lag.  dcount needs the distance to the candidate before, capped
-// at spc + 1 <= 64: the two words in front of a word are all the history it can need.
+// Word w, bit b = array coordinate wbits*w + b - lag (wbits = 32 at 64 Msps, the unit length of am_k_fe4 otherwise).  dcount
+// needs the distance to the candidate before, capped at spc + 1 <= wbits + 1: the two words in front of a word are all the
+// history it can need.
 __global__ void __launch_bounds__(4 * AM_WAVE)
 am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ seg_cnt,
                  const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t nseg,
                  uint32_t Mcap, int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
-                 const uint32_t *__restrict__ Mp)
+                 const uint32_t *__restrict__ Mp, uint32_t wbits)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t seg = blockIdx.x * 4u + threadIdx.x / AM_WAVE;
@@ -510,18 +511,18 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
         if (lane >= d) incl += up;
     }
     uint32_t g = off + incl - c;
-    const unsigned long long hist = ((unsigned long long)p1 << 32) | p2;     // the 64 positions before this word
     int prev_b = -1;
     while (word) {
         if (g >= M) break;
         const int b = __ffsll((long long)word) - 1;
-        uint32_t gap;                                        // distance to the candidate before (hist bit 63 = the position just before bit 0)
+        uint32_t gap;                                        // distance to the candidate before: this word, or the two words (wbits positions each) before it
         if (prev_b >= 0) gap = (uint32_t)(b - prev_b);
-        else if (hist) gap = (uint32_t)b + 1u + (uint32_t)__clzll((long long)hist);
+        else if (p1) gap = (uint32_t)b + wbits - (uint32_t)(31 - __clz((int)p1));
+        else if (p2) gap = (uint32_t)b + 2u * wbits - (uint32_t)(31 - __clz((int)p2));
         else gap = 0xFFFFu;
         uint32_t d = (uint32_t)spc + 1u;
         d = gap < d ? gap : d;
-        pos[g] = (uint32_t)(w * 32u) + (uint32_t)b - lag;
+        pos[g] = (uint32_t)w * wbits + (uint32_t)b - lag;
         dcount[g] = d;
         ++g;
         prev_b = b;
@@ -531,12 +532,12 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
 
 hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
                                  const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
-                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp)
+                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp, uint32_t wbits)
 {
     if (M == 0 || nseg == 0) return hipSuccess;
-    if (spc + 1 > 64) return hipErrorInvalidValue;
+    if (wbits == 0 || wbits > 32 || (uint32_t)spc + 1u > 2u * wbits) return hipErrorInvalidValue;
     hipLaunchKernelGGL(am_k_gather_bits, dim3((nseg + 3u) / 4u), dim3(4 * AM_WAVE), 0, s, bits, seg_cnt, off_local, blk_base, nseg, M, spc,
-                       lag, pos, dcount, Mp);
+                       lag, pos, dcount, Mp, wbits);
     return hipGetLastError();
 }
 
@@ -1895,7 +1896,7 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
                       am_packet *__restrict__ packets, const uint32_t *__restrict__ scalars,
                       uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
 {
-    static_assert(SPC % 2 == 0 && SPC >= 2, "pairs of samples per 16-byte load");
+    static_assert(SPC == 1 || SPC % 2 == 0, "pairs of samples per 16-byte load (1 sample per chip: no filter, the launcher passes use_pmf = 0)");
     constexpr int HEAD = 128;                                 // chips of a short packet: 16 + 2 * 56
     __shared__ float sb[AM_BURST];
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1);
@@ -1972,12 +1973,25 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
                                       const uint32_t *scalars, uint32_t *host_out, hipStream_t s, const uint32_t *Mp)
 {
     if (n_max == 0) return hipSuccess;
-    if (spc != 32) return hipErrorInvalidValue;              // (the rate the streaming front end serves)
     const uint32_t resident = (uint32_t)am_device_cus() * 5u;   // five workgroups of 256 threads per CU (registers)
     const uint32_t grid = n_max < resident ? n_max : resident;
-    hipLaunchKernelGGL((am_k_extract_slice_iq<32>), dim3(grid), dim3(256), 0, s, iq, src_abs0, src_abs1, use_pmf, s1,
-                       inavg, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow,
-                       packets, scalars, host_out, Mp);
+#define AM_XS_IQ(S)                                                                                                       \
+    hipLaunchKernelGGL((am_k_extract_slice_iq<S>), dim3(grid), dim3(256), 0, s, iq, src_abs0, src_abs1, use_pmf, s1,     \
+                       inavg, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow,          \
+                       packets, scalars, host_out, Mp)
+    if (spc == 1) use_pmf = 0;                               // (a one-sample window is the sample itself: s1 = 1)
+    switch (spc) {                                           // (the rates the streaming front ends serve)
+    case 32: AM_XS_IQ(32); break;
+    case 20: AM_XS_IQ(20); break;
+    case 16: AM_XS_IQ(16); break;
+    case 10: AM_XS_IQ(10); break;
+    case 8: AM_XS_IQ(8); break;
+    case 4: AM_XS_IQ(4); break;
+    case 2: AM_XS_IQ(2); break;
+    case 1: AM_XS_IQ(1); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef AM_XS_IQ
     return hipGetLastError();
 }
 

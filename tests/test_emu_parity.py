@@ -238,9 +238,11 @@ def test_streaming_and_tile_front_ends_agree(emu_lib, monkeypatch):
     assert pc.check_front_ends_agree(emu_lib, 64e6, iq[:400000], monkeypatch, thr=5.0, pmf=False) > 3
     bad = pc.nonfinite_stream(64e6, 400000)
     pc.check_front_ends_agree(emu_lib, 64e6, bad, monkeypatch)
-    # a rate without the streaming kernel: the tile kernel with non-finite samples in interior tiles
-    bad20 = pc.nonfinite_stream(20e6, 150000)
-    pc.check_front_ends_agree(emu_lib, 20e6, bad20, monkeypatch, expect_streaming=False)
+    # the other rates: the several-chips-per-lane streaming kernel (am_k_fe4) and the tile kernel, non-finite samples in
+    # interior steps / tiles; 10 Msps (5 samples per chip) has no streaming kernel
+    for rate in (20e6, 4e6, 2e6):
+        pc.check_front_ends_agree(emu_lib, rate, pc.nonfinite_stream(rate, 150000), monkeypatch)
+    pc.check_front_ends_agree(emu_lib, 10e6, pc.nonfinite_stream(10e6, 150000), monkeypatch, expect_streaming=False)
 
 
 def test_streaming_front_end_unaligned_and_short_inputs(emu_lib, monkeypatch):
@@ -299,7 +301,7 @@ def test_batches_in_flight_single_host_thread(emu_lib):
                                                     (64e6, 900000, 20000.0, True, [250001, 600000]),
                                                     (20e6, 500000, 5000.0, True, None), (2e6, 200000, 2000.0, True, None)])
 def test_production_stages(emu_lib, rate, n, lam, pmf, chunks):
-    """Candidate records, bursts and tags of the kernels am_process_iq runs (streaming front end at 64 Msps, tile kernel
-    elsewhere) against the oracle and, where built, the reference's own C++."""
+    """Candidate records, bursts and tags of the kernels am_process_iq runs (the streaming front ends: am_k_fe3 at 64 Msps,
+    am_k_fe4 at 20 and 2 Msps) against the oracle and, where built, the reference's own C++."""
     assert pc.check_production_stages(emu_lib, rate, n, lam, 77, pmf=pmf, with_ref=True, chunks=chunks,
-                                      want_fe=3 if rate == 64e6 else 2) > 0
+                                      want_fe=3) > 0

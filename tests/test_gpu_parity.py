@@ -275,8 +275,9 @@ def test_streaming_and_tile_front_ends_agree(klib, monkeypatch):
     assert pc.check_front_ends_agree(lib, 64e6, iq[:3000000], monkeypatch, thr=5.0, pmf=False) > 20
     bad = pc.nonfinite_stream(64e6, 4000000)
     pc.check_front_ends_agree(lib, 64e6, bad, monkeypatch)
-    for rate in (20e6, 16e6, 4e6):
-        pc.check_front_ends_agree(lib, rate, pc.nonfinite_stream(rate, 1500000), monkeypatch, expect_streaming=False)
+    for rate in (40e6, 20e6, 16e6, 8e6, 4e6, 2e6):            # am_k_fe4 (several chips per lane) and the tile kernel
+        pc.check_front_ends_agree(lib, rate, pc.nonfinite_stream(rate, 1500000), monkeypatch)
+    pc.check_front_ends_agree(lib, 10e6, pc.nonfinite_stream(10e6, 1500000), monkeypatch, expect_streaming=False)
 
 
 def test_streaming_front_end_unaligned_and_short_inputs(klib, monkeypatch):
@@ -307,7 +308,8 @@ def test_batches_in_flight_single_host_thread(lib):
 
 
 @pytest.mark.parametrize("rate,n,lam,fe", [(64e6, 64_000_000, 20000.0, 3), (64e6, 16_000_000, 2000.0, 3),
-                                            (20e6, 20_000_000, 5000.0, 2), (2e6, 20_000_000, 500.0, 2)])
+                                            (20e6, 20_000_000, 5000.0, 3), (2e6, 20_000_000, 500.0, 3),
+                                            (4e6, 8_000_000, 1000.0, 3), (10e6, 4_000_000, 2000.0, 2)])
 def test_production_stages_full_size(lib, rate, n, lam, fe):
     """stage-level parity of the kernels that actually run -- at the BASELINE sizes the
     record of every first-stage candidate (bitmap position, refined position, quiet-zone outcome, reference level), the
@@ -318,6 +320,9 @@ def test_production_stages_full_size(lib, rate, n, lam, fe):
 def test_production_stages_chunked_and_no_pmf(lib):
     assert pc.check_production_stages(lib, 64e6, 9_000_000, 20000.0, 11, chunks=[2_000_001, 5_500_000], want_fe=3) > 0
     assert pc.check_production_stages(lib, 64e6, 6_000_000, 20000.0, 12, pmf=False, want_fe=3) > 0
+    for rate, n in ((20e6, 5_000_000), (4e6, 2_000_000), (2e6, 2_000_000)):
+        assert pc.check_production_stages(lib, rate, n, 3000.0, 13, chunks=[n // 3 + 1, n // 2], want_fe=3) > 0
+        assert pc.check_production_stages(lib, rate, n // 2, 3000.0, 14, pmf=False, want_fe=3) > 0
 
 
 def test_host_free_sharded_step_on_device(lib):
