@@ -348,7 +348,8 @@ def main():
         fe_avg_ms = float(np.mean(fe_ms)) if fe_ms else 0.0
         achieved = 8.0 * n / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
         fe_kind = ctx.last_frontend()
-        kernel_name = {3: "am_k_fe3 (streaming fused |iq|^2 + PMF + reference level + preamble detection, sparse outputs)",
+        kernel_name = {3: ("am_k_fe3" if spc == 32 else "am_k_fe4<%d,G>" % spc) +
+                          " (streaming fused |iq|^2 + PMF + reference level + preamble detection, sparse outputs)",
                        2: "am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc}.get(fe_kind, "am_k_frontend")
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         traffic, traffic_src = None, None

@@ -695,7 +695,11 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     a.test_hi = clampi(fe3_floor_div(jhi + lag, FE3_T));
     // persistent workgroups: as many as are resident at once, each with a contiguous run of steps; short inputs
     // get at least 4 steps per workgroup (the ring rebuild costs one)
-    const unsigned resident = (unsigned)fe3_wgs_for_device();
+    unsigned resident = (unsigned)fe3_wgs_for_device();
+#if defined(AM_TEST_KNOBS)
+    if (const char *e = getenv("AIRMODES_FE3_WGS_PER_CU"))            // tuning: leave room on every CU for another batch's tail
+        if (atoi(e) > 0) resident = (unsigned)(atoi(e) * am_device_cus());
+#endif
     unsigned spw = (a.nsteps + resident - 1) / resident;
     if (spw < 4) spw = 4;
 #ifdef FE3_FORCE_SPW

@@ -600,22 +600,33 @@ template <int SPC, int G>
 static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t s)
 {
     using C = fe4_cfg<SPC, G>;
-    const unsigned resident = (unsigned)(FE4_WG_PER_CU * am_device_cus());
+    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    // workgroups per CU: what registers and LDS of THIS instantiation allow (6 to 8), asked of the runtime once per device
+    static std::atomic<int> per_cu[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int wpc = (dev >= 0 && dev < 64) ? per_cu[dev].load(std::memory_order_acquire) : 0;
+    if (wpc <= 0) {
+        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe4<SPC, G>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (rc != hipSuccess) return rc;
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(&am_k_fe4<SPC, G>), FE4_NT, lds) != hipSuccess ||
+            nb <= 0)
+            nb = FE4_WG_PER_CU;
+        wpc = nb > 8 ? 8 : nb;
+        if (dev >= 0 && dev < 64) per_cu[dev].store(wpc, std::memory_order_release);
+    }
+#if defined(AM_TEST_KNOBS)
+    if (const char *e = getenv("AIRMODES_FE4_WGS_PER_CU"))
+        if (atoi(e) > 0) wpc = atoi(e);
+#endif
+    const unsigned resident = (unsigned)(wpc * am_device_cus());
     unsigned spw = (a.nsteps + resident - 1) / resident;
     if (spw < 4) spw = 4;
     a.steps_per_wg = spw;
     *steps_per_wg = spw;
     const unsigned grid = (a.nsteps + spw - 1) / spw;
-    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    static std::atomic<bool> attr_done[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
-        hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&am_k_fe4<SPC, G>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (rc != hipSuccess) return rc;
-        if (dev >= 0 && dev < 64) attr_done[dev].store(true, std::memory_order_release);
-    }
     hipLaunchKernelGGL((am_k_fe4<SPC, G>), dim3(grid), dim3(FE4_NT), lds, s, a);
     return hipGetLastError();
 }

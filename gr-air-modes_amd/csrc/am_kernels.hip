@@ -1914,7 +1914,8 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     const bool pmf = use_pmf != 0;
     const bool wide = (reinterpret_cast<uintptr_t>(iq) & 15u) == 0;
     // (Giving every XCD one contiguous eighth of the hits, so that the overlapping windows of neighbouring hits meet
-    // in one L2, changed nothing: 56.3 against 56.7 us.)
+    // in one L2, changed nothing: 56.3 against 56.7 us.  Ten workgroups of two waves per CU instead of five of four --
+    // twice as many hits in flight, the second 112 chips by the same threads: 62.8 us.)
     for (uint32_t i = blockIdx.x; i < nhit; i += gridDim.x) {                 // (uniform)
         const uint32_t g = emit_idx[i];
         const uint32_t e = eo[g];

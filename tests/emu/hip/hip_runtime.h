@@ -133,6 +133,7 @@ inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }     // launch
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((grid), (block), (shmem), [&]() { kernel(__VA_ARGS__); })
