@@ -42,6 +42,11 @@ for p in (os.path.join(ROOT, "gr-air-modes_amd"), os.path.join(ROOT, "oracle"), 
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# One hardware queue per stream: the runtime multiplexes streams onto 4 queues by default, and two of am_pipe's three
+# contexts then share one and serialise (profiles/r3_final/README.md: 215 -> 240 GS/s with three batches in flight).
+# A documented runtime setting, read when HIP initialises (an application that runs am_pipe sets it too).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (before the HIP library: one HIP runtime per process)
 import torch.distributed as dist  # noqa: E402

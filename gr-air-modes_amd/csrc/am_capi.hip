@@ -120,7 +120,7 @@ struct am_ctx {
         jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y, wgmax;
     uint32_t fe3_vspan = 0, fe3_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
-    uint32_t fe_lag = 0, fe_wbits = 32;  // ... its bitmap: positions behind (lag) and per word
+    uint32_t fe_lag = 0, fe_wbits = 32, fe_segw = 48;  // ... its bitmap: positions behind (lag), per word, words per segment
     DevBuf lb_seg, lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
 
@@ -399,7 +399,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
                 HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p,
                                                 nullptr, nseg, M, c->spc, c->fe_lag,
-                                                (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp, c->fe_wbits));
+                                                (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp, c->fe_wbits, c->fe_segw));
             else
             HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
                                            c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
@@ -471,7 +471,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         // streaming kernel for the rates below 64 Msps (several chips per lane): same outputs as am_k_fe3 below
         const unsigned ns = am_fe4_steps((long long)out_n, c->spc);
         const unsigned nwv = 2;
-        ENSURE(c, c->bits, ((size_t)ns * 48 * nwv + 64) * sizeof(uint32_t));
+        ENSURE(c, c->bits, ((size_t)ns * am_fe4_words(c->spc) * nwv + 64) * sizeof(uint32_t));
         ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
         ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
@@ -489,6 +489,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         c->fe3_nv = (nsteps + spw - 1) / spw;
         c->fe_lag = am_fe4_lag(c->spc);
         c->fe_wbits = am_fe4_unit(c->spc);
+        c->fe_segw = am_fe4_words(c->spc);
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         c->bb_sparse = true;
@@ -526,6 +527,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         c->fe3_nv = (nsteps + spw - 1) / spw;
         c->fe_lag = am_fe3_lag();
         c->fe_wbits = 32;
+        c->fe_segw = 48;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         c->bb_sparse = true;

@@ -3,7 +3,7 @@
 // am_k_fe3 gives a lane one 32-sample chip.  At 20 Msps a chip has 10 samples, at 4 Msps 2, at 2 Msps 1: a lane takes a UNIT
 // of G consecutive chips instead (R = G * spc samples: 30 at 20 Msps, 32 at 4 Msps, 24 at 2 Msps), a 48-chip block is 48 / G lanes, and
 // everything else keeps am_k_fe3's shape -- persistent workgroups of two waves walking a contiguous segment in steps of
-// 96 units, |.|^2 staged straight into LDS ring rows, phase A (pulse-matched filter, chip totals, sequential in-block
+// 96 units (128 where 48 / G divides 64: then every lane of a wave owns a unit, 20 and 2 Msps), |.|^2 staged straight into LDS ring rows, phase A (pulse-matched filter, chip totals, sequential in-block
 // scans) FE4 lag units ahead of phase B (reference level + first-stage test), a candidate bitmap (R bits per unit) and
 // sparse bb / reference-level runs around candidates as the only outputs.  What changes with G > 1:
 //   * the in-chip prefix / suffix chains restart at every chip of the unit; the chip before a unit's first chip belongs
@@ -31,8 +31,6 @@
 #include "am_fe_cmpx.h"
 
 #define FE4_NW 2                          /* waves per workgroup                                         */
-#define FE4_LU AM_CHIPS_AVG               /* lanes of a wave that own a unit (48: a whole number of blocks for every G | 48) */
-#define FE4_US (FE4_LU * FE4_NW)          /* units per step                                              */
 #define FE4_NT (AM_WAVE * FE4_NW)
 #ifndef FE4_WG_PER_CU
 #define FE4_WG_PER_CU 6
@@ -46,8 +44,8 @@ struct am_fe4_args {
     float *bb_sparse;                     // bb runs around candidates (array coordinates)
     float *avg_sparse;                    // reference-level runs around candidates
     uint32_t j0, j1;                      // positions whose preamble test is wanted
-    uint32_t *bits;                       // [nsteps * 96] candidate words: bit b of word w = position w*R + b - lag
-    uint32_t *seg_cnt;                    // [nsteps * 2] candidates per (step, wave); wave w = words 48w .. 48w+47
+    uint32_t *bits;                       // [nsteps * US] candidate words: bit b of word w = position w*R + b - lag
+    uint32_t *seg_cnt;                    // [nsteps * 2] candidates per (step, wave); wave w = words LU w .. LU w + LU - 1
     float *wg_max;                        // [grid] largest bb a workgroup formed (+inf if one was not finite)
     unsigned nsteps, steps_per_wg;
     int raw_lo, raw_hi, test_lo, test_hi; // steps loaded without guards / tested without a range mask
@@ -62,16 +60,21 @@ struct fe4_cfg {
     // lanes read consecutive rows: a stride of 32 floats would put every lane on the same banks)
     static constexpr int RS = ((R + 2) % 32 == 0) ? R + 4 : R + 2;
     static constexpr int LPB = AM_CHIPS_AVG / G;                       // lanes (units) per 48-chip block
+    // lanes of a wave that own a unit: a whole number of blocks -- all 64 where 48 / G divides 64 (G = 3, 24: the 20 Msps and
+    // 2 Msps kernels), 48 otherwise
+    static constexpr int LU = (AM_WAVE % LPB == 0) ? AM_WAVE : AM_CHIPS_AVG;
+    static constexpr int US = LU * FE4_NW;                             // units per step
+    static constexpr unsigned long long LUMASK = (LU == 64) ? ~0ull : ((1ull << (LU & 63)) - 1ull);
     static constexpr int LAGU = 1 + 8 / G;                             // units phase B runs behind phase A
     static constexpr int NBU = (G - 1 + 16) / G;                       // units of bb kept after a candidate's unit
-    static constexpr int CRU = FE4_US + LAGU + LPB + 1;                // ring capacity in units
-    static constexpr int T = FE4_US * R;                               // samples per step
+    static constexpr int CRU = US + LAGU + LPB + 1;                // ring capacity in units
+    static constexpr int T = US * R;                               // samples per step
     static constexpr int PIECES = T / 2;                               // 16-byte pieces (2 samples) per step
     static constexpr int NLD = (PIECES + FE4_NT - 1) / FE4_NT;         // loads per thread and step
     static constexpr int LPR = R / 2;                                  // lanes that move one row (8 bytes each)
     static constexpr int RPI = AM_WAVE / LPR;                          // rows per wave instruction
     static_assert(AM_CHIPS_AVG % G == 0 && R % 2 == 0 && R <= 32 && RS % 2 == 0, "unit shape");
-    static constexpr int LDS_FLOATS = CRU * RS + FE4_NW * 4 * RS + 3 * CRU + 2 * SPC + (FE4_NW - 1) * SPC + 2 + FE4_NW * 64 + 4;
+    static constexpr int LDS_FLOATS = CRU * RS + FE4_NW * 4 * RS + 3 * CRU + 2 * SPC + (FE4_NW - 1) * SPC + 2 + FE4_NW * 64 + 4 + 2 * FE4_NW;
 };
 
 template <int SPC, int G>
@@ -85,6 +88,7 @@ struct fe4_smem {
     uint32_t *CARRY;          // [2] units at the start of the next step whose bb must be written (by step parity)
     uint32_t *TAB;            // [NW][64] lane of the r-th unit whose bb / reference level is written
     float *WMX;               // [NW] the waves' largest samples at the end
+    uint32_t *WOV;            // [2][NW] units after a wave's last whose bb must be written (by step parity; LU = 64 only)
 };
 
 template <int SPC, int G>
@@ -102,6 +106,7 @@ __device__ __forceinline__ fe4_smem<SPC, G> fe4_smem_at(float *base)
     L.CARRY = reinterpret_cast<uint32_t *>(L.MLW + (FE4_NW - 1) * SPC);
     L.TAB = L.CARRY + 2;
     L.WMX = reinterpret_cast<float *>(L.TAB + FE4_NW * 64);
+    L.WOV = reinterpret_cast<uint32_t *>(L.WMX + 4);
     return L;
 }
 
@@ -168,8 +173,8 @@ __device__ __forceinline__ void fe4_stage_step(const am_fe4_args &a, const fe4_s
         float2 mm; mm.x = m0; mm.y = m1;
         *reinterpret_cast<float2 *>(L.X + fe4_wrap_up<SPC, G>(slot0 + u) * C::RS + o) = mm;
         // the last chip of a wave's last unit a second time: the next wave needs it after the row holds bb
-        if ((u + 1) % FE4_LU == 0 && u + 1 < FE4_US && o >= C::R - SPC - (SPC & 1)) {
-            float *d = L.MLW + ((u + 1) / FE4_LU - 1) * SPC;
+        if ((u + 1) % C::LU == 0 && u + 1 < C::US && o >= C::R - SPC - (SPC & 1)) {
+            float *d = L.MLW + ((u + 1) / C::LU - 1) * SPC;
             const int k = o - (C::R - SPC);
             if (k >= 0) d[k] = m0;
             if (k + 1 >= 0 && k + 1 < SPC) d[k + 1] = m1;
@@ -216,8 +221,9 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     using C = fe4_cfg<SPC, G>;
     constexpr int R = C::R, RS = C::RS, LPB = C::LPB, LAGU = C::LAGU;
     const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
-    const bool unit_thread = lane < FE4_LU;
-    const int t = wv * FE4_LU + (unit_thread ? lane : FE4_LU - 1);    // unit of the step (spare lanes shadow the last one, never write)
+    constexpr int LU = C::LU;
+    const bool unit_thread = lane < LU;
+    const int t = wv * LU + (unit_thread ? lane : LU - 1);    // unit of the step (spare lanes shadow the last one, never write)
     const long long A0 = a.out_abs0 + (long long)step * C::T;
     const int slotA = fe4_wrap_up<SPC, G>(slot0 + t);
     const bool do_pmf = a.use_pmf != 0 && SPC > 1;
@@ -243,7 +249,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                 }
             }
             // the step's last chip hands its suffix sums to the next step's first chip
-            if (tid == (FE4_NW - 1) * AM_WAVE + FE4_LU - 1) {
+            if (tid == (FE4_NW - 1) * AM_WAVE + LU - 1) {
 #pragma unroll
                 for (int i = 0; i < SPC; ++i) L.SBL[par * SPC + i] = sx[(G - 1) * SPC + i];
             }
@@ -448,7 +454,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         cm &= keep;
     }
     if (!unit_thread) cm = 0u;
-    if (unit_thread) a.bits[(size_t)step * FE4_US + t] = cm;
+    if (unit_thread) a.bits[(size_t)step * C::US + t] = cm;
     uint32_t cnt = (uint32_t)__popcll((unsigned long long)cm);
     for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, AM_WAVE);
     if (lane == 0) a.seg_cnt[(size_t)step * FE4_NW + wv] = cnt;
@@ -468,7 +474,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     };
     {
         // reference level: the unit of a candidate and the one after it (a wave's lane 0 cannot see the unit before it: always)
-        const unsigned long long wa = (cand | (cand << 1) | 1ull) & ((1ull << FE4_LU) - 1ull);
+        const unsigned long long wa = (cand | (cand << 1) | 1ull) & C::LUMASK;
         const int nav = __popcll(wa);
         uint32_t *tab = L.TAB + wv * AM_WAVE;
         float *avs = L.AVS + wv * (4 * RS);
@@ -485,7 +491,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
             __builtin_amdgcn_wave_barrier();
             const int r = r0 + sub;
             if (sub < 4 && sub < C::RPI && r < nav) {
-                const int tu = wv * FE4_LU + (int)tab[r];
+                const int tu = wv * LU + (int)tab[r];
                 put2(dst, tu * R + 2 * piece, *reinterpret_cast<const float2 *>(avs + sub * RS + 2 * piece));
             }
             __builtin_amdgcn_wave_barrier();
@@ -496,10 +502,26 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         unsigned long long need = cand;
 #pragma unroll
         for (int k = 1; k <= C::NBU; ++k) need |= cand << k;
-        if (wv == 0) need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.CARRY[par ^ 1]);
-        if (wv == FE4_NW - 1) {
-            if (lane == 0) L.CARRY[par] = (uint32_t)(need >> FE4_LU) & 0xFFFFu;
-            need &= (1ull << FE4_LU) - 1ull;
+        if constexpr (LU == 64) {
+            // every lane owns a unit: what reaches past the wave's last unit goes to the next wave (through LDS, behind a
+            // barrier the reference-level rows above give slack to), or, from the last wave, to the next step
+            uint32_t ov = 0u;
+#pragma unroll
+            for (int k = 1; k <= C::NBU; ++k) ov |= (uint32_t)(cand >> (64 - k));
+            if (lane == 0) {
+                if (wv == FE4_NW - 1) L.CARRY[par] = ov;
+                else L.WOV[par * FE4_NW + wv] = ov;
+            }
+            fe4_barrier();
+            if (wv == 0) need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.CARRY[par ^ 1]);
+            else need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.WOV[par * FE4_NW + wv - 1]);
+        } else {
+            // (16 spare lanes: a wave reaches into the next wave's units itself)
+            if (wv == 0) need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.CARRY[par ^ 1]);
+            if (wv == FE4_NW - 1) {
+                if (lane == 0) L.CARRY[par] = (uint32_t)(need >> LU) & 0xFFFFu;
+                need &= C::LUMASK;
+            }
         }
         const int nflag = __popcll(need);
         uint32_t *tab = L.TAB + wv * AM_WAVE;
@@ -510,7 +532,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         for (int r0 = 0; r0 < nflag; r0 += C::RPI) {                  // (uniform trip count)
             const int r = r0 + sub;
             if (sub < C::RPI && r < nflag) {
-                const int tu = wv * FE4_LU + (int)tab[r];             // test index of the unit
+                const int tu = wv * LU + (int)tab[r];                 // test index of the unit
                 const int slot = fe4_wrap_dn<SPC, G>(fe4_wrap_up<SPC, G>(slot0 + tu) - LAGU);
                 put2(dst, tu * R + 2 * piece, *reinterpret_cast<const float2 *>(L.X + slot * RS + 2 * piece));
             }
@@ -537,7 +559,7 @@ __global__ void __launch_bounds__(FE4_NT, 3) am_k_fe4(am_fe4_args a)
     bool badrun = false;
     // the step before the segment only rebuilds the rings: its first tested unit is unit US - LAGU, whose reference level
     // reaches back LPB units
-    constexpr int WARM_P0 = ((FE4_US - C::LAGU - C::LPB - 1) * C::R / 2 / FE4_NT) * FE4_NT;
+    constexpr int WARM_P0 = ((C::US - C::LAGU - C::LPB - 1) * C::R / 2 / FE4_NT) * FE4_NT;
     for (int step = sb - 1; step < se; ++step) {
         const bool test = step >= sb;
         const bool have = step >= a.raw_lo && step < a.raw_hi;
@@ -550,7 +572,7 @@ __global__ void __launch_bounds__(FE4_NT, 3) am_k_fe4(am_fe4_args a)
         else fe4_stage_step<SPC, G, true>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid, 0);
         fe4_barrier();                                                // B1: |.|^2 of this step staged
         fe4_step<SPC, G>(a, L, step, test, slot0, par, edge, tid, mxrun, badrun);
-        slot0 = fe4_wrap_up<SPC, G>(slot0 + FE4_US);
+        slot0 = fe4_wrap_up<SPC, G>(slot0 + C::US);
         par ^= 1;
         fe4_barrier();                                                // B5: every ring read of this step done
     }
@@ -585,7 +607,12 @@ static int fe4_g_of(int spc)
 }
 int am_fe4_supported(int spc) { return fe4_g_of(spc) != 0 ? 1 : 0; }
 unsigned am_fe4_unit(int spc) { return (unsigned)(spc * fe4_g_of(spc)); }                    // R: positions per bitmap word
-unsigned am_fe4_tile(int spc) { return (unsigned)FE4_US * am_fe4_unit(spc); }                // positions per step
+unsigned am_fe4_words(int spc)                                                               // bitmap words (units) per step and wave
+{
+    const int g = fe4_g_of(spc);
+    return g ? (unsigned)((AM_WAVE % (AM_CHIPS_AVG / g) == 0) ? AM_WAVE : AM_CHIPS_AVG) : 0u;
+}
+unsigned am_fe4_tile(int spc) { return (unsigned)FE4_NW * am_fe4_words(spc) * am_fe4_unit(spc); }   // positions per step
 unsigned am_fe4_lag(int spc) { const int g = fe4_g_of(spc); return g ? (unsigned)((1 + 8 / g) * spc * g) : 0u; }
 unsigned am_fe4_steps(long long out_n, int spc)
 {

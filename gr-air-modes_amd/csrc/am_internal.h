@@ -58,10 +58,11 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
                          float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps,
                          unsigned *steps_per_wg, hipStream_t s);
 /* the same for rates below 64 Msps (am_fe4.hip): a lane takes a unit of G chips = am_fe4_unit(spc) samples, a bitmap word
- * holds that many positions: bit b of word w = array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); 96 words per
- * step, two segments (waves) of 48 */
+ * holds that many positions: bit b of word w = array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); two segments
+ * (waves) of am_fe4_words(spc) words per step: 64 at 20 and 2 Msps, 48 otherwise */
 int am_fe4_supported(int spc);
 unsigned am_fe4_unit(int spc);
+unsigned am_fe4_words(int spc);
 unsigned am_fe4_tile(int spc);
 unsigned am_fe4_lag(int spc);
 unsigned am_fe4_steps(long long out_n, int spc);
@@ -73,7 +74,8 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
  * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals; 2 segments per step) */
 hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
                                  const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
-                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr, uint32_t wbits = 32);   /* segment k = words 48k .. 48k+47; wbits positions per word */
+                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr, uint32_t wbits = 32,
+                                 uint32_t seg_words = 48);   /* segment k = words 48k .. 48k+47; wbits positions per word */
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,

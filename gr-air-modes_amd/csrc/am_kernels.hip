@@ -482,7 +482,7 @@ __global__ void __launch_bounds__(4 * AM_WAVE)
 am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ seg_cnt,
                  const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t nseg,
                  uint32_t Mcap, int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
-                 const uint32_t *__restrict__ Mp, uint32_t wbits)
+                 const uint32_t *__restrict__ Mp, uint32_t wbits, uint32_t nw)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t seg = blockIdx.x * 4u + threadIdx.x / AM_WAVE;
@@ -491,8 +491,8 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
     // the two words before, each behind the branch on the one before it, it was four -- which, measured, makes no
     // difference to the kernel's 15 us: they go to its 10 400 workgroups of four single-segment waves)
     const int lane = threadIdx.x & (AM_WAVE - 1);
-    const uint32_t nw = 48u;                                 // words of a segment (one wave of the front end = one 48-chip block)
-    const size_t w = (size_t)seg * 48u + (uint32_t)lane;
+    // nw words per segment (one wave of the front end: 48, or 64 where all of its lanes own a unit)
+    const size_t w = (size_t)seg * nw + (uint32_t)lane;
     uint32_t cnt = seg_cnt[seg];
     uint32_t off = off_local[seg] + (blk_base ? blk_base[seg / AM_SCAN_BLK] : 0u);   // exclusive scan of seg_cnt (two-level, or global)
     uint32_t word = 0, p1 = 0, p2 = 0;
@@ -532,12 +532,12 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
 
 hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
                                  const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
-                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp, uint32_t wbits)
+                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp, uint32_t wbits, uint32_t seg_words)
 {
     if (M == 0 || nseg == 0) return hipSuccess;
-    if (wbits == 0 || wbits > 32 || (uint32_t)spc + 1u > 2u * wbits) return hipErrorInvalidValue;
+    if (wbits == 0 || wbits > 32 || (uint32_t)spc + 1u > 2u * wbits || seg_words == 0 || seg_words > AM_WAVE) return hipErrorInvalidValue;
     hipLaunchKernelGGL(am_k_gather_bits, dim3((nseg + 3u) / 4u), dim3(4 * AM_WAVE), 0, s, bits, seg_cnt, off_local, blk_base, nseg, M, spc,
-                       lag, pos, dcount, Mp, wbits);
+                       lag, pos, dcount, Mp, wbits, seg_words);
     return hipGetLastError();
 }
 
