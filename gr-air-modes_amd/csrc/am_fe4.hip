@@ -64,6 +64,10 @@ struct fe4_cfg {
     // 2 Msps kernels), 48 otherwise
     static constexpr int LU = (AM_WAVE % LPB == 0) ? AM_WAVE : AM_CHIPS_AVG;
     static constexpr int US = LU * FE4_NW;                             // units per step
+    // waves per SIMD the registers are budgeted for: 3 (<= 168 VGPRs, 6 workgroups per CU; the 2 Msps kernel needs fewer and
+    // gets 8).  (4 for the 20 Msps kernel -- 128 VGPRs, 7 workgroups per CU, one step fewer per workgroup -- measured
+    // 0.058 against 0.0556 ms: the tighter register budget costs more than the step.)
+    static constexpr int MINW = 3;
     static constexpr unsigned long long LUMASK = (LU == 64) ? ~0ull : ((1ull << (LU & 63)) - 1ull);
     static constexpr int LAGU = 1 + 8 / G;                             // units phase B runs behind phase A
     static constexpr int NBU = (G - 1 + 16) / G;                       // units of bb kept after a candidate's unit
@@ -541,7 +545,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
 }
 
 template <int SPC, int G>
-__global__ void __launch_bounds__(FE4_NT, 3) am_k_fe4(am_fe4_args a)
+__global__ void __launch_bounds__(FE4_NT, (fe4_cfg<SPC, G>::MINW)) am_k_fe4(am_fe4_args a)
 {
     using C = fe4_cfg<SPC, G>;
     HIP_DYNAMIC_SHARED(unsigned char, smem);
