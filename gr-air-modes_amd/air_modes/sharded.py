@@ -23,7 +23,8 @@ samples into the next chunk.  Per step:
                      kernel, the chain is marked from there, hits are extracted and sliced.  ONE completion wait
                      per step (round 2: two waits and a host round trip for the tables between them).
   A step whose table does not fit the message, or whose scan met more candidates than the capacity it was launched for
-  (every rank sees the same flag / its own count), is repeated on the synchronous path of round 2 (am_shard_scan ->
+  (both are flagged in the message header, so every rank takes the same decision without another collective), is repeated
+  on the synchronous path of round 2 (am_shard_scan ->
   host tables -> am_shard_entry -> am_shard_resolve; `sync_steps` counts them; the first step of a receiver, which has
   no candidate-density estimate yet, reads one count back).
 
@@ -127,12 +128,10 @@ class ShardedReceiver(object):
                 msgs = self._agath
             else:
                 msgs = self._amsg
+            # `redo` is the same on every rank without another collective: a table that does not fit its message and a scan
+            # that met more candidates than the capacity it was launched for are both flagged in the message header, and
+            # every rank reads every header
             pk, redo = self.ctx.shard_resolve_async(msgs.data_ptr(), world, rank, self.small_cap, capacity=cap_pk)
-            if world > 1:
-                # every rank must take the same path: a capacity overflow is a rank's private matter (a table overflow is not)
-                flag = t.tensor([1 if redo else 0], dtype=t.int32, device=buf.device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-                redo = bool(int(flag.item()))
             if not redo:
                 return pk
             self.sync_steps += 1

@@ -1239,16 +1239,19 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
     const uint32_t M = am_count(Mcap, Mp);
     // header (device-side exchange of the tables): pos = number of entries = up to and including the first candidate at or
     // past lead_end, all min(n, M) of them if there is none.  Positions ascend: exactly one thread qualifies.
+    // header->exit = 1: the scan met more candidates than the capacity it was launched for (its table is built on an
+    // incomplete list: every rank must repeat the step, and every rank learns it from here)
     if (header) {
         const uint32_t nr = M < n ? M : n;
+        const uint64_t over = (Mp && *Mp > Mcap) ? 1u : 0u;
         if (nr == 0) {
-            if (threadIdx.x == 0) { header->pos = 0; header->exit = 0; }
+            if (threadIdx.x == 0) { header->pos = 0; header->exit = over; }
         } else
             for (uint32_t i = threadIdx.x; i < nr; i += blockDim.x) {
                 const bool term = pos[i] >= lead_end && (i == 0 || pos[i - 1u] < lead_end);
                 const bool tail = i == nr - 1u && pos[i] < lead_end;
                 // (tail with candidates left beyond the table's n entries: the table does not fit -- count n + 1 says so)
-                if (term || tail) { header->pos = term ? i + 1u : (M > n ? n + 1u : nr); header->exit = 0; }
+                if (term || tail) { header->pos = term ? i + 1u : (M > n ? n + 1u : nr); header->exit = over; }
             }
     }
     HIP_DYNAMIC_SHARED(uint16_t, lnk);
@@ -1537,14 +1540,14 @@ __global__ void am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_
     for (uint32_t r = 0; r < rank; ++r) {
         const am_shard_exit *m = msgs + (size_t)r * (cap + 1u);
         const uint64_t n = m[0].pos;
-        if (n > cap) { bad = 1; break; }
+        if (n > cap || m[0].exit != 0) { bad = 1; break; }
         const am_shard_exit *t = m + 1;
         uint64_t i = 0;
         while (i < n && t[i].pos < cur) ++i;
         if (i < n) cur = t[i].exit > cur ? t[i].exit : cur;  // no candidate left: the scan passes through
     }
     for (uint32_t r = rank; r < world && !bad; ++r)           // (every rank must take the same decision)
-        if (msgs[(size_t)r * (cap + 1u)].pos > cap) bad = 1;
+        if (msgs[(size_t)r * (cap + 1u)].pos > cap || msgs[(size_t)r * (cap + 1u)].exit != 0) bad = 1;
     uint64_t rel = cur > base_abs ? cur - base_abs : 0;
     if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
     *cur0_out = (uint32_t)rel;

@@ -250,14 +250,16 @@ int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap,
 
 /* The same step without a host round trip in the middle (round 3): the exit table stays on the device.
  * am_shard_scan_async: as am_shard_scan, but everything is only ENQUEUED and the table goes to the device message
- *   msg_dev = 1 + msg_cap entries: entry 0 = {count, -}, then the table (count = msg_cap + 1: it did not fit).
+ *   msg_dev = 1 + msg_cap entries: entry 0 = {count, overflow}, then the table (count = msg_cap + 1: it did not fit;
+ *   overflow = 1: the scan met more candidates than the capacity it was launched for).
  * The caller all-gathers the messages (device to device, e.g. torch.distributed over RCCL: am_signal_stream makes the
  *   collective's stream wait for the table, am_wait_for_stream the context for the collective) and hands all `world`
  *   of them, in chunk order, to
  * am_shard_resolve_async: composes the entry position of chunk `rank` on the device (am_shard_entry as a kernel), marks the
  *   chain from there, extracts and slices -- ONE completion wait per step.  *redo != 0: a table did not fit its message,
- *   or the scan met more candidates than the capacity it was launched for (both rare): no packets were delivered,
- *   repeat the step with am_shard_scan / am_shard_entry / am_shard_resolve. */
+ *   or some rank's scan met more candidates than the capacity it was launched for (both rare, both read from the message
+ *   headers: *redo is the same on every rank): no packets were delivered, repeat the step with am_shard_scan /
+ *   am_shard_entry / am_shard_resolve. */
 int am_shard_scan_async(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
                         uint32_t flags, am_shard_exit *msg_dev, uint64_t msg_cap);
 int am_shard_resolve_async(am_ctx *ctx, const am_shard_exit *msgs_dev, uint32_t world, uint32_t rank, uint64_t msg_cap,

@@ -69,3 +69,53 @@ def test_time_sharded_matches_single_stream(emu_lib, oracle_mod, world, small_ta
     want = oracle_mod.demod(iq, RATE)
     assert len(want) > 20
     assert np.array_equal(got, want)
+
+
+def _worker_density_jump(rank, world, port, ret):
+    for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import synth
+    from air_modes import _capi
+    from air_modes.sharded import ShardedReceiver
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        os.environ["AIRMODES_SPEC_FLOOR"] = "8"          # (test builds read it: no slack on top of the extrapolated capacity)
+        lib = _capi.Library(conftest.EMU_LIB)
+        ctx = _capi.Context(RATE, 7.0, True, lib=lib)
+        rx = ShardedReceiver(ctx, rank, world, N_PER_RANK)
+        # step 1: a nearly empty sky (the capacity estimate of step 2 comes from here) -- step 2: the LAST rank's chunk
+        # alone turns busy, its scan meets far more candidates than the capacity it is launched for
+        quiet, _ = synth.synth_capture(RATE, world * N_PER_RANK, 300.0, seed=11)
+        busy, _ = synth.synth_capture(RATE, world * N_PER_RANK, 30000.0, seed=12)
+        second = quiet.copy()
+        second[(world - 1) * N_PER_RANK:] = busy[(world - 1) * N_PER_RANK:]
+        out = []
+        for stream in (quiet, second):
+            rx.chunk.copy_(torch.from_numpy(stream[rank * N_PER_RANK:(rank + 1) * N_PER_RANK].copy().view(np.float32)))
+            out.append(rx.step())
+        ret[rank] = (out[0].tobytes(), out[1].tobytes())
+        ret["sync_%d" % rank] = rx.sync_steps
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capacity_overflow_on_one_rank_is_everybodys_redo(emu_lib, oracle_mod):
+    """The flag travels in the message header: every rank repeats the step (same count everywhere) without a collective
+    about it, and the packets are the single-stream packets."""
+    import synth
+    from air_modes import _capi
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_density_jump, args=(world, 29577, ret), nprocs=world, join=True)
+    syncs = [ret["sync_%d" % r] for r in range(world)]
+    assert syncs == [1] * world, syncs
+    quiet, _ = synth.synth_capture(RATE, world * N_PER_RANK, 300.0, seed=11)
+    busy, _ = synth.synth_capture(RATE, world * N_PER_RANK, 30000.0, seed=12)
+    second = quiet.copy()
+    second[(world - 1) * N_PER_RANK:] = busy[(world - 1) * N_PER_RANK:]
+    for k, stream in enumerate((quiet, second)):
+        got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for r in range(world)])
+        assert np.array_equal(got, oracle_mod.demod(stream, RATE)), k

@@ -14,6 +14,9 @@ if [ -f build/var/lib_fe3prof.so ]; then
   AIRMODES_HIP_LIB=$PWD/build/var/lib_fe3prof.so timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra 2>&1 >/dev/null | grep "^fe3" | tail -3 > $OUT/fe3_phase_clocks.txt
 fi
 AIRMODES_HIP_LIB=$PWD/tests/gpu_variants/libairmodes_hip_knobs.so AIRMODES_FE=2 timeout 120 python bench.py --no-cpu-baseline --no-extra > $OUT/bench_tile_kernel.json 2>/dev/null
+timeout 120 python bench.py --force-sharded --no-cpu-baseline --no-extra > $OUT/bench_force_sharded.json 2>/dev/null
 timeout 120 python bench.py --workload 2msps --no-cpu-baseline --no-extra > $OUT/bench_2msps.json 2>/dev/null
 timeout 120 python bench.py --workload 20msps --no-cpu-baseline --no-extra > $OUT/bench_20msps.json 2>/dev/null
+timeout 200 bash tools/gpu_pmc.sh > $OUT/sq_counters.txt 2>&1
+for w in 20msps 2msps; do BENCH_ARGS="--workload $w" STEPS=10 timeout 200 bash tools/gpu_kstats.sh > $OUT/kernel_stats_$w.txt 2>&1; done
 tail -c 900 $OUT/bench.json; echo; cat $OUT/fe3_phase_clocks.txt; grep -E "fe3|fe2|energy|cand|extract" $OUT/summary.txt | head -12
