@@ -238,12 +238,12 @@ def main():
             from air_modes import _capi as _c
             up = _c.Uploader(n, nslots=2, lib=lib)
             hb = [b.view(np.float32) for b in host_batches]
-            ksteps = 4
+            ksteps = 6
             for k in range(2):                                   # (the source has written its samples into the pinned buffers:
                 up.buffer(k)[:2 * n] = hb[k % len(hb)]            #  a file reader does readinto() there, modes_rx.py)
-            up.start(0, n)
             sync()
             th = time.perf_counter()
+            up.start(0, n)                                        # (inside the timed region: as many copies as scans)
             for k in range(ksteps):
                 ptr = up.wait(k % 2)
                 if k + 1 < ksteps:
