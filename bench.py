@@ -362,12 +362,13 @@ def main():
         if mode == "single" and os.path.exists(tj) and not args.emu:
             with open(tj) as f:
                 t = json.load(f)
+            t = t.get(workload, {}) if "workload" not in t else t    # (one entry per workload)
             # the counters belong to ONE version of the kernel: the file carries the hash of the kernel's source it was
             # measured on, and a kernel that changed since reports no traffic rather than somebody else's
             import hashlib
             with open(os.path.join(ROOT, "gr-air-modes_amd", "csrc", t.get("kernel_source", "am_fe3.hip")), "rb") as kf:
                 sha = hashlib.sha256(kf.read()).hexdigest()[:16]
-            if t.get("workload") == workload and args.seconds is None and args.lam is None and t.get("kernel", "") in kernel_name:
+            if t.get("workload") == workload and args.seconds is None and args.lam is None and kernel_name.startswith(t.get("kernel", "?")):
                 if t.get("kernel_source_sha16") == sha:
                     traffic = t["traffic_bytes"]
                     traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; %s sha %s)" % (

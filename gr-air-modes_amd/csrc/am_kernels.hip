@@ -2002,6 +2002,7 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
 // Completion ticket: the last launch of a scan.  The host polls the pinned word instead of asking the
 // runtime (whose completion path costs tens of microseconds per scan).
 // (count_src / count_dst: a device-side count to hand to the host along with the ticket, or null)
+// (hipStreamWriteValue32 in its place -- a queue packet instead of a dispatch -- measured the same step time, 64 and 2 Msps.)
 __global__ void am_k_ticket(uint32_t *host_word, uint32_t seq, const uint32_t *count_src, uint32_t *count_dst)
 {
     if (count_src) *count_dst = *count_src;
