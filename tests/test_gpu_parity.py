@@ -368,3 +368,44 @@ def test_host_free_sharded_step_on_device(lib):
         assert np.array_equal(got, want)
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_stream_ordering_by_events_on_device(lib):
+    """am_wait_for_stream / am_signal_stream (the sharded step's ordering against PyTorch's streams had no test on
+    the device).  A side stream is kept busy for tens of milliseconds and only then writes the samples: the context must scan
+    the samples, not the zeros that are there before; and a copy enqueued on the side stream behind am_signal_stream must see
+    the exit table the context's stream writes, not the buffer's old content."""
+    import torch
+    rate, n = 20e6, 4_000_000
+    iq, _ = synth.synth_capture(rate, n, 5000.0, 777)
+    want = oracle.demod(iq, rate)
+    assert len(want) > 50
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(iq.view(np.float32)).to(dev)
+    buf = torch.zeros_like(src)
+    side = torch.cuda.Stream(device=dev)
+    ctx = _capi.Context(rate, 7.0, True, lib=lib)
+    ctx.process_iq_device(src.data_ptr(), n, flush=True)         # (buffers allocated, capacity estimate in place)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(60_000_000)                             # ~25 ms of spinning in front of the copy
+        buf.copy_(src, non_blocking=True)
+    ctx.wait_for_stream(side.cuda_stream)
+    got = ctx.process_iq_device(buf.data_ptr(), n, flush=True)
+    assert np.array_equal(got, want)
+    # the other direction: the table of an enqueued scan, copied by the side stream
+    cap = 512
+    msg = torch.full((2 * (1 + cap),), -1, dtype=torch.int64, device=dev)
+    seen = torch.empty_like(msg)
+    torch.cuda.synchronize()
+    ctx.shard_scan_async(src.data_ptr(), 0, n, n, msg.data_ptr(), cap)
+    ctx.signal_stream(side.cuda_stream)
+    with torch.cuda.stream(side):
+        seen.copy_(msg, non_blocking=True)
+    side.synchronize()
+    torch.cuda.synchronize()
+    assert int(seen[0].item()) >= 0 and torch.equal(seen, msg)    # (the header's count was written before the copy ran)
+    pk, redo = ctx.shard_resolve_async(msg.data_ptr(), 1, 0, cap)
+    assert not redo and np.array_equal(pk, want)
+    ctx.close()
