@@ -1004,7 +1004,10 @@ am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw
     int cur = 0;
     for (int r = 0; r < AM_CB_LEVELS; ++r) {                 // successors strictly increase: <= 2^11 hops inside
         // (the thread's eight nodes side by side: all first reads, then all dependent reads, then the stores -- written
-        // as one read-read-store per node the compiler keeps them in program order, LDS stores may alias LDS loads)
+        // as one read-read-store per node the compiler keeps them in program order, LDS stores may alias LDS loads.
+        // Eight CONSECUTIVE nodes per thread -- own entries as 16-byte accesses, 16 LDS instructions per level instead of
+        // 40 -- was measured in round 3: this kernel 9.0 -> 10-11 us (a lane stride of 64 bytes is a 4-way bank conflict),
+        // the marking kernel 19.5 -> 16.5-17.2 us with the same layout: not the instruction count, dropped.)
         uint32_t t[AM_CB_PER], ne[AM_CB_PER], nl[AM_CB_PER];
 #pragma unroll
         for (int k = 0; k < AM_CB_PER; ++k) t[k] = e[cur][threadIdx.x + k * AM_CB_THREADS];
