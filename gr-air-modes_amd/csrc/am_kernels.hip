@@ -995,10 +995,21 @@ am_k_cblk_exit(const uint32_t *__restrict__ jump0, uint32_t Mcap, uint32_t headw
     }
     const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
     const uint32_t n = end - base;
-    for (int k = 0; k < AM_CB_PER; ++k) {
-        const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-        e[0][i] = (i < n) ? jump0[base + i] : end;
-        l[0][i] = base + i;
+    {
+        // (unconditional loads from clamped indices: behind `i < n` every load sat in its own branch and waited for the one
+        // before it -- eight serial memory round trips)
+        uint32_t j[AM_CB_PER];
+#pragma unroll
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            j[k] = jump0[base + (i < n ? i : n - 1u)];
+        }
+#pragma unroll
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            e[0][i] = (i < n) ? j[k] : end;
+            l[0][i] = base + i;
+        }
     }
     __syncthreads();
     int cur = 0;
@@ -1327,12 +1338,19 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
         const uint32_t n = end - base;
         const uint16_t OUT = (uint16_t)AM_CB;                // "leaves the block"
-        for (int k = 0; k < AM_CB_PER; ++k) {
-            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-            uint16_t t = OUT;
-            if (i < n) { const uint32_t j = jump0[base + i]; if (j < end) t = (uint16_t)(j - base); }
-            J[0][i] = t;
-            V[i] = (base + i == ent) ? 1 : 0;
+        {
+            uint32_t j[AM_CB_PER];                            // (unconditional loads from clamped indices, all in flight at once)
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) {
+                const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+                j[k] = jump0[base + (i < n ? i : n - 1u)];
+            }
+#pragma unroll
+            for (int k = 0; k < AM_CB_PER; ++k) {
+                const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+                J[0][i] = (i < n && j[k] < end) ? (uint16_t)(j[k] - base) : OUT;
+                V[i] = (base + i == ent) ? 1 : 0;
+            }
         }
         __syncthreads();
         // (the thread's eight nodes side by side, as in am_k_cblk_exit: reads, dependent reads, stores)
@@ -1362,16 +1380,30 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         }
         // which visited nodes are hits, and where the scan resumes after everything visited here: the largest
         // target (only needed when the stream continues)
+        // (all of a thread's loads go out together, visited or not: written as one node after the other -- position, then
+        // `valid`, then `e` behind the short-circuit, eight nodes in turn -- the kernel spent most of its time in up to 24
+        // serial memory round trips per thread)
+        bool vis[AM_CB_PER];
+        uint32_t p[AM_CB_PER], ee[AM_CB_PER], tg[AM_CB_PER];
+        uint8_t va[AM_CB_PER];
+#pragma unroll
         for (int k = 0; k < AM_CB_PER; ++k) {
             const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
-            const uint32_t g = base + i;
-            const bool vis = i < n && V[i] != 0;
-            bool em = false;
-            if (vis) {
-                const uint32_t p = ea.pos[g];
-                em = ea.valid[g] && ea.e[g] <= ea.emit_max && p >= ea.own_lo && p < ea.own_hi;
-                if (ea.want_resume) { const uint32_t tg = ea.tgt[g]; tmax = tg > tmax ? tg : tmax; }
-            }
+            vis[k] = i < n && V[i] != 0;
+        }
+#pragma unroll
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
+            const uint32_t g = base + (i < n ? i : n - 1u);   // (a node of the block in any case: no branch around the loads)
+            p[k] = ea.pos[g];
+            va[k] = ea.valid[g];
+            ee[k] = ea.e[g];
+            tg[k] = ea.tgt[g];
+        }
+#pragma unroll
+        for (int k = 0; k < AM_CB_PER; ++k) {
+            const bool em = vis[k] && va[k] != 0 && ee[k] <= ea.emit_max && p[k] >= ea.own_lo && p[k] < ea.own_hi;
+            if (vis[k] && ea.want_resume) tmax = tg[k] > tmax ? tg[k] : tmax;
             if (em) embits |= 1u << k;
         }
     }
@@ -1922,6 +1954,8 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     // (Giving every XCD one contiguous eighth of the hits, so that the overlapping windows of neighbouring hits meet
     // in one L2, changed nothing: 56.3 against 56.7 us.  Ten workgroups of two waves per CU instead of five of four --
     // twice as many hits in flight, the second 112 chips by the same threads: 62.8 us.)
+    // (Taking a hit's candidate index, refined position, reference level and first-stage position one hit AHEAD, so that
+    // those two dependent round trips ride along with the current hit's sample loads, changed nothing: 54.8 against 54.7 us.)
     for (uint32_t i = blockIdx.x; i < nhit; i += gridDim.x) {                 // (uniform)
         const uint32_t g = emit_idx[i];
         const uint32_t e = eo[g];
