@@ -1328,6 +1328,13 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
     __shared__ uint32_t wc[AM_CB_PER][AM_CB_THREADS / AM_WAVE], wmax[AM_CB_THREADS / AM_WAVE];
     __shared__ uint32_t red[AM_CB_THREADS / AM_WAVE];
     __shared__ uint32_t tick;
+#if defined(AM_MARK_PROF)
+    long long mp[8]; int mpn = 0;
+#define AM_MSTAMP() do { __syncthreads(); mp[mpn++] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    AM_MSTAMP();
+#else
+#define AM_MSTAMP() ((void)0)
+#endif
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t blk = am_chain_place(ea.slots + gridDim.x + 2, ea.epoch, &tick);   // block of candidates = place in the chain
     const uint32_t base = blk * AM_CB;
@@ -1349,12 +1356,18 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
             for (int k = 0; k < AM_CB_PER; ++k) {
                 const uint32_t i = threadIdx.x + k * AM_CB_THREADS;
                 J[0][i] = (i < n && j[k] < end) ? (uint16_t)(j[k] - base) : OUT;
-                V[i] = (base + i == ent) ? 1 : 0;
+                V[i] = 0;
             }
         }
         __syncthreads();
+        // links 2^l hops ahead, l = 1 .. : only as far as the orbit of the entry node needs them -- once J[l][entry] leaves the
+        // block, the orbit has at most 2^l nodes here
         // (the thread's eight nodes side by side, as in am_k_cblk_exit: reads, dependent reads, stores)
-        for (int l = 1; l < AM_CB_LEVELS; ++l) {
+        AM_MSTAMP();                                          // 1: successors loaded
+        const uint32_t ent_l = ent - base;
+        int nlev = 1;                                         // levels J[0 .. nlev) exist
+        while (nlev < AM_CB_LEVELS && J[nlev - 1][ent_l] != OUT) {               // (uniform: every thread reads the same word)
+            const int l = nlev;
             uint16_t t[AM_CB_PER], u[AM_CB_PER];
 #pragma unroll
             for (int k = 0; k < AM_CB_PER; ++k) t[k] = J[l - 1][threadIdx.x + k * AM_CB_THREADS];
@@ -1362,22 +1375,37 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
             for (int k = 0; k < AM_CB_PER; ++k) u[k] = J[l - 1][(t[k] == OUT) ? 0 : t[k]];
 #pragma unroll
             for (int k = 0; k < AM_CB_PER; ++k) J[l][threadIdx.x + k * AM_CB_THREADS] = (t[k] == OUT) ? OUT : u[k];
+            ++nlev;
             __syncthreads();
         }
-        // top-down: every marked node marks the node 2^l hops ahead (marks only ever land on the orbit; a mark set
-        // during a level may or may not be seen by that level: either way it is a node of the orbit)
-        for (int l = AM_CB_LEVELS - 1; l >= 0; --l) {
-            uint8_t v[AM_CB_PER];
-            uint16_t t[AM_CB_PER];
+        AM_MSTAMP();                                          // 2: levels built
+        // The orbit's q-th node (q = 0: the entry) is reached by the hops of q's binary digits, in any order (they are powers
+        // of one map): thread t enumerates q = t, t + 256, ... on its own -- up to 11 dependent LDS reads each, eight chains
+        // side by side, no barrier in between -- and marks what it reaches.  (Round 2 pushed the marks down level by level, 11
+        // more barrier-separated passes over the block: the same 4.5 us -- both are bound by the random 16-bit LDS gathers,
+        // 88 per thread.  Phase clocks of a -DAM_MARK_PROF build, us: successors 1.1, levels 3.0, orbit 4.5, the visited
+        // nodes' records 1.4, counts 0.7, waiting for the blocks before 0.4-3.4, index stores 2.)
+        {
+            uint32_t x[AM_CB_PER];
 #pragma unroll
-            for (int k = 0; k < AM_CB_PER; ++k) v[k] = V[threadIdx.x + k * AM_CB_THREADS];
+            for (int k = 0; k < AM_CB_PER; ++k) {
+                const uint32_t q = threadIdx.x + k * AM_CB_THREADS;
+                x[k] = (nlev < AM_CB_LEVELS && (q >> nlev) != 0u) ? (uint32_t)OUT : ent_l;   // (beyond the orbit's length)
+            }
+            for (int l = 0; l < nlev; ++l) {
 #pragma unroll
-            for (int k = 0; k < AM_CB_PER; ++k) t[k] = J[l][threadIdx.x + k * AM_CB_THREADS];
+                for (int k = 0; k < AM_CB_PER; ++k) {
+                    const uint32_t q = threadIdx.x + k * AM_CB_THREADS;
+                    const uint32_t nx = J[l][x[k] == OUT ? 0u : x[k]];
+                    if ((q >> l) & 1u) x[k] = (x[k] == OUT) ? (uint32_t)OUT : nx;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < AM_CB_PER; ++k)
-                if (v[k] && t[k] != OUT) V[t[k]] = 1;
-            __syncthreads();
+                if (x[k] != OUT) V[x[k]] = 1;
         }
+        __syncthreads();
+        AM_MSTAMP();                                          // 3: orbit marked
         // which visited nodes are hits, and where the scan resumes after everything visited here: the largest
         // target (only needed when the stream continues)
         // (all of a thread's loads go out together, visited or not: written as one node after the other -- position, then
@@ -1407,6 +1435,7 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
             if (em) embits |= 1u << k;
         }
     }
+    AM_MSTAMP();                                              // 4 (or 1): hits known
     // ordered compaction of the hits, in the same launch: counts per (round k, wave) -> this block's total -> the
     // totals of the blocks before it (am_chain_prefix) -> every hit's index in emit_idx[].  Node order is
     // (k, wave, lane).
@@ -1429,7 +1458,9 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         for (int k = 0; k < AM_CB_THREADS / AM_WAVE; ++k) m = wmax[k] > m ? wmax[k] : m;
         if (m) atomicMax(&ea.scalars[0], m);
     }
+    AM_MSTAMP();
     const uint32_t before = am_chain_prefix(ea.slots, blk, ea.epoch, tot, red);
+    AM_MSTAMP();                                              // chain prefix
     uint32_t off = before;
     for (int k = 0; k < AM_CB_PER; ++k) {
         const bool em = ((embits >> k) & 1u) != 0u;
@@ -1440,6 +1471,14 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         for (int q = 0; q < AM_CB_THREADS / AM_WAVE; ++q) off += wc[k][q];
     }
     if (blk == gridDim.x - 1 && threadIdx.x == 0) *ea.n_out = before + tot;
+#if defined(AM_MARK_PROF)
+    AM_MSTAMP();
+    if (threadIdx.x == 0 && (blk == 0 || blk == gridDim.x / 2 || blk == gridDim.x - 1 || blk == M / AM_CB)) {
+        printf("mark blk %u/%u ent %d:", blk, gridDim.x, ent != AM_CB_NONE);
+        for (int k = 1; k < mpn; ++k) printf(" %lld", mp[k] - mp[k - 1]);
+        printf("  (10 ns units; start %lld)\n", mp[0] % 1000000);
+    }
+#endif
 }
 
 // compute units of the current device (cached per device: a process may hold contexts on several)

@@ -8,7 +8,7 @@ python - <<'PY'
 import csv, glob
 f = glob.glob('gpurun_out/pipetrace/**/bench_kernel_trace.csv', recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
-ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Queue_Id']), r['Kernel_Name'][:28]) for r in rows]
+ev = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['Queue_Id']), r['Kernel_Name'].replace('void ', '')[:28]) for r in rows]
 ev.sort()
 queues = sorted(set(e[2] for e in ev))
 print('queues seen:', queues, ' dispatches:', len(ev))
@@ -35,6 +35,8 @@ if len(pipeq) >= 2:
     print('window %.1f us: some kernel running %.1f us, sum of kernel durations %.1f us (overlap factor %.2f)' % ((hi - lo) / 1e3, busy_any / 1e3, busy_sum / 1e3, busy_sum / max(busy_any, 1)))
     nfe = sum(1 for e in win if e[3].startswith('am_k_fe3'))
     print('fe3 launches in window:', nfe, ' -> %.1f us per batch' % ((hi - lo) / 1e3 / max(nfe, 1)))
-    for e in win[:60]:
+    alone = sum(min(e[1], hi) - max(e[0], lo) for e in win if e[3].startswith('am_k_fe3'))
+    print('am_k_fe3 running: %.1f us of the window' % (alone / 1e3))
+    for e in win[:75]:
         print('%9.1f %9.1f q%d %s' % ((e[0] - lo) / 1e3, (e[1] - lo) / 1e3, e[2], e[3]))
 PY
