@@ -882,7 +882,10 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     tgt[g] = tg;
     if (jump0) {
         // the greedy chain's successor (first candidate at or after the resume position; all positions are known by
-        // now), here instead of in a launch of its own (am_k_chain_succ: 7 us at the bench density)
+        // now), here instead of in a launch of its own (am_k_chain_succ: 7 us at the bench density).
+        // (Round 3: the scan of the bitmap's segment counts used as an index into pos[] -- two round trips, the offset and
+        // eight positions side by side, instead of a dozen dependent ones -- changed nothing: 28.0 against 28.4 us; the
+        // kernel is bound by the cache traffic of the quiet-zone reads, 1 KB per surviving candidate.)
         jump0[g] = am_lower_bound(pos, g + 1u, M, tg);
         if (g == M - 1u) jump0[M] = M;
     }
