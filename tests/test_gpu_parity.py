@@ -288,6 +288,15 @@ def test_streaming_front_end_unaligned_and_short_inputs(klib, monkeypatch):
     assert pc.check_chunked(lib, 64e6, iq, [1, 3073, 1000001, 1000002, 2500001, 2500002 + 3071], want=want) > 50
     assert pc.check_chunked(lib, 64e6, iq, list(range(70001, 5000000, 70001)), want=want) > 50
     assert pc.check_sharded(lib, 64e6, iq, 5, want=want) > 50
+    # the same for am_k_fe4 (several chips per lane): odd cuts = 8-byte aligned sources = guarded loads on every step,
+    # chunks shorter than a step (3 840 samples at 20 Msps, 3 072 at 2 Msps), shards
+    for rate, lam, seed in ((20e6, 8000.0, 79), (2e6, 1500.0, 80), (4e6, 2000.0, 81)):
+        iq, _ = synth.synth_capture(rate, 2000000, lam, seed)
+        want = oracle.demod(iq, rate)
+        assert len(want) > 30
+        assert pc.check_chunked(lib, rate, iq, [1, 3841, 500001, 500002, 1200001, 1200002 + 3071], want=want) == len(want)
+        assert pc.check_chunked(lib, rate, iq, list(range(30001, 2000000, 30001)), want=want) == len(want)
+        assert pc.check_sharded(lib, rate, iq, 3, want=want) == len(want)
 
 
 def test_batches_in_flight_single_host_thread(lib):
