@@ -1994,7 +1994,8 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     const bool pmf = use_pmf != 0;
     const bool wide = (reinterpret_cast<uintptr_t>(iq) & 15u) == 0;
     // (Giving every XCD one contiguous eighth of the hits, so that the overlapping windows of neighbouring hits meet
-    // in one L2, changed nothing: 56.3 against 56.7 us.  Ten workgroups of two waves per CU instead of five of four --
+    // in one L2, changed nothing: 56.3 against 56.7 us.  Budgeting the 64 Msps instantiation for six workgroups per CU
+    // instead of five -- 80 VGPRs, 9 of them spilled -- 59 against 55 us, and 30-37 against 27 at 2 000 bursts/s.  Ten workgroups of two waves per CU instead of five of four --
     // twice as many hits in flight, the second 112 chips by the same threads: 62.8 us.)
     // (Taking a hit's candidate index, refined position, reference level and first-stage position one hit AHEAD, so that
     // those two dependent round trips ride along with the current hit's sample loads, changed nothing: 54.8 against 54.7 us.)
@@ -2056,22 +2057,39 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
                                       const uint32_t *scalars, uint32_t *host_out, hipStream_t s, const uint32_t *Mp)
 {
     if (n_max == 0) return hipSuccess;
-    const uint32_t resident = (uint32_t)am_device_cus() * 5u;   // five workgroups of 256 threads per CU (registers)
-    const uint32_t grid = n_max < resident ? n_max : resident;
-#define AM_XS_IQ(S)                                                                                                       \
-    hipLaunchKernelGGL((am_k_extract_slice_iq<S>), dim3(grid), dim3(256), 0, s, iq, src_abs0, src_abs1, use_pmf, s1,     \
-                       inavg, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow,          \
-                       packets, scalars, host_out, Mp)
+    // workgroups of 256 threads per CU: what the instantiation's registers allow (five at 32 samples per chip, where a lane
+    // holds a 34-sample window; eight at one or two samples per chip, where the kernel is a chain of memory round trips per
+    // hit and more hits in flight is all that helps), asked of the runtime once per device and instantiation
+    static std::atomic<int> per_cu[64][8];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto resident_for = [&](const void *kernel, int slot) -> uint32_t {
+        int w = (dev >= 0 && dev < 64) ? per_cu[dev][slot].load(std::memory_order_acquire) : 0;
+        if (w <= 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&w, kernel, 256, 0) != hipSuccess || w <= 0) w = 5;
+            w = w > 8 ? 8 : w;
+            if (dev >= 0 && dev < 64) per_cu[dev][slot].store(w, std::memory_order_release);
+        }
+        return (uint32_t)w * (uint32_t)am_device_cus();
+    };
+#define AM_XS_IQ(S, SLOT)                                                                                                 \
+    do {                                                                                                                  \
+        const uint32_t resident = resident_for(reinterpret_cast<const void *>(&am_k_extract_slice_iq<S>), SLOT);         \
+        const uint32_t grid = n_max < resident ? n_max : resident;                                                        \
+        hipLaunchKernelGGL((am_k_extract_slice_iq<S>), dim3(grid), dim3(256), 0, s, iq, src_abs0, src_abs1, use_pmf, s1, \
+                           inavg, emit_idx, n_ptr, pos, e, base_abs, rate, tt, ntt, bursts_out, tags_out, crc_pow,      \
+                           packets, scalars, host_out, Mp);                                                              \
+    } while (0)
     if (spc == 1) use_pmf = 0;                               // (a one-sample window is the sample itself: s1 = 1)
     switch (spc) {                                           // (the rates the streaming front ends serve)
-    case 32: AM_XS_IQ(32); break;
-    case 20: AM_XS_IQ(20); break;
-    case 16: AM_XS_IQ(16); break;
-    case 10: AM_XS_IQ(10); break;
-    case 8: AM_XS_IQ(8); break;
-    case 4: AM_XS_IQ(4); break;
-    case 2: AM_XS_IQ(2); break;
-    case 1: AM_XS_IQ(1); break;
+    case 32: AM_XS_IQ(32, 0); break;
+    case 20: AM_XS_IQ(20, 1); break;
+    case 16: AM_XS_IQ(16, 2); break;
+    case 10: AM_XS_IQ(10, 3); break;
+    case 8: AM_XS_IQ(8, 4); break;
+    case 4: AM_XS_IQ(4, 5); break;
+    case 2: AM_XS_IQ(2, 6); break;
+    case 1: AM_XS_IQ(1, 7); break;
     default: return hipErrorInvalidValue;
     }
 #undef AM_XS_IQ
