@@ -189,10 +189,13 @@ def main():
         last_batch = (k_last % nb) if k_last is not None else 0
         npk_steps = sum(per_batch[k % nb] for k in range(args.steps))
         if mode == "single" and not args.no_extra and not args.no_pipelined and inflight == 1 and args.steps >= 3:
-            # the same steps with three batches in flight from ONE host thread (am_pipe: three contexts behind one handle,
-            # submit / collect): the launch-latency-bound tail of one batch overlaps the streaming kernel of the next
-            pipe = _capi.Pipe(rate, 7.0, True, device=(0 if args.emu else local), depth=3, lib=lib) if lib is not None \
-                else _capi.Pipe(rate, 7.0, True, device=local, depth=3)
+            # the same batches with four in flight from ONE host thread (am_pipe: four contexts behind one handle, submit /
+            # collect): the launch-latency-bound tail of one batch overlaps the streaming kernel of the next.  Timed over
+            # 24 batches including the filling and the draining of the pipe (depth 3: ~4 % less, 5 and more: less again --
+            # tools/gpu_pipe_depth.py).
+            PIPE_DEPTH, PIPE_BATCHES = 4, max(24, 2 * args.steps)
+            pipe = _capi.Pipe(rate, 7.0, True, device=(0 if args.emu else local), depth=PIPE_DEPTH, lib=lib) if lib is not None \
+                else _capi.Pipe(rate, 7.0, True, device=local, depth=PIPE_DEPTH)
 
             def pipe_steps(count):
                 counts, last = [], None
@@ -205,16 +208,18 @@ def main():
                     last = pipe.collect()
                     counts.append(len(last))
                 return counts, last
-            pipe_steps(9)
+            pipe_steps(3 * PIPE_DEPTH)
             sync()
             t3 = time.perf_counter()
-            counts3, last3 = pipe_steps(args.steps)
+            counts3, last3 = pipe_steps(PIPE_BATCHES)
             sync()
             dt3 = time.perf_counter() - t3
-            extra["pipelined"] = {"batches_in_flight": 3, "host_threads": 1, "value": n * args.steps / dt3,
-                                  "unit": "samples/s", "ms_per_step": dt3 / args.steps * 1e3,
-                                  "same_packet_counts": counts3 == [per_batch[k % nb] for k in range(args.steps)],
-                                  "same_packets_last_batch": bool(pk is not None and np.array_equal(last3, pk))}
+            want_last = ctx.process_iq_device(d_batches[(PIPE_BATCHES - 1) % nb].data_ptr(), n, flush=True)
+            extra["pipelined"] = {"batches_in_flight": PIPE_DEPTH, "host_threads": 1, "batches": PIPE_BATCHES,
+                                  "value": n * PIPE_BATCHES / dt3,
+                                  "unit": "samples/s", "ms_per_step": dt3 / PIPE_BATCHES * 1e3,
+                                  "same_packet_counts": counts3 == [per_batch[k % nb] for k in range(PIPE_BATCHES)],
+                                  "same_packets_last_batch": bool(np.array_equal(last3, want_last))}
             pipe.close()
         if mode == "single" and not args.no_extra and lam != REALISTIC_LAMBDA:
             iq_r = synth.synth_capture(rate, n, REALISTIC_LAMBDA, seed + 7)[0]
