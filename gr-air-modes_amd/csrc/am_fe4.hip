@@ -1,9 +1,9 @@
 // am_fe4.hip -- the streaming fused front end (am_fe3.hip) for rates below 64 Msps: several chips per lane.
 //
-// am_k_fe3 gives a lane one 32-sample chip.  At 20 Msps a chip has 10 samples, at 4 Msps 2, at 2 Msps 1: a lane takes a UNIT
-// of G consecutive chips instead (R = G * spc samples: 30 at 20 Msps, 32 at 4 Msps, 24 at 2 Msps), a 48-chip block is 48 / G lanes, and
+// am_k_fe3 gives a lane one 32-sample chip.  At 20 Msps a chip has 10 samples, at 10 Msps 5, at 4 Msps 2, at 2 Msps 1: a lane takes a UNIT
+// of G consecutive chips instead (R = G * spc samples, even: 30 at 20 and 10 Msps, 32 at 4 Msps, 24 at 2 Msps), a 48-chip block is 48 / G lanes, and
 // everything else keeps am_k_fe3's shape -- persistent workgroups of two waves walking a contiguous segment in steps of
-// 96 units (128 where 48 / G divides 64: then every lane of a wave owns a unit, 20 and 2 Msps), |.|^2 staged straight into LDS ring rows, phase A (pulse-matched filter, chip totals, sequential in-block
+// 96 units (128 where 48 / G divides 64: then every lane of a wave owns a unit, 20, 10 and 2 Msps), |.|^2 staged straight into LDS ring rows, phase A (pulse-matched filter, chip totals, sequential in-block
 // scans) FE4 lag units ahead of phase B (reference level + first-stage test), a candidate bitmap (R bits per unit) and
 // sparse bb / reference-level runs around candidates as the only outputs.  What changes with G > 1:
 //   * the in-chip prefix / suffix chains restart at every chip of the unit; the chip before a unit's first chip belongs
@@ -602,11 +602,12 @@ static int fe4_g_of(int spc)
     case 1: return 24;      //  2 Msps: 24 samples per lane
     case 2: return 16;      //  4 Msps: 32
     case 4: return 8;       //  8 Msps: 32
+    case 5: return 6;       // 10 Msps: 30
     case 8: return 4;       // 16 Msps: 32
     case 10: return 3;      // 20 Msps: 30
     case 16: return 2;      // 32 Msps: 32
     case 20: return 1;      // 40 Msps: 20
-    default: return 0;      // (64 Msps: am_k_fe3; everything else: the tile kernel or the rate-generic kernels)
+    default: return 0;      // (64 Msps: am_k_fe3; everything else: the rate-generic kernels)
     }
 }
 int am_fe4_supported(int spc) { return fe4_g_of(spc) != 0 ? 1 : 0; }
@@ -688,6 +689,7 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
     case 1: return fe4_launch<1, 24>(a, steps_per_wg, s);
     case 2: return fe4_launch<2, 16>(a, steps_per_wg, s);
     case 4: return fe4_launch<4, 8>(a, steps_per_wg, s);
+    case 5: return fe4_launch<5, 6>(a, steps_per_wg, s);
     case 8: return fe4_launch<8, 4>(a, steps_per_wg, s);
     case 10: return fe4_launch<10, 3>(a, steps_per_wg, s);
     case 16: return fe4_launch<16, 2>(a, steps_per_wg, s);

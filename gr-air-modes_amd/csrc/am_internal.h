@@ -59,7 +59,7 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
                          unsigned *steps_per_wg, hipStream_t s);
 /* the same for rates below 64 Msps (am_fe4.hip): a lane takes a unit of G chips = am_fe4_unit(spc) samples, a bitmap word
  * holds that many positions: bit b of word w = array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); two segments
- * (waves) of am_fe4_words(spc) words per step: 64 at 20 and 2 Msps, 48 otherwise */
+ * (waves) of am_fe4_words(spc) words per step: 64 at 20, 10 and 2 Msps, 48 otherwise */
 int am_fe4_supported(int spc);
 unsigned am_fe4_unit(int spc);
 unsigned am_fe4_words(int spc);

@@ -1976,7 +1976,8 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
                       am_packet *__restrict__ packets, const uint32_t *__restrict__ scalars,
                       uint32_t *__restrict__ host_out, const uint32_t *__restrict__ Mp)
 {
-    static_assert(SPC == 1 || SPC % 2 == 0, "pairs of samples per 16-byte load (1 sample per chip: no filter, the launcher passes use_pmf = 0)");
+    // (any SPC: a lane's window of SPC samples starts at either parity -- SPC / 2 + 1 16-byte loads cover it; 1 sample per chip:
+    // no filter, the launcher passes use_pmf = 0)
     constexpr int HEAD = 128;                                 // chips of a short packet: 16 + 2 * 56
     __shared__ float sb[AM_BURST];
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1);
@@ -2060,7 +2061,7 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
     // workgroups of 256 threads per CU: what the instantiation's registers allow (five at 32 samples per chip, where a lane
     // holds a 34-sample window; eight at one or two samples per chip, where the kernel is a chain of memory round trips per
     // hit and more hits in flight is all that helps), asked of the runtime once per device and instantiation
-    static std::atomic<int> per_cu[64][8];
+    static std::atomic<int> per_cu[64][9];
     int dev = 0;
     (void)hipGetDevice(&dev);
     auto resident_for = [&](const void *kernel, int slot) -> uint32_t {
@@ -2088,6 +2089,7 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
     case 10: AM_XS_IQ(10, 3); break;
     case 8: AM_XS_IQ(8, 4); break;
     case 4: AM_XS_IQ(4, 5); break;
+    case 5: AM_XS_IQ(5, 8); break;
     case 2: AM_XS_IQ(2, 6); break;
     case 1: AM_XS_IQ(1, 7); break;
     default: return hipErrorInvalidValue;

@@ -239,10 +239,9 @@ def test_streaming_and_tile_front_ends_agree(emu_lib, monkeypatch):
     bad = pc.nonfinite_stream(64e6, 400000)
     pc.check_front_ends_agree(emu_lib, 64e6, bad, monkeypatch)
     # the other rates: the several-chips-per-lane streaming kernel (am_k_fe4) and the tile kernel, non-finite samples in
-    # interior steps / tiles; 10 Msps (5 samples per chip) has no streaming kernel
-    for rate in (20e6, 4e6, 2e6):
+    # interior steps / tiles (10 Msps: 5 samples per chip, units of 6 chips)
+    for rate in (20e6, 10e6, 4e6, 2e6):
         pc.check_front_ends_agree(emu_lib, rate, pc.nonfinite_stream(rate, 150000), monkeypatch)
-    pc.check_front_ends_agree(emu_lib, 10e6, pc.nonfinite_stream(10e6, 150000), monkeypatch, expect_streaming=False)
 
 
 def test_streaming_front_end_unaligned_and_short_inputs(emu_lib, monkeypatch):
@@ -299,7 +298,8 @@ def test_batches_in_flight_single_host_thread(emu_lib):
 
 @pytest.mark.parametrize("rate,n,lam,pmf,chunks", [(64e6, 900000, 20000.0, True, None), (64e6, 700000, 20000.0, False, None),
                                                     (64e6, 900000, 20000.0, True, [250001, 600000]),
-                                                    (20e6, 500000, 5000.0, True, None), (2e6, 200000, 2000.0, True, None)])
+                                                    (20e6, 500000, 5000.0, True, None), (2e6, 200000, 2000.0, True, None),
+                                                    (10e6, 300000, 8000.0, True, [100001, 200000])])
 def test_production_stages(emu_lib, rate, n, lam, pmf, chunks):
     """Candidate records, bursts and tags of the kernels am_process_iq runs (the streaming front ends: am_k_fe3 at 64 Msps,
     am_k_fe4 at 20 and 2 Msps) against the oracle and, where built, the reference's own C++."""

@@ -58,7 +58,7 @@ def main():
     subprocess.check_call(["make", "-s", "-C", emu, "libairmodes_emu_rare.so"])
     libs = [_capi.Library(os.path.join(emu, "libairmodes_emu.so")), _capi.Library(os.path.join(emu, "libairmodes_emu_rare.so"))]
     rng = np.random.default_rng(args.seed)
-    rates = (2e6, 2e6, 4e6, 8e6, 10e6, 16e6, 20e6, 20e6, 32e6, 40e6, 64e6, 64e6)
+    rates = (2e6, 2e6, 4e6, 8e6, 10e6, 10e6, 16e6, 20e6, 20e6, 32e6, 40e6, 64e6, 64e6)
     for case in range(args.cases):
         rate = float(rng.choice(rates))
         spc = int(rate / 2e6)
