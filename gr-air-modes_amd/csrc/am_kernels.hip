@@ -1608,10 +1608,16 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 // entered at `cur`; the first candidate of chunk r at or after cur says where the scan leaves the chunk.  Writes the
 // array coordinate at which the scan enters chunk `rank` (cur0_out) and flags[0] |= 1 if some table did not fit its
 // message (the caller then repeats the step with full-size tables).
-__global__ void am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
-                                 uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags)
+__global__ void __launch_bounds__(AM_WAVE)
+am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
+                 uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // One wave.  The chain over the chunks is sequential (where chunk r is entered depends on where chunk r - 1 was left),
+    // but inside a table the first entry at or after `cur` is found 64 entries per memory round trip (positions ascend: a
+    // ballot) -- one thread stepping through a table entry by entry paid a dependent load per entry, and chunk 7 of 8 waits
+    // for seven tables.
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x & (AM_WAVE - 1);
     uint64_t cur = 0;
     uint32_t bad = 0;
     for (uint32_t r = 0; r < rank; ++r) {
@@ -1619,12 +1625,22 @@ __global__ void am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_
         const uint64_t n = m[0].pos;
         if (n > cap || m[0].exit != 0) { bad = 1; break; }
         const am_shard_exit *t = m + 1;
-        uint64_t i = 0;
-        while (i < n && t[i].pos < cur) ++i;
-        if (i < n) cur = t[i].exit > cur ? t[i].exit : cur;  // no candidate left: the scan passes through
+        for (uint64_t i0 = 0; i0 < n; i0 += AM_WAVE) {                       // (uniform)
+            const uint64_t i = i0 + (uint64_t)lane;
+            const bool here = i < n && t[i].pos >= cur;
+            const unsigned long long hit = __ballot(here);
+            if (hit) {
+                const uint64_t k = i0 + (uint64_t)(__ffsll((long long)hit) - 1);
+                const uint64_t ex = t[k].exit;                                // (every lane reads the same entry)
+                cur = ex > cur ? ex : cur;
+                break;
+            }
+        }                                                                     // (no candidate left: the scan passes through)
     }
-    for (uint32_t r = rank; r < world && !bad; ++r)           // (every rank must take the same decision)
+    for (uint32_t r = rank + (uint32_t)lane; r < world && !bad; r += AM_WAVE) // (every rank must take the same decision)
         if (msgs[(size_t)r * (cap + 1u)].pos > cap || msgs[(size_t)r * (cap + 1u)].exit != 0) bad = 1;
+    bad = __ballot(bad != 0u) != 0ull ? 1u : 0u;
+    if (lane != 0) return;
     uint64_t rel = cur > base_abs ? cur - base_abs : 0;
     if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
     *cur0_out = (uint32_t)rel;
@@ -1634,7 +1650,7 @@ __global__ void am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
                                  uint32_t *cur0_out, uint32_t *flags, hipStream_t s)
 {
-    hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(1), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags);
+    hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags);
     return hipGetLastError();
 }
 
