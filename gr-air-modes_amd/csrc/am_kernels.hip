@@ -489,7 +489,8 @@ am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__
     if (seg >= nseg) return;                                 // (wave-uniform; no workgroup barrier below)
     // every load the wave may need goes out at once (one memory round trip; written as count -> offset -> word ->
     // the two words before, each behind the branch on the one before it, it was four -- which, measured, makes no
-    // difference to the kernel's 15 us: they go to its 10 400 workgroups of four single-segment waves)
+    // difference to the kernel's 15 us: they go to its 10 400 workgroups of four single-segment waves.  Eight segments per wave
+    // with all their loads in one round trip -- 1 300 workgroups -- was measured in round 3: 18.5 us.)
     const int lane = threadIdx.x & (AM_WAVE - 1);
     // nw words per segment (one wave of the front end: 48, or 64 where all of its lanes own a unit)
     const size_t w = (size_t)seg * nw + (uint32_t)lane;
