@@ -313,8 +313,8 @@ int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
  * the last scan refined and chained.  Negative error code on a null context. */
 long long am_last_num_candidates(const am_ctx *ctx);
 
-/* Diagnostic: which front-end kernel the last scan ran -- 3 = streaming kernel (am_k_fe3: persistent workgroups, LDS
- * rings, sparse bb around candidates), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan
+/* Diagnostic: which front-end kernel the last scan ran -- 3 = a streaming kernel (am_k_fe3 at 64 Msps, am_k_fe4 at 2, 4, 8,
+ * 10, 16, 20, 32 and 40 Msps: persistent workgroups, LDS rings, sparse bb around candidates), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan
  * yet.  Results do not depend on it (test builds can keep the tile kernel; tests compare both). */
 int am_last_frontend(const am_ctx *ctx);
 
