@@ -139,7 +139,7 @@ struct am_ctx {
     // time-sharded mode: the chunk whose bb/avg are resident
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
     bool shard_ready = false;
-    const uint32_t *cur0_dev = nullptr; // set around chain_finish: the scan's start position is read on the device (time shards)
+    const am_entry_src *entry_src = nullptr; // set around chain_finish: the scan's start position is composed on the device (time shards)
     const uint32_t *flag_src = nullptr; // ... and this device word is handed to the host with the completion ticket (pin_scalars[4])
 
     // pinned host memory the tail kernels write into directly
@@ -652,7 +652,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                     (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
                                     own_hi, (uint32_t *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
                                     next_epoch(c), (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp,
-                                    c->cur0_dev));
+                                    c->entry_src));
     const bool keep_dev = keep_bursts || c->keep_tags;       // the bursts and their tags leave the kernel
     if (keep_dev) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
@@ -1446,8 +1446,9 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
         const uint32_t *Mp = c->spec_now ? c->Mdev : nullptr;
         int rc = chain_prepare(c, M, true, Mp);
         if (rc != AM_OK) return rc;
-        HIPCHK(c, hipMemsetAsync(msg_dev, 0, sizeof(am_shard_exit), c->stream));       // (no candidate: count 0)
         n_dev = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(M, lead + 1), msg_cap);
+        if (!n_dev)                                          // no candidate: count 0 (otherwise the table kernel writes the header:
+            HIPCHK(c, hipMemsetAsync(msg_dev, 0, sizeof(am_shard_exit), c->stream));   //  a fill is a dispatch of its own, ~4 us)
         if (n_dev)
             HIPCHK(c, am_launch_chain_exit_table((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, n_dev,
                                                  (uint32_t)std::min<uint64_t>(lead_end - out_abs0, 0xFFFFFFFFull),
@@ -1582,11 +1583,12 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     uint64_t em = 0;
     ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
     uint32_t *cur0_dev = (uint32_t *)c->scalars.p + 4, *flag_dev = (uint32_t *)c->scalars.p + 5;
-    // the entry position of this chunk, composed from everybody's exit tables on the device
-    HIPCHK(c, hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), c->stream));
-    HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev, c->stream));
+    // the entry position of this chunk is composed from everybody's exit tables on the device: by the block walk itself, or
+    // (nothing to slice here) by a launch of its own -- the other ranks must still learn whether a table overflowed: it did
+    // so on every rank alike
+    // (the flag is written, 0 or 1, by whichever kernel composes the entry: no fill in front of it)
     if (c->chain_M == 0 || !flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base) {
-        // nothing to slice here; the other ranks must still learn whether a table overflowed: it did so on every rank alike
+        HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev, c->stream));
         uint32_t f = 0;
         HIPCHK(c, hipMemcpyAsync(&f, flag_dev, sizeof(f), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1597,10 +1599,12 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     uint32_t fin = 0;
     const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
-    c->cur0_dev = cur0_dev;
+    am_entry_src es;
+    es.msgs = msgs_dev; es.world = world; es.rank = rank; es.cap = (uint32_t)msg_cap; es.base_abs = c->shard_base; es.flags = flag_dev;
+    c->entry_src = &es;
     c->flag_src = flag_dev;
     int rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
-    c->cur0_dev = nullptr;
+    c->entry_src = nullptr;
     c->flag_src = nullptr;
     if (rc == AM_RETRY_EXACT) { c->pending.clear(); *redo = 1; return AM_OK; }   // more candidates than the capacity the scan was launched for
     if (rc != AM_OK) return rc;

@@ -148,11 +148,19 @@ size_t am_chain_scratch_bytes(uint32_t M);
 hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t *jump0,
                                    uint32_t *scratch, int want_last, hipStream_t s, const uint32_t *Mp = nullptr,
                                    int have_succ = 0);   /* have_succ: jump0[] was written by am_k_cand */
+/* where the greedy scan of a time shard starts: composed on the device from everybody's exit tables (am_k_cblk_walk) */
+struct am_entry_src {
+    const am_shard_exit *msgs;      // null: the start position comes from the host
+    uint32_t world, rank, cap;
+    uint64_t base_abs;              // absolute index of the chunk's array coordinate 0
+    uint32_t *flags;                // flags[0] = 1: repeat the step
+};
+
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch, uint32_t *scalars, int want_resume,
-                                 hipStream_t s, const uint32_t *Mp = nullptr, const uint32_t *cur0_dev = nullptr);
+                                 hipStream_t s, const uint32_t *Mp = nullptr, const am_entry_src *entry_src = nullptr);
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,

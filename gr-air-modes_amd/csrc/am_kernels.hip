@@ -1116,6 +1116,43 @@ __device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint16_t
 #define AM_KEEP_VGPR(x) ((void)0)
 #endif
 
+// Time shards, device-side composition of the exit tables (am_shard_entry on the host does the same): msgs = `world`
+// messages of 1 + cap entries each, entry 0 = header {count, overflow}, then the table.  The scan starts at sample 0; chunk r
+// is entered at `cur`; the first candidate of chunk r at or after cur says where the scan leaves the chunk.  Returns the
+// absolute position at which the scan enters chunk `rank`; *bad = 1 if some table did not fit its message or some scan met
+// more candidates than its capacity (the caller then repeats the step on the synchronous path: every rank alike).
+// ONE WAVE calls it (all 64 lanes).  The chain over the chunks is sequential (where chunk r is entered depends on where chunk
+// r - 1 was left), but inside a table the first entry at or after `cur` is found 64 entries per memory round trip (positions
+// ascend: a ballot) -- one thread stepping through a table entry by entry paid a dependent load per entry, and chunk 7 of 8
+// waits for seven tables.
+__device__ __forceinline__ uint64_t am_shard_entry_wave(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank,
+                                                        uint32_t cap, int lane, uint32_t *bad_out)
+{
+    uint64_t cur = 0;
+    uint32_t bad = 0;
+    for (uint32_t r = 0; r < rank; ++r) {
+        const am_shard_exit *m = msgs + (size_t)r * (cap + 1u);
+        const uint64_t n = m[0].pos;
+        if (n > cap || m[0].exit != 0) { bad = 1; break; }
+        const am_shard_exit *t = m + 1;
+        for (uint64_t i0 = 0; i0 < n; i0 += AM_WAVE) {                       // (uniform)
+            const uint64_t i = i0 + (uint64_t)lane;
+            const bool here = i < n && t[i].pos >= cur;
+            const unsigned long long hit = __ballot(here);
+            if (hit) {
+                const uint64_t k = i0 + (uint64_t)(__ffsll((long long)hit) - 1);
+                const uint64_t ex = t[k].exit;                                // (every lane reads the same entry)
+                cur = ex > cur ? ex : cur;
+                break;
+            }
+        }                                                                     // (no candidate left: the scan passes through)
+    }
+    for (uint32_t r = rank + (uint32_t)lane; r < world && !bad; r += AM_WAVE) // (every rank must take the same decision)
+        if (msgs[(size_t)r * (cap + 1u)].pos > cap || msgs[(size_t)r * (cap + 1u)].exit != 0) bad = 1;
+    *bad_out = __ballot(bad != 0u) != 0ull ? 1u : 0u;
+    return cur;
+}
+
 // entry[b] = node at which the scan that starts at position cur0 enters block b, AM_CB_NONE if it
 // jumps over the block.  scalars[0] = cur0 (the emit kernel raises it to the resume position),
 // scalars[1] = 0.
@@ -1129,10 +1166,25 @@ __global__ void __launch_bounds__(1024)
 am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ exitnode,
                const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t cur0_host,
                uint32_t *__restrict__ entry, uint32_t *__restrict__ scalars, const uint32_t *__restrict__ Mp,
-               const uint32_t *__restrict__ cur0_dev)
+               am_entry_src es)
 {
     const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t cur0 = cur0_dev ? *cur0_dev : cur0_host;   // (time shards: the entry position was composed on the device)
+    // time shards: the position at which the scan enters this chunk is composed here, from everybody's exit tables, by the
+    // first wave -- while the other waves fetch the link table (a launch of its own cost 4.4 us + the gap behind it)
+    __shared__ uint32_t cur0_s;
+    if (es.msgs) {
+        if (threadIdx.x < AM_WAVE) {
+            uint32_t bad = 0;
+            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad);
+            if (threadIdx.x == 0) {
+                uint64_t rel = cur > es.base_abs ? cur - es.base_abs : 0;
+                if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
+                cur0_s = (uint32_t)rel;
+                es.flags[0] = bad;                           // (written either way: nobody has to clear it first)
+            }
+        }
+    } else if (threadIdx.x == 0)
+        cur0_s = cur0_host;
 #if defined(AM_WALK_DEBUG)
     int wdbg[5] = {0, 0, 0, 0, 0};
     long long wclk[5] = {0, 0, 0, 0, 0};
@@ -1153,11 +1205,13 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
     const uint32_t hi = (lo + stride < M) ? lo + stride : M;
     uint32_t p_hi = 0, p_lo = 0;
     if (stride && lo < M) { p_hi = pos[hi - 1u]; p_lo = lo ? pos[lo - 1u] : 0u; }
-    if (threadIdx.x == 0) { seg = M; root_s = M; scalars[0] = cur0; scalars[1] = 0u; }
+    if (threadIdx.x == 0) { seg = M; root_s = M; }
     am_cblk_load_links(lnk, headlink, total);
     for (uint32_t bb = threadIdx.x; bb < nblk; bb += blockDim.x) ent[bb] = (uint16_t)AM_CB_END;
     for (uint32_t gg = threadIdx.x; gg < ngrp; gg += blockDim.x) gin[gg] = (uint16_t)AM_CB_END;
     __syncthreads();
+    const uint32_t cur0 = cur0_s;
+    if (threadIdx.x == 0) { scalars[0] = cur0; scalars[1] = 0u; }
     if (stride && lo < M && p_hi >= cur0 && (lo == 0 || p_lo < cur0)) seg = lo;
     __syncthreads();
     for (uint32_t g = seg + threadIdx.x; g < M && g < seg + stride; g += blockDim.x)
@@ -1272,10 +1326,30 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
                 if (term || tail) { header->pos = term ? i + 1u : (M > n ? n + 1u : nr); header->exit = over; }
             }
     }
-    HIP_DYNAMIC_SHARED(uint16_t, lnk);
-    am_cblk_load_links(lnk, headlink, nblk * headw);
+    HIP_DYNAMIC_SHARED(uint16_t, lnk);         // [nblk * headw (+pad to 8)] links | [ngrp * headw] group exits
+    const uint32_t total = nblk * headw;
+    const uint32_t ngrp = (nblk + AM_CB_GROUP - 1u) / AM_CB_GROUP;
+    uint16_t *gex = lnk + ((total + 7u) & ~7u);
+    am_cblk_load_links(lnk, headlink, total);
     __syncthreads();
     const uint32_t hs = headw ? (uint32_t)(31 - __clz((int)headw)) : 0u, hm = headw - 1u;   // headw = 2^hs
+    // group exits, as in am_k_cblk_walk: the slot reached from head slot h of group gi's first block once the orbit is past
+    // the group, or the slot inside the group whose link is not a slot (END / OUT).  Every entry's orbit runs to the end of
+    // the chunk: block by block that was a dependent LDS read per block (189 at the bench density), through this table it
+    // is at most AM_CB_GROUP - 1 hops to the next group's first block and one read per group from there.
+    for (uint32_t idx = threadIdx.x; idx < ngrp * headw; idx += blockDim.x) {
+        const uint32_t gi = idx >> hs, h = idx & hm;
+        const uint32_t limit = (gi + 1u) * AM_CB_GROUP;      // first block of the next group
+        uint32_t slot = ((gi * AM_CB_GROUP) << hs) + h;
+        for (int hop = 0; hop < AM_CB_GROUP; ++hop) {        // (a link leads to a later block: <= AM_CB_GROUP hops)
+            const uint32_t nx = lnk[slot];
+            if (nx >= AM_CB_OUT) break;
+            slot = nx;
+            if ((slot >> hs) >= limit) break;
+        }
+        gex[idx] = (uint16_t)slot;
+    }
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         am_shard_exit t;
         if (i >= M) {                                        // (capacity launch) end marker: "no candidate here"
@@ -1297,7 +1371,20 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
                 const uint32_t kb = g / AM_CB, ki = g % AM_CB;
                 if (ki >= headw) { g = __builtin_nontemporal_load(&exitnode[g]); continue; }
                 uint32_t slot = (kb << hs) + ki, nx;
-                while ((nx = lnk[slot]) < AM_CB_OUT) slot = nx;              // one LDS read per block
+                for (;;) {
+                    const uint32_t b = slot >> hs;
+                    if (b % AM_CB_GROUP == 0u) {                             // a group's first block: through the group in one read
+                        const uint32_t gi = b / AM_CB_GROUP;
+                        const uint32_t r = gex[(gi << hs) + (slot & hm)];
+                        slot = r;
+                        if ((r >> hs) >= (gi + 1u) * AM_CB_GROUP) continue;  // past the group
+                        nx = lnk[slot];                                      // stuck inside the group: its link is END or OUT
+                        break;
+                    }
+                    nx = lnk[slot];                                          // (plain hops to the next group's first block)
+                    if (nx >= AM_CB_OUT) break;
+                    slot = nx;
+                }
                 ent = (slot >> hs) * AM_CB + (slot & hm);
                 if (nx == AM_CB_END) break;
                 g = __builtin_nontemporal_load(&exitnode[ent]);
@@ -1567,7 +1654,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch,
-                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const uint32_t *cur0_dev)
+                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src)
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -1576,8 +1663,11 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
         return rc;
     const size_t lds = am_chain_walk_lds_bytes(L.nblk, L.headw);
     if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;   // (more than ~75 000 blocks of 2048 candidates in one scan)
+    am_entry_src es;
+    if (entry_src) es = *entry_src;
+    else { es.msgs = nullptr; es.world = 0; es.rank = 0; es.cap = 0; es.base_abs = 0; es.flags = nullptr; }
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
-                       L.headw, cur0, scratch + L.off_entry, scalars, Mp, cur0_dev);
+                       L.headw, cur0, scratch + L.off_entry, scalars, Mp, es);
     am_emit_args ea;
     ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.emit_max = emit_max; ea.own_lo = own_lo;
     ea.own_hi = own_hi; ea.emit_idx = emit_idx; ea.n_out = n_out; ea.slots = slots; ea.epoch = epoch; ea.scalars = scalars;
@@ -1598,7 +1688,8 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
     if (hipError_t rc = am_chain_walk_lds(reinterpret_cast<const void *>(&am_k_cblk_exit_table), attr_set);
         rc != hipSuccess)
         return rc;
-    const size_t lds = ((size_t)L.nblk * L.headw + 8) * sizeof(uint16_t);
+    const size_t lds = am_chain_walk_lds_bytes(L.nblk, L.headw);          // (links + group exits: the walk's layout holds both)
+    if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
                        reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp, header);
     return hipGetLastError();
@@ -1613,39 +1704,15 @@ __global__ void __launch_bounds__(AM_WAVE)
 am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
                  uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags)
 {
-    // One wave.  The chain over the chunks is sequential (where chunk r is entered depends on where chunk r - 1 was left),
-    // but inside a table the first entry at or after `cur` is found 64 entries per memory round trip (positions ascend: a
-    // ballot) -- one thread stepping through a table entry by entry paid a dependent load per entry, and chunk 7 of 8 waits
-    // for seven tables.
+    // (a launch of its own only where nothing is left to slice: otherwise the block walk composes the entry itself)
     if (blockIdx.x != 0) return;
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    uint64_t cur = 0;
     uint32_t bad = 0;
-    for (uint32_t r = 0; r < rank; ++r) {
-        const am_shard_exit *m = msgs + (size_t)r * (cap + 1u);
-        const uint64_t n = m[0].pos;
-        if (n > cap || m[0].exit != 0) { bad = 1; break; }
-        const am_shard_exit *t = m + 1;
-        for (uint64_t i0 = 0; i0 < n; i0 += AM_WAVE) {                       // (uniform)
-            const uint64_t i = i0 + (uint64_t)lane;
-            const bool here = i < n && t[i].pos >= cur;
-            const unsigned long long hit = __ballot(here);
-            if (hit) {
-                const uint64_t k = i0 + (uint64_t)(__ffsll((long long)hit) - 1);
-                const uint64_t ex = t[k].exit;                                // (every lane reads the same entry)
-                cur = ex > cur ? ex : cur;
-                break;
-            }
-        }                                                                     // (no candidate left: the scan passes through)
-    }
-    for (uint32_t r = rank + (uint32_t)lane; r < world && !bad; r += AM_WAVE) // (every rank must take the same decision)
-        if (msgs[(size_t)r * (cap + 1u)].pos > cap || msgs[(size_t)r * (cap + 1u)].exit != 0) bad = 1;
-    bad = __ballot(bad != 0u) != 0ull ? 1u : 0u;
-    if (lane != 0) return;
+    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad);
+    if (threadIdx.x != 0) return;
     uint64_t rel = cur > base_abs ? cur - base_abs : 0;
     if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
     *cur0_out = (uint32_t)rel;
-    if (bad) flags[0] = 1u;
+    flags[0] = bad;
 }
 
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
