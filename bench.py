@@ -358,7 +358,7 @@ def main():
         fe_avg_ms = float(np.mean(fe_ms)) if fe_ms else 0.0
         achieved = 8.0 * n / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
         fe_kind = ctx.last_frontend()
-        kernel_name = {3: ("am_k_fe3" if spc == 32 else "am_k_fe4<%d,G>" % spc) +
+        kernel_name = {3: ("am_k_fe4<%d,G>" % spc) +
                           " (streaming fused |iq|^2 + PMF + reference level + preamble detection, sparse outputs)",
                        2: "am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc}.get(fe_kind, "am_k_frontend")
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
@@ -371,16 +371,16 @@ def main():
             # the counters belong to ONE version of the kernel: the file carries the hash of the kernel's source it was
             # measured on, and a kernel that changed since reports no traffic rather than somebody else's
             import hashlib
-            with open(os.path.join(ROOT, "gr-air-modes_amd", "csrc", t.get("kernel_source", "am_fe3.hip")), "rb") as kf:
+            with open(os.path.join(ROOT, "gr-air-modes_amd", "csrc", t.get("kernel_source", "am_fe4.hip")), "rb") as kf:
                 sha = hashlib.sha256(kf.read()).hexdigest()[:16]
             if t.get("workload") == workload and args.seconds is None and args.lam is None and kernel_name.startswith(t.get("kernel", "?")):
                 if t.get("kernel_source_sha16") == sha:
                     traffic = t["traffic_bytes"]
                     traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; %s sha %s)" % (
-                        t.get("kernel_source", "am_fe3.hip"), sha)
+                        t.get("kernel_source", "am_fe4.hip"), sha)
                 else:
                     traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
-                        t.get("kernel_source", "am_fe3.hip"), t.get("kernel_source_sha16"), sha)
+                        t.get("kernel_source", "am_fe4.hip"), t.get("kernel_source_sha16"), sha)
         par = {"single": "single GPU", "replicas": "%d independent receivers, one per GPU, no collective" % world,
                "sharded": "time-chunk shards x%d, RCCL halo exchange + scan exit-table all-gather" % world}[mode]
         res = {

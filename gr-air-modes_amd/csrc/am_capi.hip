@@ -93,7 +93,7 @@ struct am_ctx {
     bool keep_tags = false;       // AM_F_KEEP_TAGS of the call in progress: bursts + tags of its hits stay for am_fetch_tags
     uint64_t rec_base = 0;        // absolute index of array coordinate 0 of the resident records (am_fetch_candidates)
     bool poison = false;          // (test builds: AIRMODES_POISON=1) NaN-fill the sparse bb / reference-level arrays before every scan
-    bool allow_fe3 = true;        // (test builds: AIRMODES_FE=2) keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
+    bool allow_stream = true;        // (test builds: AIRMODES_FE=2) keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
     // extraction recomputes from these samples (they must stay valid until the scan's hits are sliced)
     bool bb_sparse = false;
@@ -119,7 +119,7 @@ struct am_ctx {
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
         jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y, wgmax;
-    uint32_t fe3_vspan = 0, fe3_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
+    uint32_t fe_vspan = 0, fe_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
     uint32_t fe_lag = 0, fe_wbits = 32, fe_segw = 48;  // ... its bitmap: positions behind (lag), per word, words per segment
     DevBuf lb_seg, lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
@@ -413,7 +413,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             uint8_t *late = mode == 3 ? (uint8_t *)c->energy.p : nullptr;
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
                                        nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp, late,
-                                       (const float *)c->wgmax.p, c->fe3_vspan, c->fe3_nv));
+                                       (const float *)c->wgmax.p, c->fe_vspan, c->fe_nv));
             ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
             HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
                                      (uint32_t *)c->off_local.p, nullptr, (double *)c->energy.p, M,
@@ -467,48 +467,11 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         return run_candidates(c, bb, avg, j0, j1, M_out);
     }
     c->scan_src = src; c->scan_src_abs0 = src_abs0; c->scan_src_abs1 = src_abs1;
-    if (!avg && c->allow_fe3 && am_fe4_supported(c->spc)) {
-        // streaming kernel for the rates below 64 Msps (several chips per lane): same outputs as am_k_fe3 below
-        const unsigned ns = am_fe4_steps((long long)out_n, c->spc);
-        const unsigned nwv = 2;
-        ENSURE(c, c->bits, ((size_t)ns * am_fe4_words(c->spc) * nwv + 64) * sizeof(uint32_t));
-        ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
-        ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
-        ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
-        ENSURE(c, c->wgmax, ((size_t)ns + 8) * sizeof(float));
-        unsigned nsteps = 0, spw = 1;
-        if (c->poison) {
-            HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
-            HIPCHK(c, hipMemsetAsync(c->avg.p, 0xFF, out_n * sizeof(float), c->stream));
-        }
-        HIPCHK(c, am_launch_fe4(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
-                                (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
-                                (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
-                                (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream));
-        c->fe3_vspan = spw * am_fe4_tile(c->spc);
-        c->fe3_nv = (nsteps + spw - 1) / spw;
-        c->fe_lag = am_fe4_lag(c->spc);
-        c->fe_wbits = am_fe4_unit(c->spc);
-        c->fe_segw = am_fe4_words(c->spc);
-        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-        c->dom_timed = true;
-        c->bb_sparse = true;
-        c->last_fe = 3;
-        const uint64_t endj3 = src_abs1 > out_abs0 ? src_abs1 - out_abs0 : 0;
-        uint32_t cap3 = 0;
-        if (may_speculate && c->allow_spec && c->spec_density > 0.0) {
-            const double npos = (double)(j1 - j0);
-            const double want = c->spec_density * npos * 1.25 + c->spec_floor;
-            cap3 = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
-        }
-        return run_refine(c, bb, (const float *)c->avg.p, nsteps * nwv, 0, 3, M_out,
-                          (uint32_t)std::min<uint64_t>(endj3, 0xFFFFFFFFull), cap3);
-    }
-    if (!avg && c->allow_fe3 && am_fe3_supported(c->spc)) {
+    if (!avg && c->allow_stream && am_fe4_supported(c->spc)) {
         // streaming kernel: candidate bitmap + per-(step, wave) counts; bb and the reference level only around candidates
-        const unsigned ns = am_fe3_steps((long long)out_n);
-        const unsigned nwv = am_fe3_waves();
-        ENSURE(c, c->bits, ((size_t)ns * 48 * nwv + 64) * sizeof(uint32_t));
+        const unsigned ns = am_fe4_steps((long long)out_n, c->spc);
+        const unsigned nwv = am_fe4_waves(c->spc);
+        ENSURE(c, c->bits, ((size_t)ns * am_fe4_words(c->spc) * nwv + 64) * sizeof(uint32_t));
         ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
         ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
@@ -519,15 +482,15 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
             HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
             HIPCHK(c, hipMemsetAsync(c->avg.p, 0xFF, out_n * sizeof(float), c->stream));
         }
-        HIPCHK(c, am_launch_fe3(src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
+        HIPCHK(c, am_launch_fe4(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
                                 (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
                                 (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream));
-        c->fe3_vspan = spw * am_fe3_tile();
-        c->fe3_nv = (nsteps + spw - 1) / spw;
-        c->fe_lag = am_fe3_lag();
-        c->fe_wbits = 32;
-        c->fe_segw = 48;
+        c->fe_vspan = spw * am_fe4_tile(c->spc);
+        c->fe_nv = (nsteps + spw - 1) / spw;
+        c->fe_lag = am_fe4_lag(c->spc);
+        c->fe_wbits = am_fe4_unit(c->spc);
+        c->fe_segw = am_fe4_words(c->spc);
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         c->bb_sparse = true;
@@ -805,7 +768,7 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             const char *g = getenv("AIRMODES_GENERIC");
             c->force_generic = g && g[0] == '1';
             const char *fe = getenv("AIRMODES_FE");
-            c->allow_fe3 = !(fe && fe[0] == '2');
+            c->allow_stream = !(fe && fe[0] == '2');
             const char *po = getenv("AIRMODES_POISON");
             c->poison = po && po[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");
@@ -1606,6 +1569,11 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     int rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
     c->entry_src = nullptr;
     c->flag_src = nullptr;
+    // the dominant kernel's event pair of this step's scan (am_shard_scan_async only enqueued): both events lie in front of
+    // the completion ticket chain_finish waited for
+    c->last_dom_ms = 0.0f;
+    if ((rc == AM_OK || rc == AM_RETRY_EXACT) && c->dom_timed &&
+        hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
     if (rc == AM_RETRY_EXACT) { c->pending.clear(); *redo = 1; return AM_OK; }   // more candidates than the capacity the scan was launched for
     if (rc != AM_OK) return rc;
     if (c->pin_scalars[4]) { c->pending.clear(); *redo = 1; return AM_OK; }       // a table did not fit its message

@@ -43,26 +43,16 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
                          float sL, float thr_lin, uint32_t *seg_pos, float *avg_sparse, uint32_t *blk_cnt,
                          unsigned *ntiles, unsigned *tile_len, hipStream_t s);
-/* streaming fused front end (am_fe3.hip; 32 samples per chip): persistent workgroups, LDS rings, sparse outputs.
- * Candidates leave as a bitmap: bit b of word w = array coordinate w*32 + b - am_fe3_lag(); seg_cnt holds the number of
- * candidates per (step, wave): wave w = words 48w .. 48w+47 of a step's 96.  wg_max[g] (nsteps + 8 floats are enough)
- * = the largest bb workgroup g formed, +inf if one was not finite; workgroup g formed the bb of the array coordinates
- * [g * steps_per_wg * tile, (g + 1) * steps_per_wg * tile) (and some before them). */
-int am_fe3_supported(int spc);
-unsigned am_fe3_tile(void);                 /* positions per step (3072) */
-unsigned am_fe3_lag(void);                  /* 288 */
-unsigned am_fe3_waves(void);                /* segments (waves, 48 chips = 48 bitmap words each) per step */
-unsigned am_fe3_steps(long long out_n);
-hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
-                         float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps,
-                         unsigned *steps_per_wg, hipStream_t s);
-/* the same for rates below 64 Msps (am_fe4.hip): a lane takes a unit of G chips = am_fe4_unit(spc) samples, a bitmap word
- * holds that many positions: bit b of word w = array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); two segments
- * (waves) of am_fe4_words(spc) words per step: 64 at 20, 10 and 2 Msps, 48 otherwise */
+/* streaming fused front end (am_fe4.hip): persistent workgroups, LDS rings, sparse outputs.  A lane takes a unit of G chips
+ * = am_fe4_unit(spc) samples (one 32-sample chip at 64 Msps).  Candidates leave as a bitmap, a word per unit: bit b of word w =
+ * array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); seg_cnt holds the number of candidates per (step, wave): a step
+ * has am_fe4_waves(spc) segments of am_fe4_words(spc) words (64 at 64, 20, 10 and 2 Msps, 48 otherwise).  wg_max[g] (nsteps + 8
+ * floats are enough) = the largest bb workgroup g formed, +inf if one was not finite; workgroup g formed the bb of the array
+ * coordinates [g * steps_per_wg * tile, (g + 1) * steps_per_wg * tile) (and some before them). */
 int am_fe4_supported(int spc);
 unsigned am_fe4_unit(int spc);
 unsigned am_fe4_words(int spc);
+unsigned am_fe4_waves(int spc);
 unsigned am_fe4_tile(int spc);
 unsigned am_fe4_lag(int spc);
 unsigned am_fe4_steps(long long out_n, int spc);
@@ -71,7 +61,7 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
                          float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps,
                          unsigned *steps_per_wg, hipStream_t s);
 /* flat candidate positions + dcount from the bitmap; off_local / blk_base = two-level exclusive scan of seg_cnt
- * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals; 2 segments per step) */
+ * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals, or one chained scan: null) */
 hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
                                  const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
                                  uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr, uint32_t wbits = 32,

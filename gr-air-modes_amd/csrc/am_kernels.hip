@@ -473,7 +473,7 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
     }
 }
 
-// Flat candidate positions from the streaming front end's bitmap (am_fe3.hip): one wave per (step, wave) segment,
+// Flat candidate positions from the streaming front end's bitmap (am_fe4.hip): one wave per (step, wave) segment,
 // four segments per workgroup.
 // Word w, bit b = array coordinate wbits*w + b - lag (wbits = 32 at 64 Msps, the unit length of am_k_fe4 otherwise).  dcount
 // needs the distance to the candidate before, capped at spc + 1 <= wbits + 1: the two words in front of a word are all the
@@ -700,7 +700,7 @@ __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_l
 // here in double precision with an error below 2^-47 V.  Hence whenever |D| > 2^-36 V the sign of D IS the reference's
 // comparison; only closer calls (exact ties of quantised or constant input; non-finite samples: V = +inf) repeat the
 // reference's two sequential sums.  V comes from the front end: the largest bb of the workgroup segments the samples
-// lie in (vmax[array coordinate / vspan], am_fe3.hip).  Eight loads and a dozen operations per position instead of
+// lie in (vmax[array coordinate / vspan], am_fe4.hip).  Eight loads and a dozen operations per position instead of
 // 256 convert + add instructions: 31 -> 9 us at the bench density.
 __global__ void __launch_bounds__(256)
 am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,

@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <functional>
+#include <chrono>
 
 struct dim3 {
     unsigned x, y, z;
@@ -44,6 +45,7 @@ static inline long long clock64() { static long long t = 0; return t += 1000; }
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 typedef struct hipemu_stream *hipStream_t;
+struct hipemu_event { double t_ms; };          // launches run synchronously: an event is the wall clock at its record
 typedef struct hipemu_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
@@ -122,16 +124,20 @@ inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSucc
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event{0.0}; return hipSuccess; }
 #define hipEventDisableSystemFence 0x20000000
 #define hipEventDisableTiming 0x2
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
-inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new hipemu_event{0.0}; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t)
+{
+    if (e) e->t_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return hipSuccess;
+}
 inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }     // launches run to completion synchronously
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (a && b) ? (float)(b->t_ms - a->t_ms) : 0.0f; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
 
