@@ -12,12 +12,13 @@ N = 1  workload "64msps" (BASELINE.json configs[2]: synthetic 64 Msps IQ, Poisso
        rate (20 000 /s, 87 % airtime) is a stress density; `realistic_density` repeats the measurement at
        2 000 bursts/s in the same run.
 N > 1  configs[3]: one 64 Msps stream time-sharded over the N GPUs, one process per GPU (torch.distributed
-       over RCCL): neighbours' boundary samples travel as point-to-point sends / receives (KB scale), every rank
-       scans its chunk, the scan's exit tables are all-gathered, every rank slices its own hits.  Per-GPU
-       work is fixed as N grows ("weak").  `python bench.py --gpus N` launches the N ranks itself when it is
-       not already running under torch.distributed.run.  `parity` for N > 1: a short stream through the same
-       N-rank code path against the oracle over the whole stream, plus rank 0's full-size packets against
-       the oracle over its chunk and halo.
+       over RCCL): a step is the next N seconds of ONE continuing stream, one second per GPU; every rank's tail
+       travels to the next rank as a point-to-point send / receive (KB scale), every rank scans its chunk, the
+       scan's exit tables are all-gathered, every rank slices its own hits; scan position and sample count
+       cross the steps.  Per-GPU work is fixed as N grows ("weak").  `python bench.py --gpus N` launches the
+       N ranks itself when it is not already running under torch.distributed.run.  `parity` for N > 1: a short
+       stream through the same N-rank receiver in two steps against the oracle over the whole stream, plus
+       rank 0's full-size packets against the oracle over its samples.
        --replicas: configs[4] instead -- N independent receivers (20 Msps each unless --workload says
        otherwise), one per GPU, no collective; aggregate samples/s and packets/s, every rank checked
        against the oracle.
@@ -283,7 +284,9 @@ def main():
             parity = ok
     # ------------------------------------------------------------------------------------------------------------
     else:
-        # time-sharded: rank r owns samples [r*n, (r+1)*n) of one stream of world*n samples
+        # time-sharded: ONE stream; step k hands rank r the samples [k*W*n + r*n, k*W*n + (r+1)*n) (here: the same second of
+        # signal again and again, as if the stream repeated itself).  The receiver is a stream: the scan position, the
+        # undecided tail and the sample count cross the steps (air_modes/sharded.py)
         from air_modes.sharded import ShardedReceiver
         iq = synth.synth_capture(rate, n, lam, seed + rank)[0]
         rx = ShardedReceiver(ctx, rank, world, n, device=dev)
@@ -297,50 +300,56 @@ def main():
             dist.barrier()
         sync()
         t0 = time.perf_counter()
+        npk_steps = 0
         for _ in range(args.steps):
             pk = rx.step()
+            npk_steps += len(pk)
             fe_ms.append(ctx.last_dom_ms())
         sync()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        npk_steps = len(pk) * args.steps
         inflight, nb, per_batch = 1, 1, [len(pk)]
-        # parity, part 1: a short stream through the same N-rank path against the oracle over the WHOLE stream
+        extra["sharded_sync_steps"] = rx.sync_steps
+        # parity, part 1: a short stream through the same N-rank receiver IN TWO STEPS against the oracle over the WHOLE stream
         import oracle
-        ns = max(4 * max(rx.left, rx.right), 30000 * spc)
-        whole = synth.synth_capture(rate, world * ns, lam, 4242)[0]
+        ns = max(4 * rx.halo, 30000 * spc)
+        whole = synth.synth_capture(rate, 2 * world * ns, lam, 4242)[0]
         ctx_s = new_ctx()
         rx_s = ShardedReceiver(ctx_s, rank, world, ns, device=dev)
-        rx_s.chunk.copy_(torch.from_numpy(whole[rank * ns:(rank + 1) * ns].copy().view(np.float32)))
-        mine = rx_s.step()
+        mine = []
+        for k in range(2):
+            a = (k * world + rank) * ns
+            rx_s.chunk.copy_(torch.from_numpy(whole[a:a + ns].copy().view(np.float32)))
+            mine.append(rx_s.step(flush=(k == 1)))
         if world > 1:
             parts = [None] * world
-            dist.all_gather_object(parts, mine.tobytes())
-            got = np.concatenate([np.frombuffer(p, _capi.PACKET_DTYPE) for p in parts])
+            dist.all_gather_object(parts, [m.tobytes() for m in mine])
+            got = np.concatenate([np.frombuffer(parts[r][k], _capi.PACKET_DTYPE) for k in range(2) for r in range(world)])
         else:
-            got = mine
+            got = np.concatenate(mine)
         parity_small = bool(np.array_equal(got, oracle.demod(whole, rate, 7.0, True)))
-        # part 2: rank 0's full-size packets against the oracle over its chunk + the halo it received from rank 1
+        # part 2: the full-size chunk as a finite stream of its own (flush): rank 0's packets against the oracle over its samples
+        rx.reset()
+        pk0 = rx.step(flush=True)
         parity_rank0 = None
         if rank == 0:
-            hl, hr = rx.left, rx.right
-            view = rx._buf[hl * 2:(hl + n + (hr if world > 1 else 0)) * 2].cpu().numpy().view(np.complex64)
-            want = oracle.demod(view, rate, 7.0, True) if world > 1 else oracle.demod(view, rate, 7.0, True)
+            want = oracle.demod(iq, rate, 7.0, True)
             if world > 1:
-                # the oracle saw a stream that ends after the halo: packets of this chunk are those the scan reaches
-                # before it leaves the chunk -- a prefix; what follows starts in the halo
-                keep = want[:len(pk)]
-                rest = want[len(pk):]
-                parity_rank0 = bool(np.array_equal(pk, keep) and (len(rest) == 0 or int(rest["sample"][0]) >= n - 2 * spc))
+                # rank 0 decides the positions its own samples let it decide ([0, n - H)); the oracle, whose stream ends
+                # after them, may add hits beyond
+                keep, rest = want[:len(pk0)], want[len(pk0):]
+                parity_rank0 = bool(np.array_equal(pk0, keep) and (len(rest) == 0 or int(rest["sample"][0]) >= n - rx.hold))
             else:
-                parity_rank0 = bool(np.array_equal(pk, want))
+                parity_rank0 = bool(np.array_equal(pk0, want))
         parity = parity_small if parity_rank0 is None else bool(parity_small and parity_rank0)
-        extra["parity_detail"] = {"short_stream_all_ranks": parity_small, "rank0_full_size": parity_rank0,
-                                  "short_stream_samples_per_rank": ns}
+        extra["parity_detail"] = {"short_stream_two_steps_all_ranks": parity_small, "rank0_full_size": parity_rank0,
+                                  "short_stream_samples_per_rank_per_step": ns}
         iq_check = iq
 
     # ------------------------------------------------------------------------------------------------------------
+    fe_local = float(np.mean(fe_ms)) if fe_ms else 0.0
+    fe_ranks = [fe_local]
     if world > 1:
         t = torch.tensor([dt, float(npk_steps)], dtype=torch.float64, device=dev)
         tmax = t.clone()
@@ -349,13 +358,17 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0].item())
         npk_total = int(tsum[1].item())
+        # every rank's average launch duration of the dominant kernel (HIP events on the context's own stream)
+        tk = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tk, torch.tensor([fe_local], dtype=torch.float64, device=dev))
+        fe_ranks = [float(x[0].item()) for x in tk]
     else:
         npk_total = npk_steps
 
     if rank == 0:
         total_samples = world * n * args.steps
         value = total_samples / dt
-        fe_avg_ms = float(np.mean(fe_ms)) if fe_ms else 0.0
+        fe_avg_ms = float(np.mean(fe_ranks))       # (one launch per rank and step, every rank the same n samples: the mean over ranks)
         achieved = 8.0 * n / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
         fe_kind = ctx.last_frontend()
         kernel_name = {3: ("am_k_fe4<%d,G>" % spc) +
@@ -364,7 +377,7 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "current_traffic.json")
-        if mode == "single" and os.path.exists(tj) and not args.emu:
+        if mode in ("single", "sharded") and os.path.exists(tj) and not args.emu:
             with open(tj) as f:
                 t = json.load(f)
             t = t.get(workload, {}) if "workload" not in t else t    # (one entry per workload)
@@ -382,7 +395,7 @@ def main():
                     traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
                         t.get("kernel_source", "am_fe4.hip"), t.get("kernel_source_sha16"), sha)
         par = {"single": "single GPU", "replicas": "%d independent receivers, one per GPU, no collective" % world,
-               "sharded": "time-chunk shards x%d, RCCL halo exchange + scan exit-table all-gather" % world}[mode]
+               "sharded": "time-chunk shards x%d of one continuing stream, RCCL tail exchange + scan exit-table all-gather" % world}[mode]
         res = {
             "metric": "complex samples/sec demodulated (IQ -> Mode-S packet list)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -400,6 +413,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel_ms": fe_avg_ms,
+                         "kernel_ms_per_rank": {"min": min(fe_ranks), "max": max(fe_ranks)},
                          "algorithmic_bytes_per_launch": 8 * n},
         }
         if args.emu:

@@ -10,11 +10,6 @@ import os
 
 import numpy as np
 
-# One hardware queue per stream, if nobody decided otherwise: the HIP runtime multiplexes streams onto 4 queues by default, and
-# two contexts of a Pipe that share one run their kernels one after the other (measured 215 -> 240 GS/s at depth
-# 3).  Read by the runtime when it initialises, so this only helps when this module is imported before the first HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libairmodes_hip.so")
 
@@ -22,6 +17,9 @@ AM_F_DEVICE_IN = 0x1
 AM_F_FLUSH = 0x2
 AM_F_DEVICE_OUT = 0x4
 AM_F_KEEP_TAGS = 0x8
+AM_F_MORE = 0x10
+ABI_VERSION = 2
+SHARD_MSG_HEADER = 2          # header entries of a device-side exit-table message (am_shard_scan_async)
 
 AM_OK, AM_EINVAL, AM_ENODEV, AM_ENOMEM, AM_EHIP, AM_ECAPACITY, AM_ENOTSUP = 0, -1, -2, -3, -4, -5, -6
 
@@ -104,6 +102,9 @@ class Library(object):
         L.am_shard_scan.argtypes = [vp, vp, u64, u64, u64, u32, vp, u64, pu64]
         L.am_shard_entry.argtypes = [vp, vp, vp, u32, vp]
         L.am_shard_resolve.argtypes = [vp, u64, vp, u64, pu64]
+        L.am_shard_entry2.argtypes = [vp, vp, u32, u64, vp, vp]
+        L.am_shard_get_exit.argtypes = [vp, pu64]
+        L.am_shard_set_exit.argtypes = [vp, u64]
         L.am_last_error.restype = C.c_char_p
         L.am_last_error.argtypes = [vp]
         L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
@@ -132,7 +133,7 @@ class Library(object):
         L.am_last_frontend.restype = C.c_int
         L.am_last_frontend.argtypes = [vp]
         self.L = L
-        if L.am_abi_version() != 1:
+        if L.am_abi_version() != ABI_VERSION:
             raise OSError("ABI version mismatch in %s" % path)
 
     # host-side helpers that need no context
@@ -235,9 +236,20 @@ class Context(object):
         """hip_stream (0 / None: the default stream) waits, on the device, for what the context has enqueued so far."""
         self._chk(self.lib.L.am_signal_stream(self._h, C.c_void_p(int(hip_stream) if hip_stream else None)))
 
-    def shard_scan_async(self, dev_ptr, abs_start, abs_end, total_n, msg_ptr, msg_cap, device_in=True):
+    def shard_scan_async(self, dev_ptr, abs_start, abs_end, total_n, msg_ptr, msg_cap, device_in=True, more=False):
+        """msg_ptr: SHARD_MSG_HEADER + msg_cap entries of 16 bytes.  more: the stream goes on beyond total_n (AM_F_MORE)."""
         self._chk(self.lib.L.am_shard_scan_async(self._h, C.c_void_p(int(dev_ptr)), int(abs_start), int(abs_end), int(total_n),
-                                                 AM_F_DEVICE_IN if device_in else 0, C.c_void_p(int(msg_ptr)), int(msg_cap)))
+                                                 (AM_F_DEVICE_IN if device_in else 0) | (AM_F_MORE if more else 0),
+                                                 C.c_void_p(int(msg_ptr)), int(msg_cap)))
+
+    def shard_get_exit(self):
+        """Where the scan left this context's chunk in its last resolved time-shard step (0: none yet)."""
+        v = C.c_uint64(0)
+        self._chk(self.lib.L.am_shard_get_exit(self._h, C.byref(v)))
+        return int(v.value)
+
+    def shard_set_exit(self, pos):
+        self._chk(self.lib.L.am_shard_set_exit(self._h, int(pos)))
 
     def shard_resolve_async(self, msgs_ptr, world, rank, msg_cap, capacity=4096):
         """-> (packets, redo).  redo: nothing was delivered, repeat the step on the synchronous path."""
@@ -380,12 +392,13 @@ class Context(object):
         self._chk(self.lib.L.am_shard_halo(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
-    def shard_scan(self, iq_with_halo, abs_start, abs_end, total_n, device_ptr=None):
+    def shard_scan(self, iq_with_halo, abs_start, abs_end, total_n, device_ptr=None, more=False):
         """Scan chunk [abs_start, abs_end) of a stream of total_n samples; iq_with_halo covers
-        [abs_start - left, abs_end + right) clipped to the stream.  Returns the chunk's exit table."""
-        flags = 0
+        [abs_start - left, abs_end + right) clipped to the stream.  Returns the chunk's exit table.
+        more: the stream goes on beyond total_n (AM_F_MORE: no end-of-stream rule)."""
+        flags = AM_F_MORE if more else 0
         if device_ptr is not None:
-            ptr, flags = int(device_ptr), AM_F_DEVICE_IN
+            ptr, flags = int(device_ptr), flags | AM_F_DEVICE_IN
         else:
             f = _iq_f32(iq_with_halo)
             ptr = f.ctypes.data if f.size else None
@@ -527,15 +540,16 @@ class Uploader(object):
             pass
 
 
-def shard_entries(lib, tables, starts):
-    """am_shard_entry: scan entry position of every chunk from the chunks' exit tables."""
+def shard_entries(lib, tables, starts=None, cur_in=0, with_exits=False):
+    """am_shard_entry2: the position at which the scan enters every chunk (and, with_exits, leaves it), from the chunks' exit
+    tables and the position at which it left the last chunk of the step before (cur_in; 0 at the start of a stream)."""
     n = len(tables)
     tabs = [np.ascontiguousarray(t, EXIT_DTYPE) for t in tables]
     ptrs = (C.c_void_p * n)(*[t.ctypes.data if t.size else None for t in tabs])
     counts = np.array([t.size for t in tabs], np.uint64)
-    st = np.array(starts, np.uint64)
     entry = np.zeros(n, np.uint64)
-    rc = lib.L.am_shard_entry(ptrs, counts.ctypes.data, st.ctypes.data, n, entry.ctypes.data)
+    leave = np.zeros(n, np.uint64)
+    rc = lib.L.am_shard_entry2(ptrs, counts.ctypes.data, n, int(cur_in), entry.ctypes.data, leave.ctypes.data)
     if rc != AM_OK:
-        raise AirModesError(rc, "am_shard_entry")
-    return entry
+        raise AirModesError(rc, "am_shard_entry2")
+    return (entry, leave) if with_exits else entry

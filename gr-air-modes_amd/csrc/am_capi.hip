@@ -117,11 +117,12 @@ struct am_ctx {
 
     // work buffers (grow only)
     DevBuf src, bb, avg, cand_seg, inavg, blk_cnt, blk_off, pos, e, tgt, valid,
-        jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_tot, seg_base,
+        jump, emit_idx, dcount, off_local, blk_tot2, blk_base2, energy, bits, seg_base,
         cblk_cnt, cblk_off, scalars, bursts, tags, packets, crc_pow, recs, cscratch, dc_m1, dc_y, wgmax;
     uint32_t fe_vspan = 0, fe_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
-    uint32_t fe_lag = 0, fe_wbits = 32, fe_segw = 48;  // ... its bitmap: positions behind (lag), per word, words per segment
-    DevBuf lb_seg, lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
+    uint32_t fe_lag = 0, fe_wbits = 32;  // ... its bitmap: positions behind (lag), per word
+    uint32_t fe_nwg = 0, fe_wpw = 0, fe_nwords = 0;   // ... front-end workgroups, bitmap words per workgroup, words in all
+    DevBuf lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
 
     // results of the last scan
@@ -139,6 +140,8 @@ struct am_ctx {
     // time-sharded mode: the chunk whose bb/avg are resident
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
     bool shard_ready = false;
+    bool shard_more = false;            // the resident chunk was scanned with AM_F_MORE: the stream goes on, no end-of-stream rule
+    DevBuf shard_exit;                  // device word: where the scan left this context's chunk in the last resolved step (0: none)
     const am_entry_src *entry_src = nullptr; // set around chain_finish: the scan's start position is composed on the device (time shards)
     const uint32_t *flag_src = nullptr; // ... and this device word is handed to the host with the completion ticket (pin_scalars[4])
 
@@ -210,11 +213,32 @@ int ensure_slots(am_ctx *c, DevBuf &b, size_t n)
 uint32_t next_epoch(am_ctx *c)
 {
     if (++c->lb_epoch == 0) {
-        for (DevBuf *b : {&c->lb_seg, &c->lb_dc, &c->lb_mark})
+        for (DevBuf *b : {&c->lb_dc, &c->lb_mark})
             if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, c->stream);
         c->lb_epoch = 1;
     }
     return c->lb_epoch;
+}
+
+// the small device-side scalar block of a context: [0] resume position, [1] hit flag, [4..5] time-shard entry / overflow flag,
+// zero when it is allocated
+int ensure_scalars(am_ctx *c)
+{
+    if (c->scalars.p) return AM_OK;
+    int rc = ensure(c, c->scalars, 16 * sizeof(uint32_t));
+    if (rc != AM_OK) return rc;
+    if (hipMemsetAsync(c->scalars.p, 0, 16 * sizeof(uint32_t), c->stream) != hipSuccess) return fail(c, AM_EHIP, "hipMemsetAsync");
+    return AM_OK;
+}
+
+// the device word that carries the scan position from one time-shard step to the next: zero when allocated
+int ensure_shard_exit(am_ctx *c)
+{
+    if (c->shard_exit.p) return AM_OK;
+    int rc = ensure(c, c->shard_exit, 2 * sizeof(uint64_t));
+    if (rc != AM_OK) return rc;
+    if (hipMemsetAsync(c->shard_exit.p, 0, 2 * sizeof(uint64_t), c->stream) != hipSuccess) return fail(c, AM_EHIP, "hipMemsetAsync");
+    return AM_OK;
 }
 
 void release(DevBuf &b)
@@ -260,6 +284,7 @@ void reset_stream(am_ctx *c)
     c->carry_n = 0;
     c->shard_ready = false;
     c->tt.clear();            // item offsets restart with the stream
+    if (c->shard_exit.p) (void)hipMemsetAsync(c->shard_exit.p, 0, 2 * sizeof(uint64_t), c->stream);   // the scan starts at sample 0 again
 }
 
 // positions beyond the end of the data read zeros: every bb/avg array carries this pad
@@ -356,15 +381,14 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
     if (nseg == 0) return AM_OK;
     const uint32_t *count_ptr = (const uint32_t *)c->blk_off.p + nseg;       // device-side total
     if (mode == 3) {
-        // many short segments (two per step of the streaming kernel): two-level scan, 2048 counts per workgroup
-        const uint32_t nbs = (nseg + 2047u) / 2048u;
-        ENSURE(c, c->seg_tot, ((size_t)nbs + 1) * sizeof(uint32_t));
-        ENSURE(c, c->seg_base, ((size_t)nbs + 2) * sizeof(uint32_t));
-        if (int rc = ensure_slots(c, c->lb_seg, nbs); rc != AM_OK) return rc;
-        HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg,
-                                         (unsigned long long *)c->lb_seg.p, next_epoch(c), (uint32_t *)c->seg_base.p + nbs,
-                                         c->stream));
-        count_ptr = (const uint32_t *)c->seg_base.p + nbs;
+        // streaming front end: the flat list is laid out from the per-workgroup counts by the gather kernel itself, which also
+        // leaves the total (blk_off[0]); only a scan that must know its count up front adds the counts first
+        count_ptr = (const uint32_t *)c->blk_off.p;
+        if (!(spec_cap && mode >= 2)) {
+            ENSURE(c, c->seg_base, ((size_t)c->fe_nwg + 2) * sizeof(uint32_t));
+            HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->seg_base.p, c->fe_nwg, c->stream));
+            count_ptr = (const uint32_t *)c->seg_base.p + c->fe_nwg;
+        }
     } else
         HIPCHK(c, am_launch_scan_u32((uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p, nseg, c->stream));
     c->ref_bb = bb; c->ref_avg = avg; c->ref_nseg = nseg; c->ref_stride = seg_stride; c->ref_mode = mode;
@@ -373,7 +397,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
     const uint32_t *Mp = nullptr;
     if (spec_cap && mode >= 2) {
         M = spec_cap;                                        // capacity; the kernels clip to *Mp
-        Mp = count_ptr;
+        Mp = count_ptr;                                      // (streaming front end: written by the gather kernel below)
         c->spec_now = true;
         c->Mdev = Mp;
     } else {
@@ -387,20 +411,26 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
         ENSURE(c, c->valid, (size_t)M + 1);
-        if (mode >= 2) {
-            // split refinement: positions -> one verdict (streaming front end) or energy per reachable position -> per-candidate test
+        if (mode == 3) {
+            // streaming front end: candidates arrive as a bitmap; flat positions, then late-peak decisions, quiet zones,
+            // records and the chain's successors in one launch (am_k_refine_late)
+            HIPCHK(c, am_launch_gather_wg((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, c->fe_nwg, c->fe_wpw, c->fe_nwords, M,
+                                          c->fe_lag, c->fe_wbits, (uint32_t *)c->pos.p, (uint32_t *)c->blk_off.p, c->stream));
+            ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
+            HIPCHK(c, am_launch_refine_late(bb, avg, (uint32_t *)c->pos.p, M, c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p,
+                                            (uint32_t *)c->tgt.p, (float *)c->inavg.p, (uint8_t *)c->valid.p,
+                                            (uint32_t *)c->jump.p, c->stream, Mp, (const float *)c->wgmax.p, c->fe_vspan,
+                                            c->fe_nv));
+            c->jump_ready = true;
+        } else if (mode >= 2) {
+            // split refinement behind the tile kernel: positions -> energy per reachable position -> per-candidate test
             const uint32_t nb = (M + 2047u) / 2048u;
             const uint64_t ebound = std::min<uint64_t>((uint64_t)M * (uint64_t)(c->spc + 1), (uint64_t)M + 0xFFFFFFFFull);
             ENSURE(c, c->dcount, ((size_t)M + 1) * sizeof(uint32_t));
             ENSURE(c, c->off_local, ((size_t)M + 1) * sizeof(uint32_t));
             ENSURE(c, c->blk_tot2, ((size_t)nb + 1) * sizeof(uint32_t));
             ENSURE(c, c->blk_base2, ((size_t)nb + 2) * sizeof(uint32_t));
-            ENSURE(c, c->energy, (size_t)(ebound + 2) * (mode == 3 ? 1 : sizeof(double)));
-            if (mode == 3)       // streaming front end: candidates arrive as a bitmap, two segments per step
-                HIPCHK(c, am_launch_gather_bits((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (uint32_t *)c->blk_off.p,
-                                                nullptr, nseg, M, c->spc, c->fe_lag,
-                                                (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp, c->fe_wbits, c->fe_segw));
-            else
+            ENSURE(c, c->energy, (size_t)(ebound + 2) * sizeof(double));
             HIPCHK(c, am_launch_gather_pos((uint32_t *)c->cand_seg.p, seg_stride, (uint32_t *)c->blk_off.p, nseg, M,
                                            c->spc, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, c->stream, Mp));
             // compact index of each candidate's first energy: one chained scan of the counts (global offsets)
@@ -408,17 +438,13 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p, M,
                                              (unsigned long long *)c->lb_dc.p, next_epoch(c), (uint32_t *)c->blk_base2.p + nb,
                                              c->stream, Mp));
-            // behind the streaming front end the late-peak search's comparisons are decided from exact energy differences
-            // (one byte per position); behind the tile kernel the energies themselves are formed
-            uint8_t *late = mode == 3 ? (uint8_t *)c->energy.p : nullptr;
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
-                                       nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp, late,
-                                       (const float *)c->wgmax.p, c->fe_vspan, c->fe_nv));
+                                       nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp));
             ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
             HIPCHK(c, am_launch_cand(bb, avg, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p,
                                      (uint32_t *)c->off_local.p, nullptr, (double *)c->energy.p, M,
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
-                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp, late));
+                                     (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp));
             c->jump_ready = true;
         } else
             HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
@@ -470,10 +496,10 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     if (!avg && c->allow_stream && am_fe4_supported(c->spc)) {
         // streaming kernel: candidate bitmap + per-(step, wave) counts; bb and the reference level only around candidates
         const unsigned ns = am_fe4_steps((long long)out_n, c->spc);
-        const unsigned nwv = am_fe4_waves(c->spc);
-        ENSURE(c, c->bits, ((size_t)ns * am_fe4_words(c->spc) * nwv + 64) * sizeof(uint32_t));
-        ENSURE(c, c->blk_cnt, ((size_t)ns * nwv + 8) * sizeof(uint32_t));
-        ENSURE(c, c->blk_off, ((size_t)ns * nwv + 9) * sizeof(uint32_t));
+        const unsigned wps = am_fe4_words(c->spc) * am_fe4_waves(c->spc);     // bitmap words per step
+        ENSURE(c, c->bits, ((size_t)ns * wps + 64) * sizeof(uint32_t));
+        ENSURE(c, c->blk_cnt, ((size_t)ns + 8) * sizeof(uint32_t));           // candidates per front-end workgroup
+        ENSURE(c, c->blk_off, 16 * sizeof(uint32_t));                          // [0]: their total (am_k_gather_wg)
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
         ENSURE(c, c->wgmax, ((size_t)ns + 8) * sizeof(float));
         unsigned nsteps = 0, spw = 1;
@@ -490,7 +516,9 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         c->fe_nv = (nsteps + spw - 1) / spw;
         c->fe_lag = am_fe4_lag(c->spc);
         c->fe_wbits = am_fe4_unit(c->spc);
-        c->fe_segw = am_fe4_words(c->spc);
+        c->fe_nwg = c->fe_nv;
+        c->fe_wpw = spw * wps;
+        c->fe_nwords = nsteps * wps;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         c->dom_timed = true;
         c->bb_sparse = true;
@@ -502,7 +530,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
             const double want = c->spec_density * npos * 1.25 + c->spec_floor;
             cap3 = (uint32_t)std::max<double>(1.0, std::min<double>(want, std::min<double>(npos, 4.0e9)));
         }
-        return run_refine(c, bb, (const float *)c->avg.p, nsteps * nwv, 0, 3, M_out,
+        return run_refine(c, bb, (const float *)c->avg.p, c->fe_nwg, 0, 3, M_out,
                           (uint32_t)std::min<uint64_t>(endj3, 0xFFFFFFFFull), cap3);
     }
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
@@ -545,7 +573,7 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
     if (M == 0) return AM_OK;
     const size_t stride = (size_t)M + 1;
     ENSURE(c, c->jump, stride * sizeof(uint32_t));
-    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    if (int rc = ensure_scalars(c); rc != AM_OK) return rc;
     ENSURE(c, c->cscratch, am_chain_scratch_bytes(M));
     HIPCHK(c, am_launch_chain_prepare((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, (uint32_t *)c->jump.p,
                                       (uint32_t *)c->cscratch.p, want_last ? 1 : 0, c->stream, Mp, c->jump_ready ? 1 : 0));
@@ -816,10 +844,10 @@ void am_destroy(am_ctx *c)
 #endif
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
-                     &c->energy, &c->bits, &c->seg_tot, &c->seg_base, &c->blk_cnt, &c->blk_off,
+                     &c->energy, &c->bits, &c->seg_base, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->jump, &c->emit_idx,
-                     &c->lb_seg, &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev, &c->wgmax};
+                     &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
+                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev, &c->wgmax, &c->shard_exit};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -1273,7 +1301,7 @@ int am_slicer_work(am_ctx *c, const float *bursts, const am_tag *tags, uint64_t 
     ENSURE(c, c->packets, nb * sizeof(am_packet));
     HIPCHK(c, hipMemcpyAsync(c->bursts.p, bursts, nb * AM_BURST * sizeof(float), kind, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tags.p, tags, nb * sizeof(am_tag), kind, c->stream));
-    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    if (int rc = ensure_scalars(c); rc != AM_OK) return rc;
     const uint32_t nb32 = (uint32_t)nb;
     HIPCHK(c, hipMemcpyAsync(c->scalars.p, &nb32, sizeof(nb32), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, am_launch_slice((float *)c->bursts.p, (am_tag *)c->tags.p, (const uint32_t *)c->scalars.p, nb32,
@@ -1363,10 +1391,15 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
         HIPCHK(c, hipMemcpyAsync(c->src.p, iq, nsrc * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
         src = (const float *)c->src.p;
     }
-    // positions this chunk owns; the global end-of-stream rule bounds the last chunk
+    // positions this chunk owns; the global end-of-stream rule bounds the last chunk -- unless the stream goes on (AM_F_MORE:
+    // total_n = samples so far; the chunk must come with its whole right halo)
     uint64_t em = 0;
     uint64_t P0 = abs_start, P1 = abs_start;
-    if (flush_limits(total_n, c->spc, &em)) P1 = std::max(P0, std::min(abs_end, em + 1));
+    c->shard_more = (flags & AM_F_MORE) != 0;
+    if (c->shard_more) {
+        if (abs_end + hr > total_n) return fail(c, AM_EINVAL, "AM_F_MORE: the chunk needs its whole right halo");
+        P1 = abs_end;
+    } else if (flush_limits(total_n, c->spc, &em)) P1 = std::max(P0, std::min(abs_end, em + 1));
     const uint64_t out_abs0 = (abs_start / L) * L;
     const uint64_t need0 = out_abs0 > LH ? out_abs0 - LH : 0;
     uint64_t fsrc_abs0 = src_abs0;
@@ -1410,12 +1443,15 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
         int rc = chain_prepare(c, M, true, Mp);
         if (rc != AM_OK) return rc;
         n_dev = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(M, lead + 1), msg_cap);
-        if (!n_dev)                                          // no candidate: count 0 (otherwise the table kernel writes the header:
-            HIPCHK(c, hipMemsetAsync(msg_dev, 0, sizeof(am_shard_exit), c->stream));   //  a fill is a dispatch of its own, ~4 us)
+        if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
+        // the message header: {entries, overflow}, {where the scan left this chunk a step ago, -} -- written by the table kernel,
+        // or (no candidate at all) by a one-wave launch
+        if (!n_dev) HIPCHK(c, am_launch_shard_header(msg_dev, (const uint64_t *)c->shard_exit.p, c->stream));
         if (n_dev)
             HIPCHK(c, am_launch_chain_exit_table((uint32_t *)c->pos.p, (uint32_t *)c->tgt.p, M, n_dev,
                                                  (uint32_t)std::min<uint64_t>(lead_end - out_abs0, 0xFFFFFFFFull),
-                                                 (uint32_t *)c->cscratch.p, out_abs0, msg_dev + 1, c->stream, Mp, msg_dev));
+                                                 (uint32_t *)c->cscratch.p, out_abs0, msg_dev + AM_SHARD_MSG_HEADER, c->stream, Mp,
+                                                 msg_dev, (const uint64_t *)c->shard_exit.p));
         c->last_M = M;
         c->shard_ready = true;
         return AM_OK;
@@ -1512,6 +1548,43 @@ int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, c
     return AM_OK;
 }
 
+int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *counts, uint32_t nranks, uint64_t cur_in,
+                    uint64_t *entry, uint64_t *leave)
+{
+    if (nranks && (!tables || !counts || (!entry && !leave))) return AM_EINVAL;
+    uint64_t cur = cur_in;                                      // where the scan left the last chunk of the step before
+    for (uint32_t r = 0; r < nranks; r++) {
+        if (entry) entry[r] = cur;
+        const am_shard_exit *t = tables[r];
+        const uint64_t n = counts[r];
+        uint64_t i = 0;
+        while (i < n && t[i].pos < cur) i++;
+        if (i < n) cur = t[i].exit > cur ? t[i].exit : cur;
+        if (leave) leave[r] = cur;
+    }
+    return AM_OK;
+}
+
+int am_shard_get_exit(am_ctx *c, uint64_t *pos)
+{
+    if (!c || !pos) return AM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
+    HIPCHK(c, hipMemcpyAsync(pos, c->shard_exit.p, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
+int am_shard_set_exit(am_ctx *c, uint64_t pos)
+{
+    if (!c) return AM_EINVAL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
+    HIPCHK(c, hipMemcpyAsync(c->shard_exit.p, &pos, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return AM_OK;
+}
+
 int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out)
 {
     if (!c) return AM_EINVAL;
@@ -1521,9 +1594,10 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
     c->pending.clear();
     c->last_tags = 0;
     uint64_t em = 0;
-    if (c->chain_M == 0 || !flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base) return AM_OK;
+    if (c->chain_M == 0) return AM_OK;
+    if (!c->shard_more && (!flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base)) return AM_OK;
     const uint32_t cur0 = cur_in > c->shard_base ? (uint32_t)std::min<uint64_t>(cur_in - c->shard_base, 0xFFFFFFF0u) : 0u;
-    const uint32_t emax = (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
+    const uint32_t emax = c->shard_more ? 0xFFFFFFFEu : (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
     uint32_t fin = 0;
     const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
@@ -1544,26 +1618,29 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     c->pending.clear();
     c->last_tags = 0;
     uint64_t em = 0;
-    ENSURE(c, c->scalars, 16 * sizeof(uint32_t));
+    if (int rc = ensure_scalars(c); rc != AM_OK) return rc;
     uint32_t *cur0_dev = (uint32_t *)c->scalars.p + 4, *flag_dev = (uint32_t *)c->scalars.p + 5;
     // the entry position of this chunk is composed from everybody's exit tables on the device: by the block walk itself, or
     // (nothing to slice here) by a launch of its own -- the other ranks must still learn whether a table overflowed: it did
     // so on every rank alike
     // (the flag is written, 0 or 1, by whichever kernel composes the entry: no fill in front of it)
-    if (c->chain_M == 0 || !flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base) {
-        HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev, c->stream));
+    if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
+    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base))) {
+        HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev,
+                                        (uint64_t *)c->shard_exit.p, c->stream));
         uint32_t f = 0;
         HIPCHK(c, hipMemcpyAsync(&f, flag_dev, sizeof(f), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         *redo = f ? 1 : 0;
         return AM_OK;
     }
-    const uint32_t emax = (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
+    const uint32_t emax = c->shard_more ? 0xFFFFFFFEu : (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
     uint32_t fin = 0;
     const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
     am_entry_src es;
     es.msgs = msgs_dev; es.world = world; es.rank = rank; es.cap = (uint32_t)msg_cap; es.base_abs = c->shard_base; es.flags = flag_dev;
+    es.exit_out = (uint64_t *)c->shard_exit.p;
     c->entry_src = &es;
     c->flag_src = flag_dev;
     int rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);

@@ -24,7 +24,7 @@
 //     refinement's exact energy-difference test needs (am_k_cand_d).
 //
 // Reference: python/rx_path.py:38-54 (|.|^2, moving averages), lib/preamble_impl.cc:172-179 (test).
-#include "am_internal.h"
+#include "am_fe_stream.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,7 +59,10 @@
 #define FE3_NT (AM_WAVE * FE3_NW)         /* lanes 0..47 of a wave = its block's chips; all threads stage the loads */
 #define FE3_T (FE3_S * FE3_SPC)           /* samples per step                                          */
 #define FE3_LAG 9                         /* phase B runs this many chips behind phase A               */
-#define FE3_CR (FE3_S + FE3_LAG + AM_CHIPS_AVG + 1)   /* ring capacity in chips: a step + lag + 48 back + 1 */
+#ifndef FE3_CR_EXTRA
+#define FE3_CR_EXTRA 0
+#endif
+#define FE3_CR (FE3_S + FE3_LAG + AM_CHIPS_AVG + 1 + FE3_CR_EXTRA)   /* ring capacity in chips: a step + lag + 48 back + 1 */
 #define FE3_XS 36                         /* floats per ring chip: 32 + 4 pad (16-byte reads of consecutive chips hit all banks) */
 #define FE3_BBW 17                        /* chips of bb kept from a candidate's chip on (am_k_cand reads up to pos + 16*spc) */
 
@@ -72,7 +75,7 @@ struct am_fe3_args {
     float *avg_sparse;                    // reference-level runs around candidates
     uint32_t j0, j1;                      // positions whose preamble test is wanted
     uint32_t *bits;                       // [nsteps * 96] candidate words: bit b of word w = position w*32 + b - 288
-    uint32_t *seg_cnt;                    // [nsteps * 2] candidates per (step, wave); wave w = words 48w .. 48w+47
+    uint32_t *wg_cnt;                     // [grid] candidates a workgroup found (am_k_gather_wg lays the flat list out from these)
     float *wg_max;                        // [grid] largest bb a workgroup formed (+inf if one was not finite)
     unsigned nsteps;                      // steps (= bitmap tiles) of the whole launch
     unsigned steps_per_wg;
@@ -89,69 +92,8 @@ struct am_fe3_args {
 __device__ __forceinline__ int fe3_wrap_up(int s) { return s >= FE3_CR ? s - FE3_CR : s; }     // s in [0, 2*CR)
 __device__ __forceinline__ int fe3_wrap_dn(int s) { return s < 0 ? s + FE3_CR : s; }           // s in [-CR, CR)
 
-// everything this workgroup wrote to LDS is visible to it after this (global loads / stores stay in flight)
-__device__ __forceinline__ void fe3_barrier()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-
-// value of lane-1 (lane 0 of a wave gets `first`) / of lane+1 (lane 63 gets `last`): DPP wave_shr:1 / wave_shl:1 on gfx9
-__device__ __forceinline__ float fe3_from_prev_lane(float v, float first, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v),
-                                                                 0x138, 0xf, 0xf, false));
-#else
-    const float s = __shfl_up(v, 1, AM_WAVE);
-    return lane == 0 ? first : s;
-#endif
-}
-__device__ __forceinline__ float fe3_from_next_lane(float v, float last, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, v),
-                                                                 0x130, 0xf, 0xf, false));
-#else
-    const float s = __shfl_down(v, 1, AM_WAVE);
-    return lane == AM_WAVE - 1 ? last : s;
-#endif
-}
-
-// streaming loads / stores (tuning builds compare the cache policies: FE3_NT_LOADS, FE3_NT_STORES)
-#ifndef FE3_NT_LOADS
-#define FE3_NT_LOADS 1
-#endif
-#ifndef FE3_NT_STORES
-#define FE3_NT_STORES 0
-#endif
-#if defined(__clang__)
-typedef float fe3_f4 __attribute__((ext_vector_type(4)));
-#endif
-__device__ __forceinline__ float4 fe3_gload16(const void *p)
-{
-#if FE3_NT_LOADS && defined(__HIP_DEVICE_COMPILE__)
-    const fe3_f4 t = __builtin_nontemporal_load(reinterpret_cast<const fe3_f4 *>(p));
-    float4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
-    return r;
-#else
-    return *reinterpret_cast<const float4 *>(p);
-#endif
-}
-__device__ __forceinline__ void fe3_gstore16(float *p, const float4 &u)
-{
-#if FE3_NT_STORES && defined(__HIP_DEVICE_COMPILE__)
-    fe3_f4 t; t.x = u.x; t.y = u.y; t.z = u.z; t.w = u.w;
-    __builtin_nontemporal_store(t, reinterpret_cast<fe3_f4 *>(p));
-#else
-    *reinterpret_cast<float4 *>(p) = u;
-#endif
-}
+// 16-byte store of a sparse output row piece
+__device__ __forceinline__ void fe3_gstore16(float *p, const float4 &u) { *reinterpret_cast<float4 *>(p) = u; }
 
 // Profiling builds only (-DFE3_PROFILE, tools/build_variants.sh): cycles per phase, summed over a workgroup's steps
 // by lane 0 of each wave.  The default build contains none of it.
@@ -183,7 +125,7 @@ __device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0
     const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
     const unsigned off = (unsigned)tid * 16u;
 #pragma unroll
-    for (int j = J0; j < 12; ++j) r.v[j] = fe3_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
+    for (int j = J0; j < 12; ++j) r.v[j] = fes_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
 }
 template <int J0 = 0>
 __device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int tid, const fe3_raw &r)
@@ -246,7 +188,7 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
 __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const int step, const bool test,
                                          const int slot0, const int par, const bool edge, const int tid, float &mxrun,
-                                         bool &badrun, fe3_prof &PR)
+                                         bool &badrun, uint32_t &ncand, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
     const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
@@ -307,7 +249,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
 #pragma unroll
             for (int i = 0; i < SPC; ++i) {
                 if (i == SPC - 1) bb[i] = pp[i] * a.s1;               // the window is the chip
-                else bb[i] = (fe3_from_prev_lane(sx[i + 1], pv[i + 1], lane) + pp[i]) * a.s1;
+                else bb[i] = (fes_from_prev_lane(sx[i + 1], pv[i + 1], lane) + pp[i]) * a.s1;
             }
         } else {
 #pragma unroll
@@ -336,12 +278,12 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         if (!(FE3_ABLATE & 8)) {
 #pragma unroll
             for (int r = 0; r < AM_CHIPS_AVG - 1; ++r) {
-                xs = fe3_from_prev_lane(xs, 0.0f, lane) + f;
-                ys = fe3_from_next_lane(ys, 0.0f, lane) + f;
+                xs = fes_from_prev_lane(xs, 0.0f, lane) + f;
+                ys = fes_from_next_lane(ys, 0.0f, lane) + f;
             }
         }
-        const float pt = fe3_from_prev_lane(xs, 0.0f, lane);
-        const float st = fe3_from_next_lane(ys, 0.0f, lane);
+        const float pt = fes_from_prev_lane(xs, 0.0f, lane);
+        const float st = fes_from_next_lane(ys, 0.0f, lane);
         if (chip_thread) {
             L.RTOT[slotA] = b;
             L.PT[slotA] = pt;
@@ -356,7 +298,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         }
     }
     FE3_STAMP(1);
-    fe3_barrier();                                                    // B3: ring, totals and scans of this step complete
+    fes_barrier();                                                    // B3: ring, totals and scans of this step complete
     FE3_STAMP(2);
     if (!test) return;                                                // (uniform) ring rebuild only
 
@@ -483,11 +425,9 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         cm &= keep;
     }
     if (!chip_thread) cm = 0u;
-    // candidate word, per-wave count
+    // candidate word; the lane's running count (summed over the workgroup at the end)
     if (chip_thread) a.bits[(size_t)step * FE3_S + t] = cm;
-    uint32_t cnt = (uint32_t)__popcll((unsigned long long)cm);
-    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, AM_WAVE);
-    if (lane == 0) a.seg_cnt[(size_t)step * FE3_NW + wv] = cnt;
+    ncand += (uint32_t)__popcll((unsigned long long)cm);
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
     FE3_STAMP(3);
     if (FE3_ABLATE & 1) return;
@@ -602,7 +542,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     // chips of a segment is always written (the candidates of the previous segment's tail are not known here)
     for (int i = tid0; i < FE3_CR * FE3_XS + 64 + 32 * (FE3_NW - 1) + FE3_NW * 4 * FE3_XS + 3 * FE3_CR; i += FE3_NT) L.X[i] = 0.0f;
     if (tid0 < 2) L.CARRY[tid0] = 0xFFFFu;
-    fe3_barrier();                                                    // (the first step stages into the ring right away)
+    fes_barrier();                                                    // (the first step stages into the ring right away)
 
     int slot0 = 0, par = 0;
     fe3_prof PR;
@@ -612,6 +552,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 #endif
     float mxrun = 0.0f;                                               // largest bb this thread has formed
     bool badrun = false;                                              // ... or one that is not finite
+    uint32_t ncand = 0;                                               // candidates this thread's chips held
     for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
         const bool have = step >= a.raw_lo && step < a.raw_hi;        // the step's raw samples are all present and 16-byte aligned
@@ -630,25 +571,32 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         } else
             fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
         FE3_STAMP(5);
-        fe3_barrier();                                                // B1: |.|^2 of this step staged
+        fes_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
-        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, PR);
+        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR);
         slot0 = fe3_wrap_up(slot0 + FE3_S);
         par ^= 1;
         FE3_STAMP(6);
-        fe3_barrier();                                                // B5: every ring read of this step done
+        fes_barrier();                                                // B5: every ring read of this step done
     }
     // the largest sample of the segment (with the chips the ring rebuild went through): +inf if one was not finite
     {
         float wmx = mxrun;
         for (int o = 32; o >= 1; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, AM_WAVE));
         const bool bad = __ballot(badrun) != 0ull;
-        if ((tid0 & (AM_WAVE - 1)) == 0) L.SB0[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
-        fe3_barrier();
+        uint32_t wcnt = ncand;
+        for (int o = 32; o >= 1; o >>= 1) wcnt += (uint32_t)__shfl_xor((int)wcnt, o, AM_WAVE);
+        if ((tid0 & (AM_WAVE - 1)) == 0) {
+            L.SB0[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
+            L.TAB[tid0 / AM_WAVE] = wcnt;
+        }
+        fes_barrier();
         if (tid0 == 0) {
             float v = L.SB0[0];
-            for (int w = 1; w < FE3_NW; ++w) v = fmaxf(v, L.SB0[w]);
+            uint32_t n = L.TAB[0];
+            for (int w = 1; w < FE3_NW; ++w) { v = fmaxf(v, L.SB0[w]); n += L.TAB[w]; }
             a.wg_max[blockIdx.x] = v;
+            a.wg_cnt[blockIdx.x] = n;
         }
     }
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -658,25 +606,22 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
-int am_fe3_supported(int spc) { return spc == FE3_SPC ? 1 : 0; }
 unsigned am_fe3_tile(void) { return FE3_T; }
 unsigned am_fe3_lag(void) { return FE3_LAG * FE3_SPC; }
 unsigned am_fe3_waves(void) { return FE3_NW; }
 unsigned am_fe3_steps(long long out_n) { return (unsigned)((out_n + FE3_LAG * FE3_SPC + FE3_T - 1) / FE3_T); }
 
-static long long fe3_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
-static long long fe3_ceil_div(long long x, long long d) { return -fe3_floor_div(-x, d); }
 
 static int fe3_wgs_for_device() { return FE3_WG_PER_CU * am_device_cus(); }   // resident workgroups
 
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps, unsigned *steps_per_wg,
+                         float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps, unsigned *steps_per_wg,
                          hipStream_t s)
 {
     am_fe3_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
-    a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.seg_cnt = seg_cnt; a.wg_max = wg_max;
+    a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.wg_cnt = wg_cnt; a.wg_max = wg_max;
     a.use_pmf = (use_pmf && FE3_SPC > 1) ? 1 : 0; a.s1 = s1; a.sL = sL; a.thr_lin = thr_lin;
     a.nsteps = am_fe3_steps(out_n);
     *nsteps = a.nsteps;
@@ -686,13 +631,13 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     // parity of the offset is the same for every step: T is even)
     const bool aligned = ((reinterpret_cast<uintptr_t>(iq) + (uintptr_t)(out_abs0 - src_abs0) * 8u) & 15u) == 0;
     auto clampi = [](long long v) { return (int)(v < -4 ? -4 : (v > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : v)); };
-    a.raw_lo = clampi(fe3_ceil_div(src_abs0 - out_abs0, FE3_T));
-    a.raw_hi = aligned ? clampi(fe3_floor_div(src_abs1 - out_abs0, FE3_T)) : a.raw_lo;
+    a.raw_lo = clampi(fes_ceil_div(src_abs0 - out_abs0, FE3_T));
+    a.raw_hi = aligned ? clampi(fes_floor_div(src_abs1 - out_abs0, FE3_T)) : a.raw_lo;
     // steps whose tested positions [k T - 288, k T + T - 288) all lie in [j0, min(j1, out_n))
     const long long lag = (long long)FE3_LAG * FE3_SPC;
     const long long jhi = (long long)j1 < out_n ? (long long)j1 : out_n;
-    a.test_lo = clampi(fe3_ceil_div((long long)j0 + lag, FE3_T));
-    a.test_hi = clampi(fe3_floor_div(jhi + lag, FE3_T));
+    a.test_lo = clampi(fes_ceil_div((long long)j0 + lag, FE3_T));
+    a.test_hi = clampi(fes_floor_div(jhi + lag, FE3_T));
     // persistent workgroups: as many as are resident at once, each with a contiguous run of steps; short inputs
     // get at least 4 steps per workgroup (the ring rebuild costs one)
     unsigned resident = (unsigned)fe3_wgs_for_device();

@@ -38,7 +38,7 @@
 // recomputes its samples from IQ (am_kernels.hip).
 //
 // Reference: python/rx_path.py:35-54 (spc = rate / 2e6, |.|^2, moving averages), lib/preamble_impl.cc:172-179 (test).
-#include "am_internal.h"
+#include "am_fe_stream.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -73,7 +73,7 @@ struct am_fe4_args {
     float *avg_sparse;                    // reference-level runs around candidates
     uint32_t j0, j1;                      // positions whose preamble test is wanted
     uint32_t *bits;                       // [nsteps * US] candidate words: bit b of word w = position w*R + b - lag
-    uint32_t *seg_cnt;                    // [nsteps * NW] candidates per (step, wave); wave w = words LU w .. LU w + LU - 1
+    uint32_t *wg_cnt;                     // [grid] candidates a workgroup found (am_k_gather_wg lays the flat list out from these)
     float *wg_max;                        // [grid] largest bb a workgroup formed (+inf if one was not finite)
     unsigned nsteps, steps_per_wg;
     int raw_lo, raw_hi, test_lo, test_hi; // steps loaded without guards / tested without a range mask
@@ -163,52 +163,6 @@ __device__ __forceinline__ fe4_smem<SPC, G, NW> fe4_smem_at(float *base)
     return L;
 }
 
-// everything this workgroup wrote to LDS is visible to it after this (global loads / stores stay in flight)
-__device__ __forceinline__ void fe4_barrier()
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
-// value of lane-1 (lane 0 of a wave gets `first`) / of lane+1 (lane 63 gets `last`): DPP wave_shr:1 / wave_shl:1 on gfx9
-__device__ __forceinline__ float fe4_from_prev_lane(float v, float first, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v),
-                                                                 0x138, 0xf, 0xf, false));
-#else
-    const float s = __shfl_up(v, 1, AM_WAVE);
-    return lane == 0 ? first : s;
-#endif
-}
-__device__ __forceinline__ float fe4_from_next_lane(float v, float last, int lane)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    (void)lane;
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, v),
-                                                                 0x130, 0xf, 0xf, false));
-#else
-    const float s = __shfl_down(v, 1, AM_WAVE);
-    return lane == AM_WAVE - 1 ? last : s;
-#endif
-}
-#if defined(__clang__)
-typedef float fe4_f4 __attribute__((ext_vector_type(4)));
-#endif
-__device__ __forceinline__ float4 fe4_gload16(const void *p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const fe4_f4 t = __builtin_nontemporal_load(reinterpret_cast<const fe4_f4 *>(p));
-    float4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
-    return r;
-#else
-    return *reinterpret_cast<const float4 *>(p);
-#endif
-}
-
 // Profiling builds only (-DFE4_PROFILE, tools/build_variants.sh): cycles per phase, summed over a workgroup's steps
 // by lane 0 of each wave.  The default build contains none of it.
 #if defined(FE4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -264,7 +218,7 @@ __device__ __forceinline__ void fe4_stage_step(const am_fe4_args &a, const fe4_s
 #pragma unroll
         for (int j = 0; j < C::NLD; ++j) {
             const int p = tid + C::NT * j;
-            if (p < C::PIECES && p >= p0) v[j] = fe4_gload16(gb + (size_t)p * 16u);
+            if (p < C::PIECES && p >= p0) v[j] = fes_gload16(gb + (size_t)p * 16u);
         }
 #pragma unroll
         for (int j = 0; j < C::NLD; ++j) {
@@ -285,7 +239,7 @@ __device__ __forceinline__ void fe4_stage_step(const am_fe4_args &a, const fe4_s
 template <int SPC, int G, int NW>
 __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SPC, G, NW> &L, const int step, const bool test,
                                          const int slot0, const int par, const bool edge, const int tid, float &mxrun,
-                                         bool &badrun, fe4_prof &PR)
+                                         bool &badrun, uint32_t &ncand, fe4_prof &PR)
 {
     using C = fe4_cfg<SPC, G, NW>;
     constexpr int R = C::R, RS = C::RS, LPB = C::LPB, LAGU = C::LAGU;
@@ -347,7 +301,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                 for (int i = 0; i < SPC; ++i) {
                     const int j = g * SPC + i;
                     if (i == SPC - 1) bb[j] = pp[j] * a.s1;           // the window is the chip
-                    else if (g == 0) bb[j] = (fe4_from_prev_lane(sx[(G - 1) * SPC + i + 1], pv[i + 1], lane) + pp[j]) * a.s1;
+                    else if (g == 0) bb[j] = (fes_from_prev_lane(sx[(G - 1) * SPC + i + 1], pv[i + 1], lane) + pp[j]) * a.s1;
                     else bb[j] = (sx[(g - 1) * SPC + i + 1] + pp[j]) * a.s1;
                 }
         } else {
@@ -386,7 +340,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
             float xe = xin, ye = yin;
 #pragma unroll
             for (int g = 0; g < G; ++g) { xe = xe + f[g]; ye = ye + f[G - 1 - g]; }
-            const float xp = fe4_from_prev_lane(xe, 0.0f, lane), yn = fe4_from_next_lane(ye, 0.0f, lane);
+            const float xp = fes_from_prev_lane(xe, 0.0f, lane), yn = fes_from_next_lane(ye, 0.0f, lane);
             xin = (lb == 0) ? 0.0f : xp;
             yin = (lb == LPB - 1) ? 0.0f : yn;
         }
@@ -423,7 +377,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         }
     }
     FE4_STAMP(1);
-    fe4_barrier();                                                    // B3: ring and scans of this step complete
+    fes_barrier();                                                    // B3: ring and scans of this step complete
     FE4_STAMP(2);
     if (!test) return;                                                // (uniform) ring rebuild only
 
@@ -458,8 +412,8 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                 float xe = xh, ye = yh;
 #pragma unroll
                 for (int g = 0; g < G; ++g) { xe = xe + f[g]; ye = ye + fT[G - 1 - g]; }
-                xh = fe4_from_prev_lane(xe, cf, lane);
-                yh = fe4_from_next_lane(ye, cb, lane);
+                xh = fes_from_prev_lane(xe, cf, lane);
+                yh = fes_from_next_lane(ye, cb, lane);
             }
             if (lane < s0) L.UPT[slotA] = xh;
             if (lane >= AM_WAVE - t0p) {
@@ -615,9 +569,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     }
     if (!unit_thread) cm = 0u;
     if (unit_thread) a.bits[(size_t)step * C::US + t] = cm;
-    uint32_t cnt = (uint32_t)__popcll((unsigned long long)cm);
-    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, AM_WAVE);
-    if (lane == 0) a.seg_cnt[(size_t)step * NW + wv] = cnt;
+    ncand += (uint32_t)__popcll((unsigned long long)cm);              // (summed over the workgroup at the end)
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: unit LU wave + l has a candidate
     FE4_STAMP(3);
     if (FE4_ABLATE & 1) return;
@@ -678,7 +630,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                 if (wv == NW - 1) L.CARRY[par] = ov;
                 else L.WOV[par * NW + wv] = ov;
             }
-            fe4_barrier();
+            fes_barrier();
             if (wv == 0) need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.CARRY[par ^ 1]);
             else need |= (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)L.WOV[par * NW + wv - 1]);
         } else {
@@ -718,9 +670,9 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
     const int se = (sb + (int)a.steps_per_wg < (int)a.nsteps) ? sb + (int)a.steps_per_wg : (int)a.nsteps;
     // rings start empty; the first step's unit 0 has no predecessor (its bb is never used)
     for (int i = tid0; i < C::LDS_FLOATS; i += C::NT) L.X[i] = 0.0f;
-    fe4_barrier();
+    fes_barrier();
     if (tid0 < 2) L.CARRY[tid0] = 0xFFFFu;                            // the bb of a segment's first units is always written
-    fe4_barrier();
+    fes_barrier();
     int slot0 = 0, par = 0;
     fe4_prof PR;
 #if defined(FE4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -729,6 +681,7 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
 #endif
     float mxrun = 0.0f;                                               // largest bb this thread has formed
     bool badrun = false;                                              // ... or one that is not finite
+    uint32_t ncand = 0;                                               // candidates this thread's units held
     // the step before the segment only rebuilds the rings: its first tested unit is unit US - LAGU, whose reference level
     // reaches back LPB units
     constexpr int WARM_P0 = ((C::US - C::LAGU - C::LPB - 1) * C::R / 2 / C::NT) * C::NT;
@@ -744,25 +697,32 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
         if (have) fe4_stage_step<SPC, G, NW, false>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid, test ? 0 : WARM_P0);
         else fe4_stage_step<SPC, G, NW, true>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid, 0);
         FE4_STAMP(5);
-        fe4_barrier();                                                // B1: |.|^2 of this step staged
+        fes_barrier();                                                // B1: |.|^2 of this step staged
         FE4_STAMP(0);
-        fe4_step<SPC, G, NW>(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, PR);
+        fe4_step<SPC, G, NW>(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR);
         slot0 = fe4_wrap_up<C>(slot0 + C::US);
         par ^= 1;
         FE4_STAMP(6);
-        fe4_barrier();                                                // B5: every ring read of this step done
+        fes_barrier();                                                // B5: every ring read of this step done
     }
     // the largest sample of the segment (with the units the ring rebuild went through): +inf if one was not finite
     {
         float wmx = mxrun;
         for (int o = 32; o >= 1; o >>= 1) wmx = fmaxf(wmx, __shfl_xor(wmx, o, AM_WAVE));
         const bool bad = __ballot(badrun) != 0ull;
-        if ((tid0 & (AM_WAVE - 1)) == 0) L.WMX[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
-        fe4_barrier();
+        uint32_t wcnt = ncand;
+        for (int o = 32; o >= 1; o >>= 1) wcnt += (uint32_t)__shfl_xor((int)wcnt, o, AM_WAVE);
+        if ((tid0 & (AM_WAVE - 1)) == 0) {
+            L.WMX[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
+            L.TAB[tid0 / AM_WAVE] = wcnt;
+        }
+        fes_barrier();
         if (tid0 == 0) {
             float v = L.WMX[0];
-            for (int w = 1; w < NW; ++w) v = fmaxf(v, L.WMX[w]);
+            uint32_t n = L.TAB[0];
+            for (int w = 1; w < NW; ++w) { v = fmaxf(v, L.WMX[w]); n += L.TAB[w]; }
             a.wg_max[blockIdx.x] = v;
+            a.wg_cnt[blockIdx.x] = n;
         }
     }
 #if defined(FE4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -772,6 +732,15 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
 }
 
 // ---- host side ----------------------------------------------------------------------------------------
+// 64 Msps runs am_k_fe3 (am_fe3.hip): the same machine with one chip per lane, two waves of 48 chip lanes and 16-byte LDS rows.
+// am_k_fe4<32, 1, NW> computes the same results and was measured against it in round 4 (profiles/r4_fe64: 8-byte rows cost
+// 20 %, and three waves of 64 lanes -- no idle lane, 4 blocks per step -- another 3 %); tuning builds (-DFE4_64MSPS) still
+// run it.
+#if defined(FE4_64MSPS)
+#define FE4_USE_FE3(spc) false
+#else
+#define FE4_USE_FE3(spc) ((spc) == 32)
+#endif
 // the specialisations that exist: chips per lane and waves per workgroup by samples per chip
 static int fe4_g_of(int spc)
 {
@@ -790,10 +759,15 @@ static int fe4_g_of(int spc)
 }
 static int fe4_nw_of(int spc) { return spc == 32 ? FE4_NW64 : 2; }
 int am_fe4_supported(int spc) { return fe4_g_of(spc) != 0 ? 1 : 0; }
-unsigned am_fe4_waves(int spc) { return fe4_g_of(spc) ? (unsigned)fe4_nw_of(spc) : 0u; }   // segments (waves) per step
+unsigned am_fe4_waves(int spc)                                                               // segments (waves) per step
+{
+    if (FE4_USE_FE3(spc)) return am_fe3_waves();
+    return fe4_g_of(spc) ? (unsigned)fe4_nw_of(spc) : 0u;
+}
 unsigned am_fe4_unit(int spc) { return (unsigned)(spc * fe4_g_of(spc)); }                    // R: positions per bitmap word
 unsigned am_fe4_words(int spc)                                                               // bitmap words (units) per step and wave
 {
+    if (FE4_USE_FE3(spc)) return AM_CHIPS_AVG;
     const int g = fe4_g_of(spc);
     return g ? (unsigned)(((AM_WAVE * fe4_nw_of(spc)) % (AM_CHIPS_AVG / g) == 0) ? AM_WAVE : AM_CHIPS_AVG) : 0u;
 }
@@ -804,9 +778,6 @@ unsigned am_fe4_steps(long long out_n, int spc)
     const long long T = am_fe4_tile(spc);
     return T ? (unsigned)((out_n + am_fe4_lag(spc) + T - 1) / T) : 0u;
 }
-
-static long long fe4_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
-static long long fe4_ceil_div(long long x, long long d) { return -fe4_floor_div(-x, d); }
 
 template <int SPC, int G, int NW>
 static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t s)
@@ -879,13 +850,16 @@ static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t
 
 hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps,
+                         float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
                          unsigned *steps_per_wg, hipStream_t s)
 {
     if (!am_fe4_supported(spc)) return hipErrorInvalidValue;
+    if (FE4_USE_FE3(spc))
+        return am_launch_fe3(iq, src_abs0, src_abs1, out_abs0, out_n, bb_sparse, avg_sparse, j0, j1, use_pmf, s1, sL, thr_lin, bits,
+                             wg_cnt, wg_max, nsteps, steps_per_wg, s);
     am_fe4_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
-    a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.seg_cnt = seg_cnt; a.wg_max = wg_max;
+    a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.wg_cnt = wg_cnt; a.wg_max = wg_max;
     a.use_pmf = use_pmf ? 1 : 0; a.s1 = s1; a.sL = sL; a.thr_lin = thr_lin;
     a.nsteps = am_fe4_steps(out_n, spc);
     a.prof = nullptr;
@@ -897,12 +871,12 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
     // parity of the offset is the same for every step: T is even)
     const bool aligned = ((reinterpret_cast<uintptr_t>(iq) + (uintptr_t)(out_abs0 - src_abs0) * 8u) & 15u) == 0 && (T % 2) == 0;
     auto clampi = [](long long v) { return (int)(v < -4 ? -4 : (v > 0x7FFFFFF0ll ? 0x7FFFFFF0ll : v)); };
-    a.raw_lo = clampi(fe4_ceil_div(src_abs0 - out_abs0, T));
-    a.raw_hi = aligned ? clampi(fe4_floor_div(src_abs1 - out_abs0, T)) : a.raw_lo;
+    a.raw_lo = clampi(fes_ceil_div(src_abs0 - out_abs0, T));
+    a.raw_hi = aligned ? clampi(fes_floor_div(src_abs1 - out_abs0, T)) : a.raw_lo;
     // steps whose tested positions [k T - lag, k T + T - lag) all lie in [j0, min(j1, out_n))
     const long long jhi = (long long)j1 < out_n ? (long long)j1 : out_n;
-    a.test_lo = clampi(fe4_ceil_div((long long)j0 + lag, T));
-    a.test_hi = clampi(fe4_floor_div(jhi + lag, T));
+    a.test_lo = clampi(fes_ceil_div((long long)j0 + lag, T));
+    a.test_hi = clampi(fes_floor_div(jhi + lag, T));
     switch (spc) {
     case 1: return fe4_launch<1, 24, 2>(a, steps_per_wg, s);
     case 2: return fe4_launch<2, 16, 2>(a, steps_per_wg, s);
@@ -912,6 +886,10 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
     case 10: return fe4_launch<10, 3, 2>(a, steps_per_wg, s);
     case 16: return fe4_launch<16, 2, 2>(a, steps_per_wg, s);
     case 20: return fe4_launch<20, 1, 2>(a, steps_per_wg, s);
+#if defined(FE4_64MSPS)
     default: return fe4_launch<32, 1, FE4_NW64>(a, steps_per_wg, s);
+#else
+    default: return hipErrorInvalidValue;
+#endif
     }
 }

@@ -1,0 +1,60 @@
+// am_fe_stream.h -- device helpers shared by the streaming fused front ends (am_fe3.hip: 64 Msps, one 32-sample chip per
+// lane, 16-byte LDS rows; am_fe4.hip: 2 .. 40 Msps, a unit of G chips per lane, 8-byte LDS rows).  Not part of the public ABI.
+#ifndef AM_FE_STREAM_H
+#define AM_FE_STREAM_H
+
+#include "am_internal.h"
+
+// everything this workgroup wrote to LDS is visible to it after this (global loads / stores stay in flight)
+__device__ __forceinline__ void fes_barrier()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
+// value of lane-1 (lane 0 of a wave gets `first`) / of lane+1 (lane 63 gets `last`): DPP wave_shr:1 / wave_shl:1 on gfx9
+__device__ __forceinline__ float fes_from_prev_lane(float v, float first, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, first), __builtin_bit_cast(int, v),
+                                                                 0x138, 0xf, 0xf, false));
+#else
+    const float s = __shfl_up(v, 1, AM_WAVE);
+    return lane == 0 ? first : s;
+#endif
+}
+__device__ __forceinline__ float fes_from_next_lane(float v, float last, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, v),
+                                                                 0x130, 0xf, 0xf, false));
+#else
+    const float s = __shfl_down(v, 1, AM_WAVE);
+    return lane == AM_WAVE - 1 ? last : s;
+#endif
+}
+
+// 16 bytes of raw IQ with the streaming (nt) policy: every sample is read once
+#if defined(__clang__)
+typedef float fes_f4 __attribute__((ext_vector_type(4)));
+#endif
+__device__ __forceinline__ float4 fes_gload16(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const fes_f4 t = __builtin_nontemporal_load(reinterpret_cast<const fes_f4 *>(p));
+    float4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    return r;
+#else
+    return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+
+static inline long long fes_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
+static inline long long fes_ceil_div(long long x, long long d) { return -fes_floor_div(-x, d); }
+
+#endif

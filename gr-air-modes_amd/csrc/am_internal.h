@@ -43,12 +43,22 @@ hipError_t am_launch_fe2(int spc, const float *iq, long long src_abs0, long long
                          long long out_n, float *bb, float *avg, uint32_t j0, uint32_t j1, int use_pmf, float s1,
                          float sL, float thr_lin, uint32_t *seg_pos, float *avg_sparse, uint32_t *blk_cnt,
                          unsigned *ntiles, unsigned *tile_len, hipStream_t s);
-/* streaming fused front end (am_fe4.hip): persistent workgroups, LDS rings, sparse outputs.  A lane takes a unit of G chips
+/* streaming fused front ends (am_fe4.hip; am_fe3.hip at 64 Msps): persistent workgroups, LDS rings, sparse outputs.  A lane takes a unit of G chips
  * = am_fe4_unit(spc) samples (one 32-sample chip at 64 Msps).  Candidates leave as a bitmap, a word per unit: bit b of word w =
- * array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); seg_cnt holds the number of candidates per (step, wave): a step
- * has am_fe4_waves(spc) segments of am_fe4_words(spc) words (64 at 64, 20, 10 and 2 Msps, 48 otherwise).  wg_max[g] (nsteps + 8
+ * array coordinate w * am_fe4_unit(spc) + b - am_fe4_lag(spc); a step has am_fe4_waves(spc) x am_fe4_words(spc) words (waves of 64
+ * words at 20, 10 and 2 Msps, of 48 otherwise).  wg_cnt[g] = candidates workgroup g found; wg_max[g] (nsteps + 8
  * floats are enough) = the largest bb workgroup g formed, +inf if one was not finite; workgroup g formed the bb of the array
  * coordinates [g * steps_per_wg * tile, (g + 1) * steps_per_wg * tile) (and some before them). */
+/* (behind am_fe4_* / am_launch_fe4 at 64 Msps: am_k_fe3, am_fe3.hip -- the same machine with one 32-sample chip per lane and
+ * 16-byte LDS rows; two segments of 48 words per step, lag 288) */
+unsigned am_fe3_tile(void);                 /* positions per step (3072) */
+unsigned am_fe3_lag(void);                  /* 288 */
+unsigned am_fe3_waves(void);                /* segments (waves, 48 chips = 48 bitmap words each) per step */
+unsigned am_fe3_steps(long long out_n);
+hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
+                         float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
+                         float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
+                         unsigned *steps_per_wg, hipStream_t s);
 int am_fe4_supported(int spc);
 unsigned am_fe4_unit(int spc);
 unsigned am_fe4_words(int spc);
@@ -58,14 +68,14 @@ unsigned am_fe4_lag(int spc);
 unsigned am_fe4_steps(long long out_n, int spc);
 hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
-                         float thr_lin, uint32_t *bits, uint32_t *seg_cnt, float *wg_max, unsigned *nsteps,
+                         float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
                          unsigned *steps_per_wg, hipStream_t s);
-/* flat candidate positions + dcount from the bitmap; off_local / blk_base = two-level exclusive scan of seg_cnt
- * (am_launch_exscan_blocks + am_launch_scan_u32 of its block totals, or one chained scan: null) */
-hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
-                                 const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
-                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp = nullptr, uint32_t wbits = 32,
-                                 uint32_t seg_words = 48);   /* segment k = words 48k .. 48k+47; wbits positions per word */
+/* flat candidate positions from the bitmap, one workgroup per front-end workgroup: workgroup g owns the words
+ * [g * words_per_wg, (g + 1) * words_per_wg) (nwords in all) and starts its part of pos[] at the sum of wg_cnt[0 .. g)
+ * -- no scan launch, no chain.  Entries at or beyond Mcap are dropped; *total_out = the number of candidates. */
+hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uint32_t nwg, uint32_t words_per_wg,
+                               uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *pos,
+                               uint32_t *total_out, hipStream_t s);
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
@@ -73,18 +83,19 @@ hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, co
                                 hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
                                    hipStream_t s, const uint32_t *Mp = nullptr);
-/* late != null (behind the streaming front end): one byte per compact index instead of one energy --
- * late[k] = E(q+1) > E(q), decided from the exact difference of the two sums wherever that is safe (am_k_energy);
- * vmax[array coordinate / vspan] (nv entries) bounds the samples */
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s, const uint32_t *Mp = nullptr, uint8_t *late = nullptr,
-                            const float *vmax = nullptr, uint32_t vspan = 0, uint32_t nv = 0);
+                            double *energy, hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp = nullptr,
-                          const uint8_t *late = nullptr);
+                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp = nullptr);
+/* behind the streaming front ends: late-peak decisions + per-candidate test + record + successor in one launch (the
+ * decisions stay in LDS; no dcount / compact offsets).  vmax[array coordinate / vspan] (nv entries) bounds the samples */
+hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const uint32_t *pos, uint32_t M, int spc,
+                                 float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
+                                 uint32_t *jump0, hipStream_t s, const uint32_t *Mp, const float *vmax, uint32_t vspan,
+                                 uint32_t nv);
 /* exclusive scan of n counts in ONE launch (2048 per workgroup, chained through slots[]: am_chain_prefix);
  * slots: one 64-bit word per workgroup, zero at allocation; epoch: a value no earlier launch on these slots used */
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
@@ -144,6 +155,7 @@ struct am_entry_src {
     uint32_t world, rank, cap;
     uint64_t base_abs;              // absolute index of the chunk's array coordinate 0
     uint32_t *flags;                // flags[0] = 1: repeat the step
+    uint64_t *exit_out;             // where the scan leaves this chunk (absolute): the next step's message carries it
 };
 
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
@@ -154,11 +166,14 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
-                                      hipStream_t s, const uint32_t *Mp = nullptr, am_shard_exit *header = nullptr);
-/* device-side am_shard_entry: `world` messages of 1 + cap entries (entry 0: {count, -}); writes the array coordinate at
- * which the scan enters chunk `rank` and sets flags[0] if some table did not fit */
+                                      hipStream_t s, const uint32_t *Mp = nullptr, am_shard_exit *header = nullptr,
+                                      const uint64_t *carry = nullptr);   /* header[1] = {*carry, 0}: where the scan left this chunk a step ago */
+/* device-side am_shard_entry2: `world` messages of AM_SHARD_MSG_HEADER + cap entries; writes the array coordinate at which the
+ * scan enters chunk `rank`, the absolute position at which it leaves it, and sets flags[0] if some table did not fit */
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
-                                 uint32_t *cur0_out, uint32_t *flags, hipStream_t s);
+                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s);
+/* the header of a message without a table: {0, 0}, {*carry, 0} */
+hipError_t am_launch_shard_header(am_shard_exit *header, const uint64_t *carry, hipStream_t s);
 
 /* ---- burst extraction + slicer + CRC --------------------------------------------------- */
 /* "rx_time" stream tag (lib/preamble_impl.cc:165-170): from item `offset` on, time = (secs, frac) +

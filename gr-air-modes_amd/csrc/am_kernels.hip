@@ -473,72 +473,93 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
     }
 }
 
-// Flat candidate positions from the streaming front end's bitmap (am_fe4.hip): one wave per (step, wave) segment,
-// four segments per workgroup.
-// Word w, bit b = array coordinate wbits*w + b - lag (wbits = 32 at 64 Msps, the unit length of am_k_fe4 otherwise).  dcount
-// needs the distance to the candidate before, capped at spc + 1 <= wbits + 1: the two words in front of a word are all the
-// history it can need.
-__global__ void __launch_bounds__(4 * AM_WAVE)
-am_k_gather_bits(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ seg_cnt,
-                 const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t nseg,
-                 uint32_t Mcap, int spc, uint32_t lag, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
-                 const uint32_t *__restrict__ Mp, uint32_t wbits, uint32_t nw)
+// Flat candidate positions from the streaming front ends' bitmap (am_fe3.hip / am_fe4.hip), one workgroup per FRONT-END
+// workgroup (round 4).  Word w, bit b = array coordinate wbits * w + b - lag (wbits = 32 at 64 Msps, the unit length of
+// am_k_fe4 otherwise).  Front-end workgroup g tested the words [g * words_per_wg, (g + 1) * words_per_wg) and left their
+// candidate count in wg_cnt[g]: this workgroup's part of pos[] starts at wg_cnt[0] + ... + wg_cnt[g - 1], which it adds up
+// itself (a few KB of counts) -- no scan launch in front of it, no chain between workgroups, nothing to wait for.  (Round 3:
+// a chained scan of 41 664 per-(step, wave) counts, then one wave per 48-word segment: 6.3 + 14.9 us at the bench density.)
+// A thread takes four consecutive words per round (one 16-byte load); the round's counts are scanned in the workgroup.
+// Entries at or beyond Mcap (a capacity launch that was too small: the scan is redone) are dropped; *total_out = the
+// number of candidates there are.
+__global__ void __launch_bounds__(256)
+am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wg_cnt, uint32_t nwg, uint32_t words_per_wg,
+               uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *__restrict__ pos,
+               uint32_t *__restrict__ total_out)
 {
-    const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t seg = blockIdx.x * 4u + threadIdx.x / AM_WAVE;
-    if (seg >= nseg) return;                                 // (wave-uniform; no workgroup barrier below)
-    // every load the wave may need goes out at once (one memory round trip; written as count -> offset -> word ->
-    // the two words before, each behind the branch on the one before it, it was four -- which, measured, makes no
-    // difference to the kernel's 15 us: they go to its 10 400 workgroups of four single-segment waves.  Eight segments per wave
-    // with all their loads in one round trip -- 1 300 workgroups -- was measured in round 3: 18.5 us.)
-    const int lane = threadIdx.x & (AM_WAVE - 1);
-    // nw words per segment (one wave of the front end: 48, or 64 where all of its lanes own a unit)
-    const size_t w = (size_t)seg * nw + (uint32_t)lane;
-    uint32_t cnt = seg_cnt[seg];
-    uint32_t off = off_local[seg] + (blk_base ? blk_base[seg / AM_SCAN_BLK] : 0u);   // exclusive scan of seg_cnt (two-level, or global)
-    uint32_t word = 0, p1 = 0, p2 = 0;
-    if ((uint32_t)lane < nw) {
-        word = bits[w];
-        p1 = w >= 1 ? bits[w - 1] : 0u;
-        p2 = w >= 2 ? bits[w - 2] : 0u;
+    __shared__ uint32_t ws[256 / AM_WAVE];
+    __shared__ uint32_t red[256 / AM_WAVE];
+    const uint32_t g = blockIdx.x;
+    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
+    const uint32_t w_begin = g * words_per_wg;
+    const uint32_t w_end = (w_begin + words_per_wg < nwords) ? w_begin + words_per_wg : nwords;
+    const bool vec = (reinterpret_cast<uintptr_t>(bits + w_begin) & 15u) == 0;   // (uniform)
+    auto load4 = [&](uint32_t w0, uint32_t *x) __attribute__((always_inline)) {
+        x[0] = x[1] = x[2] = x[3] = 0u;
+        if (vec && w0 + 4u <= w_end) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(bits + w0);
+            x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (w0 + (uint32_t)k < w_end) x[k] = bits[w0 + (uint32_t)k];
+        }
+    };
+    // the first two rounds' words (all of them at 64 Msps) go out together with the counts of the workgroups before this one:
+    // one memory round trip in front of the arithmetic, not three
+    uint32_t xa[4], xb[4];
+    load4(w_begin + 4u * threadIdx.x, xa);
+    load4(w_begin + 4u * (threadIdx.x + blockDim.x), xb);
+    // where this workgroup's candidates start
+    uint32_t acc = 0;
+    for (uint32_t k = threadIdx.x; k < g; k += blockDim.x) acc += wg_cnt[k];
+    for (int o = AM_WAVE / 2; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, AM_WAVE);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int k = 0; k < 256 / AM_WAVE; ++k) run += red[k];
+    uint32_t round = 0;
+    for (uint32_t c0 = w_begin; c0 < w_end; c0 += 4u * blockDim.x, ++round) {
+        const uint32_t w0 = c0 + 4u * threadIdx.x;
+        uint32_t x[4];
+        if (round == 0) { x[0] = xa[0]; x[1] = xa[1]; x[2] = xa[2]; x[3] = xa[3]; }
+        else if (round == 1) { x[0] = xb[0]; x[1] = xb[1]; x[2] = xb[2]; x[3] = xb[3]; }
+        else load4(w0, x);
+        const uint32_t c = (uint32_t)(__popc(x[0]) + __popc(x[1]) + __popc(x[2]) + __popc(x[3]));
+        uint32_t incl = c;
+        for (int d = 1; d < AM_WAVE; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
+            if (lane >= d) incl += up;
+        }
+        __syncthreads();                                      // (ws may still be read from the round before)
+        if (lane == AM_WAVE - 1) ws[wv] = incl;
+        __syncthreads();
+        uint32_t idx = run + incl - c, tot = 0;
+        for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) idx += ws[k]; tot += ws[k]; }
+        run += tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t word = x[k];
+            const uint32_t p0 = (w0 + (uint32_t)k) * wbits - lag;
+            while (word) {
+                const int b = __ffs((int)word) - 1;
+                if (idx < Mcap) pos[idx] = p0 + (uint32_t)b;
+                ++idx;
+                word &= word - 1u;
+            }
+        }
     }
-    AM_PIN_U32(cnt); AM_PIN_U32(off); AM_PIN_U32(word); AM_PIN_U32(p1); AM_PIN_U32(p2);
-    if (cnt == 0) return;
-    if (off >= M) return;
-    const uint32_t c = (uint32_t)__popcll((unsigned long long)word);
-    uint32_t incl = c;
-    for (int d = 1; d < AM_WAVE; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
-        if (lane >= d) incl += up;
-    }
-    uint32_t g = off + incl - c;
-    int prev_b = -1;
-    while (word) {
-        if (g >= M) break;
-        const int b = __ffsll((long long)word) - 1;
-        uint32_t gap;                                        // distance to the candidate before: this word, or the two words (wbits positions each) before it
-        if (prev_b >= 0) gap = (uint32_t)(b - prev_b);
-        else if (p1) gap = (uint32_t)b + wbits - (uint32_t)(31 - __clz((int)p1));
-        else if (p2) gap = (uint32_t)b + 2u * wbits - (uint32_t)(31 - __clz((int)p2));
-        else gap = 0xFFFFu;
-        uint32_t d = (uint32_t)spc + 1u;
-        d = gap < d ? gap : d;
-        pos[g] = (uint32_t)w * wbits + (uint32_t)b - lag;
-        dcount[g] = d;
-        ++g;
-        prev_b = b;
-        word &= word - 1u;
-    }
+    if (g == nwg - 1u && threadIdx.x == 0) *total_out = run;
 }
 
-hipError_t am_launch_gather_bits(const uint32_t *bits, const uint32_t *seg_cnt, const uint32_t *off_local,
-                                 const uint32_t *blk_base, uint32_t nseg, uint32_t M, int spc, uint32_t lag, uint32_t *pos,
-                                 uint32_t *dcount, hipStream_t s, const uint32_t *Mp, uint32_t wbits, uint32_t seg_words)
+hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uint32_t nwg, uint32_t words_per_wg,
+                               uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *pos,
+                               uint32_t *total_out, hipStream_t s)
 {
-    if (M == 0 || nseg == 0) return hipSuccess;
-    if (wbits == 0 || wbits > 32 || (uint32_t)spc + 1u > 2u * wbits || seg_words == 0 || seg_words > AM_WAVE) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(am_k_gather_bits, dim3((nseg + 3u) / 4u), dim3(4 * AM_WAVE), 0, s, bits, seg_cnt, off_local, blk_base, nseg, M, spc,
-                       lag, pos, dcount, Mp, wbits, seg_words);
+    if (nwg == 0) return hipSuccess;
+    if (wbits == 0 || wbits > 32 || words_per_wg == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(am_k_gather_wg, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag, wbits, pos,
+                       total_out);
     return hipGetLastError();
 }
 
@@ -692,21 +713,10 @@ __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_l
 #endif
 #define AM_ESTAGE 2048              /* floats of bb a pass may stage (8 KB) */
 
-// LATE MODE (late != null; behind the streaming front end, round 3): instead of E(q) the kernel writes one byte per
-// compact index, late[k] = (E(q+1) > E(q)), which is all the late-peak search asks (preamble_impl.cc:184-192) -- and
-// decides it from the EXACT difference of the two sums: they share all but eight samples,
-// D = sum over the four pulses of bb[q + c spc + spc] - bb[q + c spc].  Both reference sums have non-negative terms
-// not above V, so each carries a rounding error below (4 spc - 1) 2^-53 * 4 spc V <= 2^-39 V for spc <= 32; D is formed
-// here in double precision with an error below 2^-47 V.  Hence whenever |D| > 2^-36 V the sign of D IS the reference's
-// comparison; only closer calls (exact ties of quantised or constant input; non-finite samples: V = +inf) repeat the
-// reference's two sequential sums.  V comes from the front end: the largest bb of the workgroup segments the samples
-// lie in (vmax[array coordinate / vspan], am_fe4.hip).  Eight loads and a dozen operations per position instead of
-// 256 convert + add instructions: 31 -> 9 us at the bench density.
 __global__ void __launch_bounds__(256)
 am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,
             const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t Mcap, int spc,
-            double *__restrict__ energy, const uint32_t *__restrict__ Mp, uint8_t *__restrict__ late,
-            const float *__restrict__ vmax, uint32_t vspan, uint32_t nv)
+            double *__restrict__ energy, const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
     __shared__ uint32_t coff[AM_ECB + 1];   // compact offset of each candidate of this group (+ end)
@@ -745,31 +755,8 @@ am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, cons
         }
         __syncthreads();
         const uint32_t w0 = qr[0] & ~3u;                     // 16-byte aligned start of the window
-        const uint32_t wn = qr[1] + 10u * (uint32_t)spc + (late ? 1u : 0u) - w0;   // samples q .. q + 10*spc - 1 of every lane (late mode: one more)
-        if (late) {
-            // staged or not, the eight samples of D come from W or from memory; a close call goes to memory for both sums
-            const bool staged = wn <= AM_ESTAGE;               // (uniform)
-            if (staged) {
-                for (uint32_t i = 4u * threadIdx.x; i < wn; i += 4u * blockDim.x) {
-                    const float4 t = *reinterpret_cast<const float4 *>(bb + w0 + i);   // (arrays are padded)
-                    *reinterpret_cast<float4 *>(&W[i]) = t;
-                }
-                __syncthreads();
-            }
-            if (k < kend) {
-                const float *p = staged ? W + (q - w0) : bb + q;
-                const uint32_t v0 = q / vspan, v1 = (q + 11u * (uint32_t)spc + 1u) / vspan;
-                const float vb = fmaxf(vmax[v0 < nv ? v0 : nv - 1u], vmax[v1 < nv ? v1 : nv - 1u]);
-                const double bound = (double)vb * 0x1p-36;     // (+inf when a sample is not finite: nothing is decided by D)
-                double d = (double)p[spc] - (double)p[0];
-                d = d + ((double)p[3 * spc] - (double)p[2 * spc]);
-                d = d + ((double)p[8 * spc] - (double)p[7 * spc]);
-                d = d + ((double)p[10 * spc] - (double)p[9 * spc]);
-                bool lt = d > 0.0;
-                if (!(fabs(d) > bound)) lt = am_preamble_energy(bb + q + 1u, spc) > am_preamble_energy(bb + q, spc);
-                late[k] = lt ? 1 : 0;
-            }
-        } else if (wn <= AM_ESTAGE) {
+        const uint32_t wn = qr[1] + 10u * (uint32_t)spc - w0;   // samples q .. q + 10*spc - 1 of every lane
+        if (wn <= AM_ESTAGE) {
             for (uint32_t i = 4u * threadIdx.x; i < wn; i += 4u * blockDim.x) {
                 const float4 t = *reinterpret_cast<const float4 *>(bb + w0 + i);   // (arrays are padded)
                 *reinterpret_cast<float4 *>(&W[i]) = t;
@@ -820,7 +807,7 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
           const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t Mcap, int spc,
           float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
           float *__restrict__ inavg, uint8_t *__restrict__ valid, uint32_t *__restrict__ jump0,
-          const uint32_t *__restrict__ Mp, const uint8_t *__restrict__ late)
+          const uint32_t *__restrict__ Mp)
 {
     const uint32_t M = am_count(Mcap, Mp);
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -834,21 +821,7 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     // for spc dependent loads)
     int how_late = 0;
     bool rising = true;
-    if (late) {
-        // late mode (am_k_energy): one byte per position says whether the search moves on from it
-        const uint8_t *Lb = late + e_first;
-        for (int k0 = 0; k0 < spc && rising; k0 += 8) {
-            uint8_t lv[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) lv[k] = Lb[(k0 + k < spc) ? k0 + k : spc - 1];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (rising && k0 + k < spc) {
-                    if (lv[k]) how_late++; else rising = false;
-                }
-            }
-        }
-    } else {
+    {
         const double *E = energy + e_first;
         for (int k0 = 0; k0 < spc && rising; k0 += 8) {
             double ev[9];
@@ -892,6 +865,153 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     }
 }
 
+// The refinement behind the streaming front ends in ONE launch (round 4): late-peak decisions and the per-candidate test
+// of am_k_energy (late mode) + am_k_cand, per group of AM_RCB consecutive candidates.  The decisions never leave LDS, and
+// with them went the global compact layout: no distance-to-the-predecessor array, no scan of it (two launches fewer, and
+// am_k_gather_bits no longer writes 4 bytes per candidate).
+//   * candidate i of the group owns the positions [lo_i, pos_i + spc), lo_i = max(pos_i, pos_{i-1} + spc) -- what its
+//     predecessors in the group do not cover (the group's first candidate: all spc of them; a neighbouring group may
+//     decide up to spc - 1 positions a second time, identically); an LDS scan of the counts lays them out contiguously,
+//     position pos_i + s at index coff[i] - (lo_i - pos_i) + s;
+//   * one lane per position: late[k] = (E(q+1) > E(q)).  The late-peak search only needs the SIGN of E(q+1) - E(q), and
+//     the two sums share all but eight samples: D = sum over the four pulses of bb[q + c spc + spc] - bb[q + c spc].  Both
+//     reference sums have non-negative terms not above V, so each carries a rounding error below (4 spc - 1) 2^-53 * 4 spc V
+//     <= 2^-39 V for spc <= 32; D is formed here in double precision with an error below 2^-47 V.  Hence whenever
+//     |D| > 2^-36 V the sign of D IS the reference's comparison; only closer calls (exact ties of quantised or constant
+//     input; non-finite samples: V = +inf) repeat the reference's two sequential sums (preamble_impl.cc:91-98).  V comes from
+//     the front end: the largest bb of the workgroup segments the samples lie in (vmax[array coordinate / vspan]);
+//   * one lane per candidate: the late-peak search over those bytes (preamble_impl.cc:184-192), the quiet zones
+//     (:198-209), the record, and the greedy chain's successor.
+#define AM_RCB 256                  /* candidates per workgroup */
+__global__ void __launch_bounds__(256)
+am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
+                 uint32_t Mcap, int spc, float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo,
+                 uint32_t *__restrict__ tgt, float *__restrict__ inavg, uint8_t *__restrict__ valid,
+                 uint32_t *__restrict__ jump0, const uint32_t *__restrict__ Mp, const float *__restrict__ vmax,
+                 uint32_t vspan, uint32_t nv)
+{
+    const uint32_t M = am_count(Mcap, Mp);
+    __shared__ uint32_t coff[AM_RCB + 1];   // compact index of the first position candidate i owns (+ end)
+    __shared__ uint32_t clo[AM_RCB];        // that position
+    __shared__ uint32_t ws[AM_RCB / AM_WAVE];
+    __shared__ uint8_t LATE[AM_RCB * 32];   // (spc <= 32: the launcher checks)
+    const uint32_t c0 = blockIdx.x * AM_RCB;
+    if (c0 >= M) return;                                      // (uniform)
+    const uint32_t nc = (M - c0 < AM_RCB) ? M - c0 : AM_RCB;
+    const uint32_t i = threadIdx.x;
+    const int lane = (int)(i & (AM_WAVE - 1)), wv = (int)(i / AM_WAVE);
+    const bool live = i < nc;
+    const uint32_t g = c0 + (live ? i : 0u);
+    const uint32_t j = pos[g];
+    uint32_t lo = j, d = 0;
+    if (live) {
+        if (i) { const uint32_t pv = pos[g - 1u] + (uint32_t)spc; lo = pv > j ? pv : j; }
+        d = j + (uint32_t)spc - lo;                           // >= 1: positions ascend strictly
+    }
+    {
+        uint32_t incl = d;
+        for (int o = 1; o < AM_WAVE; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, AM_WAVE);
+            if (lane >= o) incl += up;
+        }
+        if (lane == AM_WAVE - 1) ws[wv] = incl;
+        __syncthreads();
+        uint32_t off = incl - d;
+        for (int k = 0; k < wv; ++k) off += ws[k];
+        if (live) { coff[i] = off; clo[i] = lo; }
+        if (i == nc - 1u) coff[nc] = off + d;
+    }
+    __syncthreads();
+    const uint32_t kend = coff[nc];
+    // V bounds every sample the group's positions can see: the largest bb of the front-end workgroups whose segments they
+    // span (usually one; a larger V only sends more close calls to the exact sums)
+    float vb = 0.0f;
+    {
+        uint32_t v0 = clo[0] / vspan, v1 = (clo[nc - 1u] + 13u * (uint32_t)spc + 1u) / vspan;
+        v0 = v0 < nv ? v0 : nv - 1u;
+        v1 = v1 < nv ? v1 : nv - 1u;
+        for (uint32_t v = v0; v <= v1; ++v) vb = fmaxf(vb, vmax[v]);      // (every lane the same words)
+    }
+    const double bound = (double)vb * 0x1p-36;                 // (+inf when a sample is not finite: nothing is decided by D)
+    // four positions per lane and round, their 32 loads in flight together (a group has ~950 positions: one round trip; the
+    // first version staged each 256-position pass in LDS behind barriers: four dependent round trips)
+    for (uint32_t k0 = 0; k0 < kend; k0 += 4u * blockDim.x) {
+        uint32_t q[4];
+        bool has[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t k = k0 + (uint32_t)u * blockDim.x + threadIdx.x;
+            has[u] = k < kend;
+            uint32_t l = 0, h = nc;                            // last candidate with coff <= k
+            const uint32_t kk = has[u] ? k : kend - 1u;
+            while (h - l > 1) {
+                const uint32_t mid = (l + h) >> 1;
+                if (coff[mid] <= kk) l = mid; else h = mid;
+            }
+            q[u] = clo[l] + (kk - coff[l]);
+        }
+        float x[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *p = bb + q[u];                        // (arrays are padded: a lane without a position reads its neighbour's)
+            x[u][0] = p[0]; x[u][1] = p[spc]; x[u][2] = p[2 * spc]; x[u][3] = p[3 * spc];
+            x[u][4] = p[7 * spc]; x[u][5] = p[8 * spc]; x[u][6] = p[9 * spc]; x[u][7] = p[10 * spc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double dd = (double)x[u][1] - (double)x[u][0];
+            dd = dd + ((double)x[u][3] - (double)x[u][2]);
+            dd = dd + ((double)x[u][5] - (double)x[u][4]);
+            dd = dd + ((double)x[u][7] - (double)x[u][6]);
+            bool lt = dd > 0.0;
+            if (has[u] && !(fabs(dd) > bound)) lt = am_preamble_energy(bb + q[u] + 1u, spc) > am_preamble_energy(bb + q[u], spc);
+            if (has[u]) LATE[k0 + (uint32_t)u * blockDim.x + threadIdx.x] = lt ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // ---- one lane per candidate -------------------------------------------------------------------------------
+    int how_late = 0;
+    if (live) {
+        const uint8_t *Lb = LATE + (coff[i] - (lo - j));       // decision of position j (see above: never below LATE[0])
+        bool rising = true;
+        for (int k = 0; k < spc && rising; ++k) {
+            if (Lb[k]) how_late++; else rising = false;
+        }
+    }
+    const uint32_t e = j + (uint32_t)how_late;
+    // quiet zones (preamble_impl.cc:198-209)
+    const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
+    const float av = (e >= end_j) ? 0.0f : avg_sparse[e];    // beyond the end of the stream: 0
+    float ps = p0 + p1;
+    ps = ps + p2;
+    ps = ps + p3;
+    const float avgpeak = (float)((double)ps / 4.0);
+    const float sthr = av + (avgpeak - av) / thr_lin;
+    const bool ok = live && !am_any_above2(bb + e + 3 * spc, 3 * spc + 1,             // offsets 3spc .. 6spc
+                                           bb + e + 10 * spc, 5 * spc + 1, sthr);     // offsets 10spc .. 15spc
+    if (!live) return;
+    eo[g] = e;
+    inavg[g] = av;
+    valid[g] = ok ? 1 : 0;
+    const uint32_t tg = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+    tgt[g] = tg;
+    // the greedy chain's successor: first candidate at or after the resume position
+    jump0[g] = am_lower_bound(pos, g + 1u, M, tg);
+    if (g == M - 1u) jump0[M] = M;
+}
+
+hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const uint32_t *pos, uint32_t M, int spc,
+                                 float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
+                                 uint32_t *jump0, hipStream_t s, const uint32_t *Mp, const float *vmax, uint32_t vspan,
+                                 uint32_t nv)
+{
+    if (M == 0) return hipSuccess;
+    if (spc > 32 || spc < 1 || !vmax || vspan == 0 || nv == 0 || !jump0) return hipErrorInvalidValue;   // (the rounding bound is stated for 4 spc <= 128 terms)
+    hipLaunchKernelGGL(am_k_refine_late, dim3((M + AM_RCB - 1) / AM_RCB), dim3(AM_RCB), 0, s, bb, avg_sparse, pos, M, spc, thr_lin,
+                       end_j, e, tgt, inavg, valid, jump0, Mp, vmax, vspan, nv);
+    return hipGetLastError();
+}
+
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
                                 uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
                                 hipStream_t s, const uint32_t *Mp)
@@ -919,24 +1039,22 @@ hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n,
 }
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s, const uint32_t *Mp, uint8_t *late, const float *vmax,
-                            uint32_t vspan, uint32_t nv)
+                            double *energy, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
-    if (late && (spc > 32 || !vmax || vspan == 0 || nv == 0)) return hipErrorInvalidValue;   // (the rounding bound is stated for 4 spc <= 128 terms)
     const unsigned grid = (unsigned)(((uint64_t)M + AM_ECB - 1) / AM_ECB);
     hipLaunchKernelGGL(am_k_energy, dim3(grid), dim3(256), 0, s, bb, pos, dcount, off_local, blk_base, M, spc,
-                       energy, Mp, late, vmax, vspan, nv);
+                       energy, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
                           const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
                           int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp, const uint8_t *late)
+                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp)
 {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_cand, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg_sparse, pos, dcount, off_local,
-                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp, late);
+                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp);
     return hipGetLastError();
 }
 
@@ -1116,25 +1234,30 @@ __device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint16_t
 #define AM_KEEP_VGPR(x) ((void)0)
 #endif
 
-// Time shards, device-side composition of the exit tables (am_shard_entry on the host does the same): msgs = `world`
-// messages of 1 + cap entries each, entry 0 = header {count, overflow}, then the table.  The scan starts at sample 0; chunk r
-// is entered at `cur`; the first candidate of chunk r at or after cur says where the scan leaves the chunk.  Returns the
-// absolute position at which the scan enters chunk `rank`; *bad = 1 if some table did not fit its message or some scan met
-// more candidates than its capacity (the caller then repeats the step on the synchronous path: every rank alike).
+// Time shards, device-side composition of the exit tables (am_shard_entry2 on the host does the same): msgs = `world`
+// messages of AM_SHARD_MSG_HEADER + cap entries each: entry 0 = {count, overflow}, entry 1 = {where the scan left that
+// rank's chunk in the step BEFORE, -}, then the table.  The scan enters chunk 0 where it left the last chunk of the step
+// before (0 at the start of a stream); chunk r is entered at `cur`; the first candidate of chunk r at or after cur says
+// where the scan leaves the chunk.  Returns the absolute position at which the scan enters chunk `rank`, *exit_out = where
+// it leaves it; *bad = 1 if some table did not fit its message or some scan met more candidates than its capacity (the
+// caller then repeats the step on the synchronous path: every rank alike).
 // ONE WAVE calls it (all 64 lanes).  The chain over the chunks is sequential (where chunk r is entered depends on where chunk
 // r - 1 was left), but inside a table the first entry at or after `cur` is found 64 entries per memory round trip (positions
 // ascend: a ballot) -- one thread stepping through a table entry by entry paid a dependent load per entry, and chunk 7 of 8
 // waits for seven tables.
 __device__ __forceinline__ uint64_t am_shard_entry_wave(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank,
-                                                        uint32_t cap, int lane, uint32_t *bad_out)
+                                                        uint32_t cap, int lane, uint32_t *bad_out, uint64_t *exit_out)
 {
-    uint64_t cur = 0;
+    const size_t stride = (size_t)cap + AM_SHARD_MSG_HEADER;
+    uint64_t cur = msgs[(size_t)(world - 1u) * stride + 1u].pos;             // (every lane reads the same word)
+    uint64_t entry = cur;
     uint32_t bad = 0;
-    for (uint32_t r = 0; r < rank; ++r) {
-        const am_shard_exit *m = msgs + (size_t)r * (cap + 1u);
+    for (uint32_t r = 0; r <= rank; ++r) {
+        const am_shard_exit *m = msgs + (size_t)r * stride;
         const uint64_t n = m[0].pos;
         if (n > cap || m[0].exit != 0) { bad = 1; break; }
-        const am_shard_exit *t = m + 1;
+        if (r == rank) entry = cur;
+        const am_shard_exit *t = m + AM_SHARD_MSG_HEADER;
         for (uint64_t i0 = 0; i0 < n; i0 += AM_WAVE) {                       // (uniform)
             const uint64_t i = i0 + (uint64_t)lane;
             const bool here = i < n && t[i].pos >= cur;
@@ -1147,10 +1270,11 @@ __device__ __forceinline__ uint64_t am_shard_entry_wave(const am_shard_exit *__r
             }
         }                                                                     // (no candidate left: the scan passes through)
     }
-    for (uint32_t r = rank + (uint32_t)lane; r < world && !bad; r += AM_WAVE) // (every rank must take the same decision)
-        if (msgs[(size_t)r * (cap + 1u)].pos > cap || msgs[(size_t)r * (cap + 1u)].exit != 0) bad = 1;
+    for (uint32_t r = rank + 1u + (uint32_t)lane; r < world && !bad; r += AM_WAVE)   // (every rank must take the same decision)
+        if (msgs[(size_t)r * stride].pos > cap || msgs[(size_t)r * stride].exit != 0) bad = 1;
     *bad_out = __ballot(bad != 0u) != 0ull ? 1u : 0u;
-    return cur;
+    *exit_out = cur;
+    return entry;
 }
 
 // entry[b] = node at which the scan that starts at position cur0 enters block b, AM_CB_NONE if it
@@ -1175,12 +1299,14 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
     if (es.msgs) {
         if (threadIdx.x < AM_WAVE) {
             uint32_t bad = 0;
-            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad);
+            uint64_t leave = 0;
+            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad, &leave);
             if (threadIdx.x == 0) {
                 uint64_t rel = cur > es.base_abs ? cur - es.base_abs : 0;
                 if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
                 cur0_s = (uint32_t)rel;
                 es.flags[0] = bad;                           // (written either way: nobody has to clear it first)
+                if (!bad) *es.exit_out = leave;              // where the scan leaves this chunk: the next step's message carries it
             }
         }
     } else if (threadIdx.x == 0)
@@ -1306,7 +1432,7 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
                      const uint32_t *__restrict__ exitnode, const uint32_t *__restrict__ lastnode,
                      const uint16_t *__restrict__ headlink, uint32_t Mcap, uint32_t nblk, uint32_t headw, uint32_t n,
                      uint32_t lead_end, uint64_t base_abs, am_shard_exit *__restrict__ table,
-                     const uint32_t *__restrict__ Mp, am_shard_exit *__restrict__ header)
+                     const uint32_t *__restrict__ Mp, am_shard_exit *__restrict__ header, const uint64_t *__restrict__ carry)
 {
     const uint32_t M = am_count(Mcap, Mp);
     // header (device-side exchange of the tables): pos = number of entries = up to and including the first candidate at or
@@ -1316,6 +1442,7 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
     if (header) {
         const uint32_t nr = M < n ? M : n;
         const uint64_t over = (Mp && *Mp > Mcap) ? 1u : 0u;
+        if (threadIdx.x == 0 && carry) { header[1].pos = *carry; header[1].exit = 0; }
         if (nr == 0) {
             if (threadIdx.x == 0) { header->pos = 0; header->exit = over; }
         } else
@@ -1665,7 +1792,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;   // (more than ~75 000 blocks of 2048 candidates in one scan)
     am_entry_src es;
     if (entry_src) es = *entry_src;
-    else { es.msgs = nullptr; es.world = 0; es.rank = 0; es.cap = 0; es.base_abs = 0; es.flags = nullptr; }
+    else { es.msgs = nullptr; es.world = 0; es.rank = 0; es.cap = 0; es.base_abs = 0; es.flags = nullptr; es.exit_out = nullptr; }
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp, es);
     am_emit_args ea;
@@ -1680,7 +1807,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
 // exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
-                                      hipStream_t s, const uint32_t *Mp, am_shard_exit *header)
+                                      hipStream_t s, const uint32_t *Mp, am_shard_exit *header, const uint64_t *carry)
 {
     if (n == 0 || M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -1691,34 +1818,46 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
     const size_t lds = am_chain_walk_lds_bytes(L.nblk, L.headw);          // (links + group exits: the walk's layout holds both)
     if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(am_k_cblk_exit_table, dim3(1), dim3(1024), lds, s, pos, tgt, scratch, scratch + L.off_last,
-                       reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp, header);
+                       reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk, L.headw, n, lead_end, base_abs, table, Mp, header, carry);
     return hipGetLastError();
 }
 
-// Time shards, device-side composition of the exit tables (am_shard_entry on the host does the same): msgs = `world`
-// messages of 1 + cap entries each, entry 0 = header {count, -}, then the table.  The scan starts at sample 0; chunk r is
-// entered at `cur`; the first candidate of chunk r at or after cur says where the scan leaves the chunk.  Writes the
-// array coordinate at which the scan enters chunk `rank` (cur0_out) and flags[0] |= 1 if some table did not fit its
-// message (the caller then repeats the step with full-size tables).
+// The composition as a launch of its own (am_shard_entry_wave): where nothing is left to slice -- otherwise the block walk
+// composes the entry itself.  Writes the array coordinate at which the scan enters chunk `rank` (cur0_out), where it leaves
+// it (*exit_out) and flags[0] = 1 if some table did not fit its message.  With msgs == null (a chunk without a single
+// candidate before the first exchange): the header of the own message only -- {0, 0}, {carry, 0}.
 __global__ void __launch_bounds__(AM_WAVE)
 am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
-                 uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags)
+                 uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags,
+                 uint64_t *__restrict__ exit_out, am_shard_exit *__restrict__ header, const uint64_t *__restrict__ carry)
 {
-    // (a launch of its own only where nothing is left to slice: otherwise the block walk composes the entry itself)
     if (blockIdx.x != 0) return;
+    if (header) {
+        if (threadIdx.x == 0) { header[0].pos = 0; header[0].exit = 0; header[1].pos = *carry; header[1].exit = 0; }
+        return;
+    }
     uint32_t bad = 0;
-    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad);
+    uint64_t leave = 0;
+    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad, &leave);
     if (threadIdx.x != 0) return;
     uint64_t rel = cur > base_abs ? cur - base_abs : 0;
     if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
     *cur0_out = (uint32_t)rel;
     flags[0] = bad;
+    if (!bad) *exit_out = leave;
 }
 
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
-                                 uint32_t *cur0_out, uint32_t *flags, hipStream_t s)
+                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags);
+    hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags, exit_out,
+                       (am_shard_exit *)nullptr, (const uint64_t *)nullptr);
+    return hipGetLastError();
+}
+hipError_t am_launch_shard_header(am_shard_exit *header, const uint64_t *carry, hipStream_t s)
+{
+    hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, (const am_shard_exit *)nullptr, 0u, 0u, 0u, (uint64_t)0,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, header, carry);
     return hipGetLastError();
 }
 
@@ -2185,6 +2324,10 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
 // Completion ticket: the last launch of a scan.  The host polls the pinned word instead of asking the
 // runtime (whose completion path costs tens of microseconds per scan).
 // (count_src / count_dst: a device-side count to hand to the host along with the ticket, or null)
+// (Round 4: the ticket handed out by the last workgroup of the extraction kernel instead -- every workgroup counts itself
+// done with an atomic, the last one stores the ticket.  The count has to be ordered behind the workgroup's packet stores: with
+// a system-scope fence per workgroup the extraction kernel went 55 -> 111 us, with a device-scope one 55 -> 159 us -- on this
+// part either one writes back an XCD's L2, 1 300 times over.  The launch of its own, 4.2 us + the gap, stays.)
 // (hipStreamWriteValue32 in its place -- a queue packet instead of a dispatch -- measured the same step time, 64 and 2 Msps.)
 __global__ void am_k_ticket(uint32_t *host_word, uint32_t seq, const uint32_t *count_src, uint32_t *count_dst)
 {

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AM_ABI_VERSION 1
+#define AM_ABI_VERSION 2
 
 /* error codes */
 #define AM_OK          0
@@ -39,6 +39,8 @@ extern "C" {
 #define AM_F_FLUSH      0x2u  /* end of stream: examine the tail under the reference's
                                  end-of-buffer rule (preamble_impl.cc:150,212)              */
 #define AM_F_DEVICE_OUT 0x4u  /* am_frontend_work only: bb/avg are device pointers          */
+#define AM_F_MORE       0x10u /* am_shard_scan / am_shard_scan_async: the stream goes on beyond total_n (= the samples so
+                                 far): no end-of-stream rule; the chunk must come with its whole right halo            */
 #define AM_F_KEEP_TAGS  0x8u  /* am_process_iq / am_submit_iq: also keep what the preamble block hands the slicer for
                                  this call's hits -- 240-float bursts + "preamble_found" tags (lib/preamble_impl.cc:
                                  219-232) -- for am_fetch_tags                                  */
@@ -234,6 +236,7 @@ int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
  * am_shard_entry: tables[r] / counts[r] for r = 0..nranks-1 in chunk order, starts[r] = abs_start of
  *   chunk r; writes entry[r] = scan position when it reaches chunk r (entry[0] = 0). Host only.
  * am_shard_resolve: cur_in = entry of this rank's chunk. */
+#define AM_SHARD_MSG_HEADER 2   /* header entries of a device message (am_shard_scan_async) */
 typedef struct am_shard_exit {
     uint64_t pos;          /* absolute position of the candidate                            */
     uint64_t exit;         /* scan position after the chunk's last visited candidate, if the
@@ -247,11 +250,28 @@ int am_shard_scan(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs
 int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, const uint64_t *starts,
                    uint32_t nranks, uint64_t *entry);
 int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out);
+/* A receiver, not a batch (round 4): the scan position crosses STEPS as it crosses chunks (lib/preamble_impl.cc:213,237,244:
+ * consume_each -- the reference's scan resumes where the last general_work left off, for ever).  Step k covers the samples
+ * [k W n, (k + 1) W n); rank r owns the POSITIONS [k W n + r n - H, k W n + (r + 1) n - H), H = `right` of am_shard_halo (the
+ * look-ahead a decision needs), so its chunk needs left + H samples of the rank before it (of the last rank's previous
+ * step for rank 0) and none of the rank after it; it scans with AM_F_MORE and total_n = the samples so far, and the last
+ * step of the stream without the flag and with the true length.
+ * am_shard_entry2: am_shard_entry with the position at which the scan left the last chunk of the step before (cur_in; 0 at
+ *   the start of a stream); also writes leave[r] = where the scan leaves chunk r (either array may be NULL).
+ * am_shard_get_exit / am_shard_set_exit: where the scan left THIS context's chunk in its last resolved step -- the word the
+ *   host-free step keeps on the device and sends along in the next step's message header (below); a step that ran on the
+ *   synchronous path sets it (leave[rank]), a caller that falls back to that path reads it. */
+int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *counts, uint32_t nranks, uint64_t cur_in,
+                    uint64_t *entry, uint64_t *leave);
+int am_shard_get_exit(am_ctx *ctx, uint64_t *pos);
+int am_shard_set_exit(am_ctx *ctx, uint64_t pos);
 
 /* The same step without a host round trip in the middle (round 3): the exit table stays on the device.
  * am_shard_scan_async: as am_shard_scan, but everything is only ENQUEUED and the table goes to the device message
- *   msg_dev = 1 + msg_cap entries: entry 0 = {count, overflow}, then the table (count = msg_cap + 1: it did not fit;
- *   overflow = 1: the scan met more candidates than the capacity it was launched for).
+ *   msg_dev = AM_SHARD_MSG_HEADER + msg_cap entries: entry 0 = {count, overflow} (count = msg_cap + 1: the table did not
+ *   fit; overflow = 1: the scan met more candidates than the capacity it was launched for), entry 1 = {where the scan left
+ *   this context's chunk in the step before, -} (how the scan position reaches the next step: every rank reads the last
+ *   rank's), then the table.
  * The caller all-gathers the messages (device to device, e.g. torch.distributed over RCCL: am_signal_stream makes the
  *   collective's stream wait for the table, am_wait_for_stream the context for the collective) and hands all `world`
  *   of them, in chunk order, to

@@ -25,6 +25,7 @@ struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline void __threadfence_system() {}
+static inline void __threadfence() {}
 #define __builtin_readcyclecounter() 0ull
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
@@ -67,6 +68,7 @@ inline int __syncthreads_or(int pred) { return hipemu::barrier_or(pred); }
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
 // (fibers of one OS thread never interleave inside this)
 #define __hip_atomic_compare_exchange_strong(p, expected, desired, so, fo, scope) ((*(p) == *(expected)) ? (*(p) = (desired), true) : (*(expected) = *(p), false))
 // only used on values that are already the same in every lane of the wave
@@ -77,6 +79,8 @@ inline int __syncthreads_or(int pred) { return hipemu::barrier_or(pred); }
 #define __builtin_amdgcn_wave_barrier() ((void)hipemu::ballot(0))
 inline unsigned long long __ballot(int pred) { return hipemu::ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }

@@ -34,9 +34,13 @@ def test_single_gpu_line(emu_lib):
 def test_gpus_2_launches_two_ranks_time_sharded(emu_lib):
     d = run_bench("--gpus", "2", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
-    assert d["parity"] is True and d["parity_detail"]["short_stream_all_ranks"] is True
+    assert d["parity"] is True and d["parity_detail"]["short_stream_two_steps_all_ranks"] is True
     assert d["parity_detail"]["rank0_full_size"] is True
     assert "time-chunk shards x2" in d["config"]["parallelism"]
+    # the N > 1 line carries the roofline of the dominant kernel (it printed 0): every rank's event pair
+    r = d["roofline"]
+    assert r["frac"] > 0 and r["kernel_ms"] > 0 and 0 < r["kernel_ms_per_rank"]["min"] <= r["kernel_ms_per_rank"]["max"]
+    assert d["sharded_sync_steps"] == 0
 
 
 def test_replicas_two_receivers(emu_lib):
@@ -49,3 +53,9 @@ def test_replicas_two_receivers(emu_lib):
 def test_lambda_knob(emu_lib):
     d = run_bench("--workload", "20msps", "--seconds", "0.01", "--lambda", "500", "--batches", "1")
     assert d["config"]["bursts_per_second"] == 500 and d["parity"] is True
+
+
+def test_force_sharded_one_rank_line(emu_lib):
+    """--force-sharded: one rank through the streaming time-shard receiver; the line carries the dominant kernel's time."""
+    d = run_bench("--force-sharded", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["parity"] is True and d["roofline"]["frac"] > 0

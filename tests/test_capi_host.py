@@ -26,7 +26,7 @@ def test_library_builds_loads_and_exports_all_symbols():
     for s in syms:
         assert hasattr(lib, s), "libairmodes_hip.so does not export %s" % s
     lib.am_abi_version.restype = ctypes.c_uint32
-    assert lib.am_abi_version() == 1
+    assert lib.am_abi_version() == 2
     # host-only helpers are callable without a GPU
     lib.am_crc24.restype = ctypes.c_uint32
     b = bytes.fromhex("8D4840D6202CC371C32CE0")

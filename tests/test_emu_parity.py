@@ -140,6 +140,10 @@ def test_greedy_chain_rare_branches(emu_lib_rare):
     assert ctx.last_num_candidates() > 2 * 2048
     ctx.close()
     assert np.array_equal(pk, oracle.demod(iq64, 64e6, 7.0, True)) and len(pk) > 20
+    # the rare build runs 64 Msps through am_k_fe4<32, 1, 3> (-DFE4_64MSPS: three waves, all 64 lanes own a chip, 48-chip
+    # blocks that straddle waves) instead of am_k_fe3: stage-level parity of that kernel
+    assert pc.check_production_stages(emu_lib_rare, 64e6, 900000, 20000.0, 78, with_ref=True, want_fe=3) > 0
+    assert pc.check_production_stages(emu_lib_rare, 64e6, 800000, 20000.0, 79, pmf=False, chunks=[250001, 600000], want_fe=3) > 0
 
 
 def test_speculative_capacity_overflow_is_redone(emu_lib, monkeypatch):

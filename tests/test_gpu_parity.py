@@ -263,6 +263,10 @@ def test_greedy_chain_rare_branches_on_device():
     assert ctx.last_num_candidates() > 16 * 2048
     ctx.close()
     assert np.array_equal(pk, oracle.demod(iq64, 64e6, 7.0, True)) and len(pk) > 100
+    # the rare build runs 64 Msps through am_k_fe4<32, 1, 3> (-DFE4_64MSPS: three waves, all 64 lanes own a chip, 48-chip
+    # blocks that straddle waves) instead of am_k_fe3: stage-level parity of that kernel on the device
+    assert pc.check_production_stages(rare, 64e6, 12_000_000, 20000.0, 608, with_ref=True, want_fe=3) > 0
+    assert pc.check_production_stages(rare, 64e6, 5_000_000, 20000.0, 609, chunks=[1_000_001, 3_300_000], want_fe=3) > 0
 
 
 def test_streaming_and_tile_front_ends_agree(klib, monkeypatch):
@@ -317,7 +321,9 @@ def test_batches_in_flight_single_host_thread(lib):
 
 @pytest.mark.parametrize("rate,n,lam,fe", [(64e6, 64_000_000, 20000.0, 3), (64e6, 16_000_000, 2000.0, 3),
                                             (20e6, 20_000_000, 5000.0, 3), (2e6, 20_000_000, 500.0, 3),
-                                            (4e6, 8_000_000, 1000.0, 3), (10e6, 4_000_000, 2000.0, 3)])
+                                            (4e6, 8_000_000, 1000.0, 3), (10e6, 4_000_000, 2000.0, 3),
+                                            (8e6, 6_000_000, 2000.0, 3), (16e6, 6_000_000, 4000.0, 3),
+                                            (32e6, 8_000_000, 8000.0, 3), (40e6, 8_000_000, 10000.0, 3)])
 def test_production_stages_full_size(lib, rate, n, lam, fe):
     """stage-level parity of the kernels that actually run -- at the BASELINE sizes the
     record of every first-stage candidate (bitmap position, refined position, quiet-zone outcome, reference level), the
@@ -347,25 +353,38 @@ def test_host_free_sharded_step_on_device(lib):
     rx.chunk.copy_(torch.from_numpy(iq.view(np.float32)))
     torch.cuda.synchronize()
     for _ in range(3):
-        assert np.array_equal(rx.step(), want)
+        assert np.array_equal(rx.step(flush=True), want)       # (flush: a finite batch, the receiver starts over)
     assert rx.sync_steps == 0
+    # ... and as a STREAM: the same capture in four steps of n / 4 samples -- the scan position, the undecided tail and the
+    # sample count cross the steps (lib/preamble_impl.cc:213,237,244); one rank = the last rank = rank 0
+    m4 = n // 4
+    rx4 = ShardedReceiver(ctx, 0, 1, m4, device="cuda:0")
+    parts = []
+    for k in range(4):
+        rx4.chunk.copy_(torch.from_numpy(iq[k * m4:(k + 1) * m4].view(np.float32)))
+        parts.append(rx4.step(flush=(k == 3)))
+    assert np.array_equal(np.concatenate(parts), want) and all(len(p_) > 0 for p_ in parts)
+    assert rx4.sync_steps == 0
     ctx.close()
     # four chunks on one GPU, tables gathered by hand: what the all_gather delivers
     G, cap = 4, 512
     ctxs = [_capi.Context(rate, 7.0, True, lib=lib) for _ in range(G)]
     hl, hr = ctxs[0].shard_halo()
     dev = torch.device("cuda:0")
-    msgs = torch.zeros(G * 2 * (1 + cap), dtype=torch.int64, device=dev)
+    W = 2 * (_capi.SHARD_MSG_HEADER + cap)                     # int64 words per message: header + cap entries of (pos, exit)
+    msgs = torch.zeros(G * W, dtype=torch.int64, device=dev)
     bufs = []
     m = n // G
     got = None
     for rep in range(2):               # (the second pass launches for a capacity: no read-back at all)
+        for c_ in ctxs:
+            c_.reset()                 # (a new stream: the scan starts at sample 0 again, not where the last pass left off)
         for g in range(G):
             a, b = g * m, (g + 1) * m
             lo, hi = max(0, a - hl), min(n, b + hr)
             t = torch.from_numpy(iq[lo:hi].view(np.float32)).to(dev)
             bufs.append(t)
-            ctxs[g].shard_scan_async(t.data_ptr(), a, b, n, msgs[g * 2 * (1 + cap):].data_ptr(), cap)
+            ctxs[g].shard_scan_async(t.data_ptr(), a, b, n, msgs[g * W:].data_ptr(), cap)
         torch.cuda.synchronize()
         parts = []
         for g in range(G):
@@ -404,7 +423,7 @@ def test_stream_ordering_by_events_on_device(lib):
     assert np.array_equal(got, want)
     # the other direction: the table of an enqueued scan, copied by the side stream
     cap = 512
-    msg = torch.full((2 * (1 + cap),), -1, dtype=torch.int64, device=dev)
+    msg = torch.full((2 * (_capi.SHARD_MSG_HEADER + cap),), -1, dtype=torch.int64, device=dev)
     seen = torch.empty_like(msg)
     torch.cuda.synchronize()
     ctx.shard_scan_async(src.data_ptr(), 0, n, n, msg.data_ptr(), cap)

