@@ -124,6 +124,7 @@ struct am_ctx {
     uint32_t fe_nwg = 0, fe_wpw = 0, fe_nwords = 0;   // ... front-end workgroups, bitmap words per workgroup, words in all
     DevBuf lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
+    uint32_t tk_base[2] = {0, 0};     // value of the ticket counters scalars[10], [11] when the next launch on them starts (am_chain_place)
 
     // results of the last scan
     std::vector<am_packet> h_packets;   // am_slicer_work: every sliced burst, reserved[0] = accepted
@@ -379,6 +380,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
     c->Mdev = nullptr;
     c->jump_ready = false;
     if (nseg == 0) return AM_OK;
+    if (int rcs = ensure_scalars(c); rcs != AM_OK) return rcs;
     const uint32_t *count_ptr = (const uint32_t *)c->blk_off.p + nseg;       // device-side total
     if (mode == 3) {
         // streaming front end: the flat list is laid out from the per-workgroup counts by the gather kernel itself, which also
@@ -437,6 +439,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             if (int rc = ensure_slots(c, c->lb_dc, nb); rc != AM_OK) return rc;
             HIPCHK(c, am_launch_exscan_chain((uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p, M,
                                              (unsigned long long *)c->lb_dc.p, next_epoch(c), (uint32_t *)c->blk_base2.p + nb,
+                                             (uint32_t *)c->scalars.p + 9, (uint32_t *)c->scalars.p + 10, &c->tk_base[0],
                                              c->stream, Mp));
             HIPCHK(c, am_launch_energy(bb, (uint32_t *)c->pos.p, (uint32_t *)c->dcount.p, (uint32_t *)c->off_local.p,
                                        nullptr, M, c->spc, (double *)c->energy.p, c->stream, Mp));
@@ -584,6 +587,11 @@ int chain_prepare(am_ctx *c, uint32_t M, bool want_last, const uint32_t *Mp = nu
 int chain_collect(am_ctx *c, uint32_t M, const uint32_t *Mp, uint32_t n_max, bool keep_bursts, uint32_t *final_cur)
 {
     c->tail_synced = true;
+    if (c->pin_scalars[5]) {
+        // a chained scan gave up waiting for a workgroup that never published (am_chain_prefix): nothing of this step is valid
+        (void)hipMemsetAsync((uint32_t *)c->scalars.p + 9, 0, sizeof(uint32_t), c->stream);
+        return fail(c, AM_EHIP, "a chained scan on the device timed out (a workgroup never published its count)");
+    }
     if (Mp) {
         // launched for a capacity: now the real candidate count is known
         c->last_M = c->pin_scalars[2];
@@ -642,7 +650,8 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     HIPCHK(c, am_launch_chain_visit((uint32_t *)c->pos.p, (uint32_t *)c->jump.p, M, cur0, (uint32_t *)c->cscratch.p,
                                     (uint8_t *)c->valid.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, emit_max, own_lo,
                                     own_hi, (uint32_t *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
-                                    next_epoch(c), (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp,
+                                    next_epoch(c), (uint32_t *)c->scalars.p + 11, &c->tk_base[1],
+                                    (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp,
                                     c->entry_src));
     const bool keep_dev = keep_bursts || c->keep_tags;       // the bursts and their tags leave the kernel
     if (keep_dev) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
@@ -657,13 +666,14 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
     }
     if (!c->pin_scalars) {
         HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
-        memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));     // [0..2] results of the slice launch, [8] completion ticket
+        memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));     // [0..2] results of the slice launch, [3..4] time shards, [5] chained-scan error, [8] completion ticket
     }
     // extraction + slicing in one launch; the bursts and their tags leave the kernel only for the block-level
     // caller (am_preamble_work), the accepted packets always land in pinned host memory
     c->pin_scalars[0] = 0;
     c->pin_scalars[1] = cur0;
     c->pin_scalars[2] = 0;
+    c->pin_scalars[5] = 0;
     // (the slicing waves write the accepted packets straight to the pinned array.  Routing them through device memory
     // and one coalesced copy in the ticket kernel was tried: the extraction kernel did not get faster and the copy
     // added 13 us to the ticket.)

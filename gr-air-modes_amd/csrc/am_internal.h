@@ -99,7 +99,9 @@ hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const
 /* exclusive scan of n counts in ONE launch (2048 per workgroup, chained through slots[]: am_chain_prefix);
  * slots: one 64-bit word per workgroup, zero at allocation; epoch: a value no earlier launch on these slots used */
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
-                                  uint32_t *total_out, hipStream_t s, const uint32_t *Mp = nullptr);
+                                  uint32_t *total_out, uint32_t *err, uint32_t *ticket, uint32_t *ticket_base, hipStream_t s,
+                                  const uint32_t *Mp = nullptr);   /* *err = 1: the chain gave up; ticket: device counter,
+                                  *ticket_base: the value it has when this launch starts (advanced by the grid size) */
 hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s, const uint32_t *count_src = nullptr,
                             uint32_t *count_dst = nullptr);
 
@@ -161,7 +163,8 @@ struct am_entry_src {
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
-                                 unsigned long long *slots, uint32_t epoch, uint32_t *scalars, int want_resume,
+                                 unsigned long long *slots, uint32_t epoch, uint32_t *ticket, uint32_t *ticket_base,
+                                 uint32_t *scalars, int want_resume,
                                  hipStream_t s, const uint32_t *Mp = nullptr, const am_entry_src *entry_src = nullptr);
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,

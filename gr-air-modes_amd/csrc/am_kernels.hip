@@ -510,9 +510,22 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
     uint32_t xa[4], xb[4];
     load4(w_begin + 4u * threadIdx.x, xa);
     load4(w_begin + 4u * (threadIdx.x + blockDim.x), xb);
-    // where this workgroup's candidates start
+    // where this workgroup's candidates start: the counts of the workgroups before it, eight per thread and round trip (a plain
+    // `acc += wg_cnt[k]` loop waits for every load before it issues the next: six serial round trips at 64 Msps)
     uint32_t acc = 0;
-    for (uint32_t k = threadIdx.x; k < g; k += blockDim.x) acc += wg_cnt[k];
+    for (uint32_t k0 = threadIdx.x; k0 < g; k0 += 8u * blockDim.x) {
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t k = k0 + (uint32_t)j * blockDim.x;
+            v[j] = wg_cnt[k < g ? k : 0u];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            AM_PIN_U32(v[j]);
+            if (k0 + (uint32_t)j * blockDim.x < g) acc += v[j];
+        }
+    }
     for (int o = AM_WAVE / 2; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, AM_WAVE);
     if (lane == 0) red[wv] = acc;
     __syncthreads();
@@ -565,17 +578,26 @@ hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uin
 
 // ------------------------------------------------------------------------------------------
 // Exclusive prefix of one value per workgroup inside a single launch (a chained scan in its plainest form).
-// Workgroup b publishes (epoch, value) in slots[b] and adds up the values of the workgroups before it, waiting
-// for the ones that have not published yet: those were dispatched before b, so they are running or done and the
-// wait cannot deadlock.  `epoch` differs from launch to launch (the host counts), so the slots are never reset.
+// A workgroup first DRAWS ITS PLACE in the chain (am_chain_place: an atomic counter tagged with the launch's epoch), then
+// publishes (epoch, value) in slots[place] and adds up the values of the places before it, waiting for the ones that have
+// not published yet.  Whoever holds a lower place has drawn it, i.e. is running: the wait cannot deadlock, whatever
+// order the hardware dispatches workgroups in and wherever it puts them (MI355X_MICROARCH.md: dispatch order and placement
+// are undefined).  Round 3 took blockIdx.x as the place below 512 workgroups -- an argument about dispatch order, and a
+// __builtin_trap() behind it; the ticket costs one same-address atomic per workgroup (~11 ns each, ~200 workgroups).
+// `epoch` differs from launch to launch (the host counts), so neither slots nor the counter are ever reset.
 // The word carries its own payload, so the atomics are relaxed (device scope): release / acquire would write back
 // and invalidate the whole L2 of the XCD at every step (measured: the marking kernel 18 -> 35 us).
-// All threads of the workgroup call it (it synchronises); red = LDS scratch, one word per wave.
-// What it replaces: a one-workgroup scan launch between producer and consumer, 4.7 us each, three per scan.
+// Should a place never be published after all (a workgroup that died), the wait gives up after AM_CHAIN_SPIN_MAX polls
+// (~2 s): am_chain_prefix returns AM_CHAIN_FAIL to every thread, the caller skips its stores and raises the context's
+// error word, and the host returns AM_EHIP from the call -- an error at the C ABI, not a hang and not a trap (a trap
+// takes the whole process down, every other context with it).
+// All threads of the workgroup call these (they synchronise); red / tick = LDS scratch.
+// What the chain replaces: a one-workgroup scan launch between producer and consumer, 4.7 us each.
 // ------------------------------------------------------------------------------------------
 #ifndef AM_CHAIN_SPIN_MAX
 #define AM_CHAIN_SPIN_MAX (1u << 25)
 #endif
+#define AM_CHAIN_FAIL 0xFFFFFFFFu
 __device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, uint32_t b, uint32_t epoch, uint32_t mine,
                                                     uint32_t *red)
 {
@@ -583,54 +605,37 @@ __device__ __forceinline__ uint32_t am_chain_prefix(unsigned long long *slots, u
         __hip_atomic_store(&slots[b], ((unsigned long long)epoch << 32) | (unsigned long long)mine, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     uint32_t acc = 0;
-    for (uint32_t k = threadIdx.x; k < b; k += blockDim.x) {
+    bool failed = false;
+    for (uint32_t k = threadIdx.x; k < b && !failed; k += blockDim.x) {
         unsigned long long v = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (unsigned spins = 0; (uint32_t)(v >> 32) != epoch; ++spins) {
-            // a predecessor that never publishes would hang the queue: after ~2 s of waiting the launch is aborted instead
-            // (the host then sees a failed launch and returns AM_EHIP) -- see am_chain_place for why it cannot happen
-            if (spins == AM_CHAIN_SPIN_MAX) __builtin_trap();
+            if (spins == AM_CHAIN_SPIN_MAX) { failed = true; break; }
             __builtin_amdgcn_s_sleep(1);
             v = __hip_atomic_load(&slots[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         acc += (uint32_t)v;
     }
     for (int o = AM_WAVE / 2; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, AM_WAVE);
+    const bool wave_failed = __ballot(failed) != 0ull;
     const int nw = (int)(blockDim.x / AM_WAVE);
     __syncthreads();                                          // (red may still be read from an earlier use)
-    if ((threadIdx.x & (AM_WAVE - 1)) == 0) red[threadIdx.x / AM_WAVE] = acc;
+    if ((threadIdx.x & (AM_WAVE - 1)) == 0) red[threadIdx.x / AM_WAVE] = wave_failed ? AM_CHAIN_FAIL : acc;
     __syncthreads();
     uint32_t tot = 0;
-    for (int k = 0; k < nw; ++k) tot += red[k];
-    return tot;
+    bool any_failed = false;
+    for (int k = 0; k < nw; ++k) { any_failed = any_failed || red[k] == AM_CHAIN_FAIL; tot += red[k]; }
+    return any_failed ? AM_CHAIN_FAIL : tot;                  // (a sum of candidate counts never reaches 2^32 - 1)
 }
 
-// The workgroup's place in the chain.  Normally blockIdx.x.  Why waiting for lower indices cannot deadlock: a 1-D
-// grid is dealt to the 8 XCDs round robin (workgroup i to XCD i mod 8) and EACH XCD starts its share in index order.
-// A workgroup waits only for lower indices; the lowest one that has not started is the next in its own XCD's queue, and
-// what occupies that XCD is either other kernels (this library's all terminate: the persistent front end walks a
-// finite segment) or workgroups of this launch with lower indices still -- by induction one of them can always run.
-// That holds with several contexts in flight (am_pipe) as long as the launch fits the chip at once -- a launch of this
-// family has hundreds of workgroups; the chip holds thousands of them.  Beyond AM_CHAIN_TICKET_MIN workgroups (millions
-// of candidates in one scan: pathological input) resident slots can run out, and a workgroup waiting for one that has
-// not started could wait for ever; then the place is a ticket drawn at the start (an atomic counter tagged with the
-// launch's epoch), so everything a workgroup waits for is already running.  Same-address atomics serialise (~11 ns
-// each), hence not the default.  Should the argument above ever fail, am_chain_prefix gives up after
-// AM_CHAIN_SPIN_MAX polls (~2 s) and aborts the launch: an error at the C ABI, not a hang.
+// The workgroup's place in the chain: a ticket drawn at its start, so that everything it will wait for is already running.
+// The counter only ever counts up: EVERY workgroup of every launch draws exactly one ticket, so the host knows the value the
+// counter has when a launch starts (`base`: the grids of the launches before it, modulo 2^32) and a place is ticket - base.
+// One plain fetch-add per workgroup.  (A compare-and-swap loop that re-tagged the counter with the launch's epoch -- no
+// host bookkeeping -- made ~250 workgroups retry against each other: the marking kernel 16 -> 260 us, measured.)
 // All threads call it (it synchronises); tick = LDS scratch word.
-#ifndef AM_CHAIN_TICKET_MIN
-#define AM_CHAIN_TICKET_MIN 512
-#endif
-__device__ __forceinline__ uint32_t am_chain_place(unsigned long long *ticket, uint32_t epoch, uint32_t *tick)
+__device__ __forceinline__ uint32_t am_chain_place(uint32_t *ticket, uint32_t base, uint32_t *tick)
 {
-    if (gridDim.x <= AM_CHAIN_TICKET_MIN) return blockIdx.x;                  // (uniform)
-    if (threadIdx.x == 0) {
-        unsigned long long old = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
-        do {
-            want = ((uint32_t)(old >> 32) == epoch) ? old + 1ull : (((unsigned long long)epoch << 32) | 1ull);
-        } while (!__hip_atomic_compare_exchange_strong(ticket, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-        *tick = ((uint32_t)(old >> 32) == epoch) ? (uint32_t)old : 0u;
-    }
+    if (threadIdx.x == 0) *tick = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
     __syncthreads();
     return *tick;
 }
@@ -640,14 +645,14 @@ __device__ __forceinline__ uint32_t am_chain_place(unsigned long long *ticket, u
 __global__ void __launch_bounds__(256)
 am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t ncap,
                   const uint32_t *__restrict__ Mp, unsigned long long *slots, uint32_t epoch,
-                  uint32_t *__restrict__ total_out)
+                  uint32_t *__restrict__ total_out, uint32_t *__restrict__ err, uint32_t *ticket, uint32_t ticket_base)
 {
     const uint32_t n = am_count(ncap, Mp);
     __shared__ uint32_t ws[256 / AM_WAVE];
     __shared__ uint32_t red[256 / AM_WAVE];
     __shared__ uint32_t tick;
     const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
-    const uint32_t blk = am_chain_place(slots + gridDim.x + 2, epoch, &tick);   // (the slots array has 8 spare words)
+    const uint32_t blk = am_chain_place(ticket, ticket_base, &tick);
     const uint32_t base = blk * AM_SCAN_BLK + threadIdx.x * 8;
     uint32_t v[8], sum = 0;
 #pragma unroll
@@ -662,6 +667,10 @@ am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, u
     uint32_t off = incl - sum, total = 0;
     for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) off += ws[k]; total += ws[k]; }
     const uint32_t before = am_chain_prefix(slots, blk, epoch, total, red);
+    if (before == AM_CHAIN_FAIL) {                            // (uniform) a place was never published: no stores, the error word, an empty result
+        if (threadIdx.x == 0) { *err = 1u; if (blk == gridDim.x - 1) *total_out = 0u; }
+        return;
+    }
     off += before;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = off; off += v[k]; }
@@ -883,6 +892,7 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
 //   * one lane per candidate: the late-peak search over those bytes (preamble_impl.cc:184-192), the quiet zones
 //     (:198-209), the record, and the greedy chain's successor.
 #define AM_RCB 256                  /* candidates per workgroup */
+#define AM_RPL 2                    /* positions per lane and round */
 __global__ void __launch_bounds__(256)
 am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
                  uint32_t Mcap, int spc, float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo,
@@ -933,13 +943,14 @@ am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_spa
         for (uint32_t v = v0; v <= v1; ++v) vb = fmaxf(vb, vmax[v]);      // (every lane the same words)
     }
     const double bound = (double)vb * 0x1p-36;                 // (+inf when a sample is not finite: nothing is decided by D)
-    // four positions per lane and round, their 32 loads in flight together (a group has ~950 positions: one round trip; the
-    // first version staged each 256-position pass in LDS behind barriers: four dependent round trips)
-    for (uint32_t k0 = 0; k0 < kend; k0 += 4u * blockDim.x) {
-        uint32_t q[4];
-        bool has[4];
+    // AM_RPL positions per lane and round, their loads in flight together (a group has ~950 positions; the first version staged
+    // each 256-position pass in LDS behind barriers: a dependent round trip per pass.  Four per lane cost the registers of a
+    // sixth resident workgroup per CU: 34 -> 46 us at the bench density, measured; two do not)
+    for (uint32_t k0 = 0; k0 < kend; k0 += AM_RPL * blockDim.x) {
+        uint32_t q[AM_RPL];
+        bool has[AM_RPL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AM_RPL; ++u) {
             const uint32_t k = k0 + (uint32_t)u * blockDim.x + threadIdx.x;
             has[u] = k < kend;
             uint32_t l = 0, h = nc;                            // last candidate with coff <= k
@@ -950,22 +961,37 @@ am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_spa
             }
             q[u] = clo[l] + (kk - coff[l]);
         }
-        float x[4][8];
+        float x[AM_RPL][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float *p = bb + q[u];                        // (arrays are padded: a lane without a position reads its neighbour's)
+        for (int u = 0; u < AM_RPL; ++u) {
+            const float *p = bb + q[u];                        // (a lane without a position reads the group's last one again)
             x[u][0] = p[0]; x[u][1] = p[spc]; x[u][2] = p[2 * spc]; x[u][3] = p[3 * spc];
             x[u][4] = p[7 * spc]; x[u][5] = p[8 * spc]; x[u][6] = p[9 * spc]; x[u][7] = p[10 * spc];
         }
+        bool close = false;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AM_RPL; ++u) {
             double dd = (double)x[u][1] - (double)x[u][0];
             dd = dd + ((double)x[u][3] - (double)x[u][2]);
             dd = dd + ((double)x[u][5] - (double)x[u][4]);
             dd = dd + ((double)x[u][7] - (double)x[u][6]);
-            bool lt = dd > 0.0;
-            if (has[u] && !(fabs(dd) > bound)) lt = am_preamble_energy(bb + q[u] + 1u, spc) > am_preamble_energy(bb + q[u], spc);
-            if (has[u]) LATE[k0 + (uint32_t)u * blockDim.x + threadIdx.x] = lt ? 1 : 0;
+            const bool far = fabs(dd) > bound;
+            close = close || (has[u] && !far);
+            if (has[u] && far) LATE[k0 + (uint32_t)u * blockDim.x + threadIdx.x] = dd > 0.0 ? 1 : 0;
+        }
+        if (close) {
+            // (rare: exact ties of quantised or constant input, non-finite samples) the reference's two sequential sums
+#pragma unroll 1
+            for (int u = 0; u < AM_RPL; ++u) {
+                if (!has[u]) continue;
+                double dd = (double)x[u][1] - (double)x[u][0];
+                dd = dd + ((double)x[u][3] - (double)x[u][2]);
+                dd = dd + ((double)x[u][5] - (double)x[u][4]);
+                dd = dd + ((double)x[u][7] - (double)x[u][6]);
+                if (!(fabs(dd) > bound))
+                    LATE[k0 + (uint32_t)u * blockDim.x + threadIdx.x] =
+                        am_preamble_energy(bb + q[u] + 1u, spc) > am_preamble_energy(bb + q[u], spc) ? 1 : 0;
+            }
         }
     }
     __syncthreads();
@@ -1030,11 +1056,14 @@ hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint
     return hipGetLastError();
 }
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
-                                  uint32_t *total_out, hipStream_t s, const uint32_t *Mp)
+                                  uint32_t *total_out, uint32_t *err, uint32_t *ticket, uint32_t *ticket_base, hipStream_t s,
+                                  const uint32_t *Mp)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_exscan_chain, dim3((n + AM_SCAN_BLK - 1) / AM_SCAN_BLK), dim3(256), 0, s, in, out, n, Mp, slots,
-                       epoch, total_out);
+    const uint32_t grid = (n + AM_SCAN_BLK - 1) / AM_SCAN_BLK;
+    hipLaunchKernelGGL(am_k_exscan_chain, dim3(grid), dim3(256), 0, s, in, out, n, Mp, slots, epoch, total_out, err, ticket,
+                       *ticket_base);
+    *ticket_base += grid;                                    // (every workgroup draws one)
     return hipGetLastError();
 }
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
@@ -1533,6 +1562,8 @@ struct am_emit_args {
     uint32_t *n_out;                // out: how many
     unsigned long long *slots;      // chained scan of the per-block hit counts (am_chain_prefix)
     uint32_t epoch;
+    uint32_t *ticket;               // ... and the counter its places are drawn from (am_chain_place)
+    uint32_t ticket_base;
     uint32_t *scalars;              // [0]: raised to the largest resume target of a visited candidate
     int want_resume;
 };
@@ -1554,7 +1585,7 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
 #define AM_MSTAMP() ((void)0)
 #endif
     const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t blk = am_chain_place(ea.slots + gridDim.x + 2, ea.epoch, &tick);   // block of candidates = place in the chain
+    const uint32_t blk = am_chain_place(ea.ticket, ea.ticket_base, &tick);   // block of candidates = place in the chain
     const uint32_t base = blk * AM_CB;
     const uint32_t ent = (base < M) ? entry[blk] : AM_CB_NONE;
     const int lane = threadIdx.x & (AM_WAVE - 1), w = threadIdx.x / AM_WAVE;
@@ -1679,6 +1710,10 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
     AM_MSTAMP();
     const uint32_t before = am_chain_prefix(ea.slots, blk, ea.epoch, tot, red);
     AM_MSTAMP();                                              // chain prefix
+    if (before == AM_CHAIN_FAIL) {                            // (uniform) a place was never published: no stores, the error word, no hits
+        if (threadIdx.x == 0) { ea.scalars[9] = 1u; if (blk == gridDim.x - 1) *ea.n_out = 0u; }
+        return;
+    }
     uint32_t off = before;
     for (int k = 0; k < AM_CB_PER; ++k) {
         const bool em = ((embits >> k) & 1u) != 0u;
@@ -1780,7 +1815,7 @@ hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uin
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
-                                 unsigned long long *slots, uint32_t epoch,
+                                 unsigned long long *slots, uint32_t epoch, uint32_t *ticket, uint32_t *ticket_base,
                                  uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src)
 {
     if (M == 0) return hipSuccess;
@@ -1799,6 +1834,8 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.emit_max = emit_max; ea.own_lo = own_lo;
     ea.own_hi = own_hi; ea.emit_idx = emit_idx; ea.n_out = n_out; ea.slots = slots; ea.epoch = epoch; ea.scalars = scalars;
     ea.want_resume = want_resume;
+    ea.ticket = ticket; ea.ticket_base = *ticket_base;
+    *ticket_base += L.nblk;                                  // (every workgroup draws one)
     hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M, ea,
                        Mp);
     return hipGetLastError();
@@ -2039,6 +2076,7 @@ am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg
         host_out[0] = *n_ptr;
         host_out[1] = scalars[0];
         host_out[2] = Mp ? *Mp : 0u;                          // actual candidate count (speculative launches)
+        host_out[5] = scalars[9];                             // a chained scan of this step gave up (am_chain_prefix)
     }
     if (i >= *n_ptr) return;                              // wave-uniform; device-side hit count
     const uint32_t g = emit_idx[i];
@@ -2214,6 +2252,7 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         host_out[0] = nhit;
         host_out[1] = scalars[0];
         host_out[2] = Mp ? *Mp : 0u;
+        host_out[5] = scalars[9];                             // a chained scan of this step gave up (am_chain_prefix)
     }
     const bool pmf = use_pmf != 0;
     const bool wide = (reinterpret_cast<uintptr_t>(iq) & 15u) == 0;

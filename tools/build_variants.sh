@@ -6,7 +6,7 @@
 #               -DFE3_NT_LOADS -DFE3_NT_STORES -DFE3_FORCE_SPW=n (steps per workgroup)  -DFE2_PROFILING (tile kernel)
 #   extraction  -DAM_XPROF (phase clocks + per-workgroup lifetimes, printed when a context is destroyed)
 #   chain       -DAM_WALK_DEBUG (the block walk's lane 0 prints hop counts and cycles)  -DAM_MARK_PROF (phase clocks of the marking kernel, printed by four blocks)  -DAM_CB_HEADW -DAM_CB_GROUP
-#               -DAM_CHAIN_TICKET_MIN (0: chained scans always draw tickets)
+#
 #   refinement  -DAM_ECB (candidates per workgroup of the energy kernel)
 # Run every variant on the GPU box under `timeout`: a variant that computes garbage can loop for ever.
 set -e
