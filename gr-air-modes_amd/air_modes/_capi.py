@@ -105,6 +105,8 @@ class Library(object):
         L.am_shard_entry2.argtypes = [vp, vp, u32, u64, vp, vp]
         L.am_shard_get_exit.argtypes = [vp, pu64]
         L.am_shard_set_exit.argtypes = [vp, u64]
+        L.am_shard_keep_tail.argtypes = [vp, vp, vp, u64]
+        L.am_stream_copy.argtypes = [vp, vp, vp, u64]
         L.am_last_error.restype = C.c_char_p
         L.am_last_error.argtypes = [vp]
         L.am_last_timing.argtypes = [vp, C.POINTER(f32), C.POINTER(f32)]
@@ -250,6 +252,14 @@ class Context(object):
 
     def shard_set_exit(self, pos):
         self._chk(self.lib.L.am_shard_set_exit(self._h, int(pos)))
+
+    def shard_keep_tail(self, dst_ptr, src_ptr, nbytes):
+        """Every following resolve step copies nbytes (device to device) from src to dst behind its slicing, before it completes."""
+        self._chk(self.lib.L.am_shard_keep_tail(self._h, C.c_void_p(int(dst_ptr) or None), C.c_void_p(int(src_ptr) or None), int(nbytes)))
+
+    def stream_copy(self, dst_ptr, src_ptr, nbytes):
+        """A device-to-device copy on the context's stream (ordered with its scans)."""
+        self._chk(self.lib.L.am_stream_copy(self._h, C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)), int(nbytes)))
 
     def shard_resolve_async(self, msgs_ptr, world, rank, msg_cap, capacity=4096):
         """-> (packets, redo).  redo: nothing was delivered, repeat the step on the synchronous path."""

@@ -77,11 +77,35 @@ class ShardedReceiver(object):
         emulated = "emu" in str(getattr(ctx.lib, "path", ""))
         self.host_free = bool(host_free) and (self._buf.is_cuda or emulated)
         self.chunk = self._buf[self.halo * 2:(self.halo + self.n) * 2]
+        # the rank whose tail the next STEP needs (the last one) keeps it inside the resolve call: behind the slicing, which
+        # still reads the samples, in front of the completion -- done when step() returns, before `chunk` is overwritten
+        self._keeps = self.rank == self.world - 1
+        if self._keeps:
+            ctx.shard_keep_tail(self._tail.data_ptr(), self._own_tail.data_ptr(), self.halo * 8)
+        else:
+            ctx.shard_keep_tail(0, 0, 0)
+        ctx._keep_owner = id(self)                        # (a context serves one receiver at a time: the newest)
+
+    def close(self):
+        """The context forgets this receiver's buffers (before the receiver goes away while the context lives on)."""
+        ctx = getattr(self, "ctx", None)
+        if ctx is not None and getattr(ctx, "_h", None) and getattr(ctx, "_keep_owner", None) == id(self):
+            ctx.shard_keep_tail(0, 0, 0)
+            ctx._keep_owner = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _alloc(self, dev):
         t = self.torch
         self._buf = t.zeros((self.halo + self.n) * 2, dtype=t.float32, device=dev)
         self._tail = t.zeros(self.halo * 2, dtype=t.float32, device=dev)     # the last rank's tail of the step before
+        # views used every step (slicing a tensor costs microseconds of host time each)
+        self._halo_view = self._buf[:self.halo * 2]
+        self._own_tail = self._buf[self.n * 2:]                                # the own samples' last `halo`
         # synchronous path: [count, exit of the step before, pos0, exit0, pos1, exit1, ...] as int64, in two sizes
         self._msg = t.zeros(2 + 2 * self.tab_cap, dtype=t.int64, device=dev)
         self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
@@ -123,22 +147,26 @@ class ShardedReceiver(object):
         if world > 1:
             ops = []
             if not last:
-                ops.append(dist.P2POp(dist.isend, own[(n - halo) * 2:], rank + 1, self.group))
+                ops.append(dist.P2POp(dist.isend, self._own_tail, rank + 1, self.group))
             elif self.k > 0:
                 ops.append(dist.P2POp(dist.isend, self._tail, 0, self.group))
             if rank > 0:
-                ops.append(dist.P2POp(dist.irecv, buf[:halo * 2], rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, self._halo_view, rank - 1, self.group))
             elif self.k > 0:
-                ops.append(dist.P2POp(dist.irecv, buf[:halo * 2], world - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, self._halo_view, world - 1, self.group))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()          # (RCCL: orders the current stream behind the transfer, the host does not block)
         elif self.k > 0:
-            buf[:halo * 2].copy_(self._tail)
-        if on_gpu:
+            # one rank: it is its own predecessor (the kept tail goes in front of the chunk on the context's own stream)
+            self.ctx.stream_copy(self._halo_view.data_ptr(), self._tail.data_ptr(), halo * 8)
+        cur = t.cuda.current_stream(buf.device).cuda_stream if on_gpu else 0
+        if on_gpu and (cur != 0 or world > 1):
             # the scan behind the current stream (whoever filled `chunk`, the receive above): the context keeps its own
-            # stream, whatever stream is current when step() is called
-            self.ctx.wait_for_stream(t.cuda.current_stream(buf.device).cuda_stream)
+            # stream, whatever stream is current when step() is called.  (The legacy default stream needs no event: the
+            # context's stream is a blocking one, which the runtime orders behind it -- and an event across two idle
+            # hardware queues costs tens of microseconds per step.)
+            self.ctx.wait_for_stream(cur)
         # 2. the positions this rank decides, and the samples it has for that
         first_chunk = self.k == 0 and rank == 0
         a0 = 0 if first_chunk else S0 + rank * n - H
@@ -151,7 +179,6 @@ class ShardedReceiver(object):
         cap_pk = max(64, n // 2000 + 64)
         pk = None
         if self.host_free:
-            cur = t.cuda.current_stream(buf.device).cuda_stream if on_gpu else 0
             self.ctx.shard_scan_async(ptr, a0, a1, total, self._amsg.data_ptr(), self.small_cap, device_in=on_gpu, more=more)
             if world > 1:
                 if on_gpu:
@@ -175,9 +202,7 @@ class ShardedReceiver(object):
         if flush:
             self.reset()
         else:
-            if last:
-                self._tail.copy_(own[(n - halo) * 2:])
-            self.k += 1
+            self.k += 1                                      # (the last rank's tail was kept inside the resolve call)
         return pk
 
     def _step_sync(self, ptr, a0, a1, total, more, cap_pk, on_gpu):

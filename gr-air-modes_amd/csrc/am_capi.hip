@@ -142,6 +142,10 @@ struct am_ctx {
     uint64_t shard_base = 0, shard_start = 0, shard_end = 0, shard_total = 0;
     bool shard_ready = false;
     bool shard_more = false;            // the resident chunk was scanned with AM_F_MORE: the stream goes on, no end-of-stream rule
+    void *keep_dst = nullptr;           // am_shard_keep_tail: copied between a resolve step's slicing and its completion
+    const void *keep_src = nullptr;
+    uint64_t keep_bytes = 0;
+    bool resolving_shard = false;       // set around chain_finish by the am_shard_resolve* calls
     DevBuf shard_exit;                  // device word: where the scan left this context's chunk in the last resolved step (0: none)
     const am_entry_src *entry_src = nullptr; // set around chain_finish: the scan's start position is composed on the device (time shards)
     const uint32_t *flag_src = nullptr; // ... and this device word is handed to the host with the completion ticket (pin_scalars[4])
@@ -693,6 +697,10 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                       keep_dev ? (float *)c->bursts.p : nullptr,
                                       keep_dev ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p, c->pin_packets,
                                       (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
+    if (c->keep_bytes && c->resolving_shard)
+        // time shards: the samples the next step needs in front of its chunk, kept while this step's are still in place
+        // (am_shard_keep_tail; behind the extraction kernel, which still reads them; complete when the ticket is seen)
+        HIPCHK(c, hipMemcpyAsync(c->keep_dst, c->keep_src, c->keep_bytes, hipMemcpyDeviceToDevice, c->stream));
     const uint32_t seq = ++c->ticket_seq;
     HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, c->flag_src, c->flag_src ? c->pin_scalars + 4 : nullptr));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan (behind the ticket)
@@ -1595,6 +1603,22 @@ int am_shard_set_exit(am_ctx *c, uint64_t pos)
     return AM_OK;
 }
 
+int am_shard_keep_tail(am_ctx *c, void *dst, const void *src, uint64_t nbytes)
+{
+    if (!c || (nbytes && (!dst || !src))) return AM_EINVAL;
+    c->keep_dst = dst; c->keep_src = src; c->keep_bytes = nbytes;
+    return AM_OK;
+}
+
+int am_stream_copy(am_ctx *c, void *dst, const void *src, uint64_t nbytes)
+{
+    if (!c || (nbytes && (!dst || !src))) return AM_EINVAL;
+    if (!nbytes) return AM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, c->stream));
+    return AM_OK;
+}
+
 int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out)
 {
     if (!c) return AM_EINVAL;
@@ -1604,14 +1628,21 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
     c->pending.clear();
     c->last_tags = 0;
     uint64_t em = 0;
-    if (c->chain_M == 0) return AM_OK;
-    if (!c->shard_more && (!flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base)) return AM_OK;
+    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base))) {
+        if (c->keep_bytes) {                                    // (nothing to slice: the tail is still kept)
+            HIPCHK(c, hipMemcpyAsync(c->keep_dst, c->keep_src, c->keep_bytes, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return AM_OK;
+    }
     const uint32_t cur0 = cur_in > c->shard_base ? (uint32_t)std::min<uint64_t>(cur_in - c->shard_base, 0xFFFFFFF0u) : 0u;
     const uint32_t emax = c->shard_more ? 0xFFFFFFFEu : (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
     uint32_t fin = 0;
     const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) /
                                          ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
+    c->resolving_shard = true;
     int rc = chain_finish(c, (const float *)c->bb.p, cur0, emax, c->shard_base, false, &fin, max_hits);
+    c->resolving_shard = false;
     if (rc != AM_OK) return rc;
     c->last_tags = c->n_hits;
     return hand_out(c, out, cap, n_out);
@@ -1639,6 +1670,7 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
         HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev,
                                         (uint64_t *)c->shard_exit.p, c->stream));
         uint32_t f = 0;
+        if (c->keep_bytes) HIPCHK(c, hipMemcpyAsync(c->keep_dst, c->keep_src, c->keep_bytes, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(&f, flag_dev, sizeof(f), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         *redo = f ? 1 : 0;
@@ -1653,7 +1685,9 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     es.exit_out = (uint64_t *)c->shard_exit.p;
     c->entry_src = &es;
     c->flag_src = flag_dev;
+    c->resolving_shard = true;
     int rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
+    c->resolving_shard = false;
     c->entry_src = nullptr;
     c->flag_src = nullptr;
     // the dominant kernel's event pair of this step's scan (am_shard_scan_async only enqueued): both events lie in front of

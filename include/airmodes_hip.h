@@ -263,6 +263,15 @@ int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap,
  *   synchronous path sets it (leave[rank]), a caller that falls back to that path reads it. */
 int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *counts, uint32_t nranks, uint64_t cur_in,
                     uint64_t *entry, uint64_t *leave);
+/* The samples the NEXT step needs in front of a chunk are this step's last ones, and the caller is about to overwrite them:
+ * am_shard_keep_tail registers a device-to-device copy (nbytes from src to dst; 0: none) that every following
+ * am_shard_resolve / am_shard_resolve_async enqueues behind its slicing -- which still reads the samples -- and in front of
+ * its completion, so that it is done when the call returns (a host-side copy after the call costs a launch and an event on
+ * the critical path of the next step).  dst must not be part of what a repeated step would scan.
+ * am_stream_copy: a device-to-device copy on the context's stream, ordered with its scans (e.g. the kept tail into the halo
+ * in front of the chunk, before the next am_shard_scan_async). */
+int am_shard_keep_tail(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
+int am_stream_copy(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
 int am_shard_get_exit(am_ctx *ctx, uint64_t *pos);
 int am_shard_set_exit(am_ctx *ctx, uint64_t pos);
 
