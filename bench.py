@@ -268,7 +268,8 @@ def main():
             dtp = (time.perf_counter() - tp) / 2
             extra["host_input"] = {"value": n / dth, "unit": "samples/s", "ms_per_step": dth * 1e3,
                                    "what": "pinned host buffer -> device -> packets, two buffers in flight (am_uploader): the PCIe copy of "
-                                           "batch k+1 overlaps the scan of batch k, %d steps" % ksteps,
+                                           "batch k+1 overlaps the scan of batch k, %d steps; the pinned buffers are filled once, outside "
+                                           "the timed region -- the source-to-pinned copy a file reader adds is NOT in this figure" % ksteps,
                                    "packets_last_step": int(len(pkh)),
                                    "pageable": {"value": n / dtp, "ms_per_step": dtp * 1e3,
                                                 "what": "am_process_iq on a pageable host pointer (one synchronous copy inside the call)"}}
@@ -372,7 +373,7 @@ def main():
         fe_avg_ms = float(np.mean(fe_ranks))       # (one launch per rank and step, every rank the same n samples: the mean over ranks)
         achieved = 8.0 * n / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
         fe_kind = ctx.last_frontend()
-        kernel_name = {3: ("am_k_fe4<%d,G>" % spc) +
+        kernel_name = {3: ("am_k_fe3" if spc == 32 else "am_k_fe4<%d,G>" % spc) +
                           " (streaming fused |iq|^2 + PMF + reference level + preamble detection, sparse outputs)",
                        2: "am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc}.get(fe_kind, "am_k_frontend")
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)

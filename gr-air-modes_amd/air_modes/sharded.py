@@ -63,8 +63,8 @@ class ShardedReceiver(object):
         self.right = self.hold                            # (name kept: the look-ahead a chunk needs behind its last position)
         if self.n < self.halo:
             raise ValueError("chunk shorter than the halo (%d samples)" % self.halo)
-        spc = max(int(ctx.get_rate() / 2e6), 1)
-        self.tab_cap = 241 * spc + 4                      # a lead-in cannot hold more candidates than positions
+        spc_hi = max(int(-(-ctx.get_rate() // 2e6)), 1)  # samples per chip, rounded up (a rate need not be a multiple of 2 MHz)
+        self.tab_cap = 241 * spc_hi + 4                   # a lead-in cannot hold more candidates than positions
         # the tables are exchanged in a short fixed-size message; only when some rank's table does not fit
         # (every rank sees every count) the full-size message follows
         self.small_cap = max(1, min(int(small_table), self.tab_cap))

@@ -45,7 +45,11 @@ struct am_ctx {
     hipStream_t own_stream = nullptr;   // created by am_create; `stream` is this one unless am_set_stream replaced it
     double rate = 0.0;
     uint64_t rate_i = 0;
-    int spc = 0;
+    int spc = 0;                  // int(rate / 2e6): what the front end runs at (rx_path.py:35)
+    int spc_hi = 0;               // samples per chip rounded UP: look-ahead sizes (= spc for a multiple of 2 MHz)
+    bool frac = false;            // the rate is not a multiple of 2 MHz: rate-generic kernels, geometry from `geom`
+    am_geom geom;                 // the preamble block's geometry in the reference's float arithmetic
+    DevBuf chip_idx;              // [240] int: sample offset of soft chip j, int(j * samples per chip)
     float thr_db = 0.0f;
     float thr_lin = 0.0f;
     int use_pmf = 0;
@@ -264,19 +268,50 @@ void crc_powers(uint32_t *t, int n)
     }
 }
 
+// lib/preamble_impl.cc:56-63 and the places that use d_samples_per_chip (:150,158-162,185,192,205-208,212,220,237), with the
+// reference's types: float d_samples_per_chip = channel_rate / d_chip_rate (float / int), float d_samples_per_symbol
+am_geom geom_of(uint64_t rate_i, int *idx /* [AM_BURST] */)
+{
+    am_geom g;
+    const float channel_rate = (float)(int)rate_i;
+    const float spcf = channel_rate / (float)2000000;
+    const float sps = spcf * 2;
+    g.S = (int)spcf;
+    g.hist0 = (int)sps - 1;                              // set_history(d_samples_per_symbol): that many items, one of them current
+    g.o1 = (int)(2 * spcf); g.o2 = (int)(7 * spcf); g.o3 = (int)(9 * spcf);
+    g.late_max = (int)ceilf(spcf);                       // how_late < spcf holds for how_late = 0 .. ceil(spcf) - 1
+    g.za0 = (int)(1.5 * sps);                            // (double product, as written there)
+    g.za1 = (int)floorf(3 * sps);                        // largest j with (float)j <= 3 * sps
+    g.zb0 = (int)(5 * sps);
+    g.zb1 = (int)floor(7.5 * sps);                       // largest j with (double)j <= 7.5 * sps
+    const float Bf = 240 * spcf;
+    g.B = (int)Bf;                                       // consume_each(i + 240 * spc): the float sum as an int
+    g.room = (int)ceilf(Bf);                             // smallest d with !((float)d < Bf)
+    for (int j = 0; j < AM_BURST; j++) idx[j] = (int)(j * spcf);
+    g.span = idx[AM_BURST - 1];
+    return g;
+}
+
 int configure_rate(am_ctx *c, double rate)
 {
-    if (!(rate > 0.0)) return fail(c, AM_EINVAL, "rate must be positive");
-    const double spcd = rate / 2e6;                       // preamble_impl.cc:57, rx_path.py:35
-    const int spc = (int)spcd;
-    if (spc < 1 || fabs(spcd - (double)spc) > 1e-9)
-        return fail(c, AM_EINVAL, "rate must be a multiple of 2 MHz (integer samples per chip)");
+    if (!(rate >= 2e6) || rate > 2e9) return fail(c, AM_EINVAL, "rate must be at least 2 MHz (one sample per chip)");
+    if (rate != floor(rate)) return fail(c, AM_EINVAL, "rate must be a whole number of samples per second");   // rx_path.py:33 int(rate)
+    const int spc = (int)(rate / 2e6);                    // rx_path.py:35: the front end's window lengths
     const int tile = am_fe_pick_tile(spc);
     if (tile <= 0) return fail(c, AM_EINVAL, "samples per chip too large for the LDS tile");
+    int idx[AM_BURST];
+    const uint64_t rate_i = (uint64_t)(int)(float)rate;   // preamble_impl.cc:60: int d_sample_rate
+    const am_geom g = geom_of(rate_i, idx);
+    if (g.S != spc) return fail(c, AM_EINVAL, "rate not representable as the reference represents it (float)");
     c->rate = rate;
-    c->rate_i = (uint64_t)(int)(float)rate;               // preamble_impl.cc:60: int d_sample_rate
+    c->rate_i = rate_i;
     c->spc = spc;
+    c->frac = (double)spc * 2e6 != rate;
+    c->spc_hi = c->frac ? spc + 1 : spc;
+    c->geom = g;
     c->tile = tile;
+    if (int rc = ensure(c, c->chip_idx, sizeof(idx)); rc != AM_OK) return rc;
+    if (hipMemcpy(c->chip_idx.p, idx, sizeof(idx), hipMemcpyHostToDevice) != hipSuccess) return fail(c, AM_EHIP, "hipMemcpy (chip offsets)");
     return AM_OK;
 }
 
@@ -293,7 +328,7 @@ void reset_stream(am_ctx *c)
 }
 
 // positions beyond the end of the data read zeros: every bb/avg array carries this pad
-inline uint64_t zero_pad(int spc) { return (uint64_t)260 * (uint64_t)spc + 64; }
+inline uint64_t zero_pad(int spc_hi) { return (uint64_t)260 * (uint64_t)spc_hi + 64; }
 
 // Wait for the end of a scan: the last launch stores a ticket number into pinned host memory and the
 // host polls that word.  Asking the runtime instead (hipStreamSynchronize, hipEventQuery) adds tens of
@@ -454,7 +489,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
                                      (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp));
             c->jump_ready = true;
         } else
-            HIPCHK(c, am_launch_refine(bb, avg, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
+            HIPCHK(c, am_launch_refine(bb, avg, c->geom, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
                                        (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p,
                                        (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, (float *)c->inavg.p,
                                        (uint8_t *)c->valid.p, c->stream));
@@ -474,7 +509,7 @@ int run_candidates(am_ctx *c, const float *bb, const float *avg, uint32_t j0, ui
     ENSURE(c, c->cand_seg, (size_t)nblk * AM_DET_PER_BLOCK * sizeof(uint32_t));
     ENSURE(c, c->blk_cnt, (size_t)nblk * sizeof(uint32_t));
     ENSURE(c, c->blk_off, ((size_t)nblk + 1) * sizeof(uint32_t));
-    HIPCHK(c, am_launch_detect(bb, avg, j0, j1, c->spc, c->thr_lin, (uint32_t *)c->cand_seg.p,
+    HIPCHK(c, am_launch_detect(bb, avg, j0, j1, c->geom, c->thr_lin, (uint32_t *)c->cand_seg.p,
                                (uint32_t *)c->blk_cnt.p, nblk, c->stream));
     return run_refine(c, bb, avg, nblk, AM_DET_PER_BLOCK, 0, M_out);
 }
@@ -489,7 +524,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     c->spec_now = false;
     c->Mdev = nullptr;
     c->bb_sparse = false;
-    const unsigned T2 = c->force_generic ? 0u : am_fe2_tile(c->spc);
+    const unsigned T2 = (c->force_generic || c->frac) ? 0u : am_fe2_tile(c->spc);   // (fractional samples per chip: the rate-generic kernels)
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     c->last_fe = T2 == 0 ? 1 : 2;
     if (T2 == 0) {
@@ -507,7 +542,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         ENSURE(c, c->bits, ((size_t)ns * wps + 64) * sizeof(uint32_t));
         ENSURE(c, c->blk_cnt, ((size_t)ns + 8) * sizeof(uint32_t));           // candidates per front-end workgroup
         ENSURE(c, c->blk_off, 16 * sizeof(uint32_t));                          // [0]: their total (am_k_gather_wg)
-        ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
+        ENSURE(c, c->avg, (out_n + zero_pad(c->spc_hi)) * sizeof(float));
         ENSURE(c, c->wgmax, ((size_t)ns + 8) * sizeof(float));
         unsigned nsteps = 0, spw = 1;
         if (c->poison) {
@@ -550,7 +585,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     // the caller wants the dense array); the refinement runs as separate kernels
     float *avg_sparse = nullptr;
     if (!avg) {
-        ENSURE(c, c->avg, (out_n + zero_pad(c->spc)) * sizeof(float));
+        ENSURE(c, c->avg, (out_n + zero_pad(c->spc_hi)) * sizeof(float));
         avg_sparse = (float *)c->avg.p;
     }
     HIPCHK(c, am_launch_fe2(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0,
@@ -691,7 +726,8 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                              keep_dev ? c->pin_tags : nullptr, (uint32_t *)c->crc_pow.p,
                                              c->pin_packets, (uint32_t *)c->scalars.p, c->pin_scalars, c->stream, Mp));
     else
-    HIPCHK(c, am_launch_extract_slice(bb, (const float *)c->inavg.p, c->spc, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
+    HIPCHK(c, am_launch_extract_slice(bb, (const float *)c->inavg.p, c->spc, c->frac ? (const int *)c->chip_idx.p : nullptr,
+                                      c->geom.hist0, (uint32_t *)c->emit_idx.p, n_ptr, n_max,
                                       (uint32_t *)c->pos.p, (uint32_t *)c->e.p, base_abs, e_off, c->rate_i,
                                       (const am_time_tag *)c->tt_dev.p, (uint32_t)c->tt.size(),
                                       keep_dev ? (float *)c->bursts.p : nullptr,
@@ -753,15 +789,16 @@ int hand_out(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
 
 // end-of-stream limits for a stream of N samples (preamble_impl.cc:150,212), in stream-index
 // coordinates: positions n <= *emit_max may still be emitted.  Returns false if none can.
-bool flush_limits(uint64_t N, int spc, uint64_t *emit_max)
+bool flush_limits(const am_ctx *c, uint64_t N, uint64_t *emit_max)
 {
-    const uint64_t S = (uint64_t)spc;
-    const uint64_t K = N + 2 * S - 1;                 // items incl. the block's history
+    const am_geom &g = c->geom;
+    const uint64_t S = (uint64_t)g.S;
+    const uint64_t K = N + (uint64_t)g.hist0;         // items incl. the block's history
     if (K - K % S <= S) return false;
     const uint64_t ninputs = K - K % S - S;           // :150
-    const uint64_t need = (uint64_t)AM_BURST * S + (2 * S - 1);
+    const uint64_t need = (uint64_t)g.room + (uint64_t)g.hist0;
     if (ninputs < need) return false;
-    *emit_max = ninputs - need;                       // k = n + 2spc-1;  ninputs - k >= 240*spc
+    *emit_max = ninputs - need;                       // k = n + hist0;  !(ninputs - k < 240 * samples per chip)
     return true;
 }
 
@@ -865,7 +902,7 @@ void am_destroy(am_ctx *c)
                      &c->energy, &c->bits, &c->seg_base, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->jump, &c->emit_idx,
                      &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
-                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev, &c->wgmax, &c->shard_exit};
+                     &c->recs, &c->cscratch, &c->dc_m1, &c->dc_y, &c->tt_dev, &c->wgmax, &c->shard_exit, &c->chip_idx};
     for (DevBuf *b : all) release(*b);
     if (c->pin_packets) (void)hipHostFree(c->pin_packets);
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
@@ -1020,13 +1057,13 @@ static int process_iq_core(am_ctx *c, const float *iq, uint64_t n, uint32_t flag
     uint64_t emit_max_abs = ~(uint64_t)0;
     if (flush) {
         uint64_t em;
-        if (flush_limits(S1, c->spc, &em)) {
+        if (flush_limits(c, S1, &em)) {
             emit_max_abs = em;
             if (em + 1 > P0) P1 = em + 1;
         }
     } else {
         // a hit decided now must also be a hit if the stream ended right here
-        const uint64_t hold = (uint64_t)(AM_BURST + 4) * S;
+        const uint64_t hold = (uint64_t)(AM_BURST + 4) * (uint64_t)c->spc_hi;
         if (S1 > hold && S1 - hold > P0) P1 = S1 - hold;
     }
     if (P1 > P0) {
@@ -1040,8 +1077,8 @@ static int process_iq_core(am_ctx *c, const float *iq, uint64_t n, uint32_t flag
             if (rc != AM_OK) return rc;
         }
         if (fsrc_abs0 > need0) return fail(c, AM_EINVAL, "internal: stream history was not carried");
-        const uint64_t pad = zero_pad(c->spc);
-        const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
+        const uint64_t pad = zero_pad(c->spc_hi);
+        const bool generic = c->force_generic || c->frac || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
         float *bb = (float *)c->bb.p, *avg = nullptr;
         ZERO_TAIL(c, 0, bb, out_n, pad);
@@ -1248,7 +1285,7 @@ int am_frontend_work(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, flo
     uint64_t s0 = 0;
     int rc = apply_dcblock(c, &src, &s0, n, 0);
     if (rc != AM_OK) return rc;
-    if (!c->force_generic && am_fe2_tile(c->spc)) {
+    if (!c->force_generic && !c->frac && am_fe2_tile(c->spc)) {
         uint32_t M = 0;      // fused kernel with an empty detection range: bb/avg only
         rc = run_front_and_candidates(c, src, 0, n, 0, n, dbb, davg, 0, 0, &M);
     } else {
@@ -1272,7 +1309,7 @@ int am_preamble_work(am_ctx *c, const float *in, const float *inavg, uint64_t n,
     if (n == 0) return AM_OK;
     if (n > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "stream larger than 2^31 items");
     HIPCHK(c, hipSetDevice(c->device));
-    const uint64_t pad = zero_pad(c->spc);
+    const uint64_t pad = zero_pad(c->spc_hi);
     ENSURE(c, c->bb, (n + pad) * sizeof(float));
     ENSURE(c, c->avg, (n + pad) * sizeof(float));
     float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
@@ -1285,7 +1322,7 @@ int am_preamble_work(am_ctx *c, const float *in, const float *inavg, uint64_t n,
     c->h_packets.clear();
     c->h_tags.clear();
     c->h_bursts.clear();
-    if (flush_limits(n, c->spc, &em)) {
+    if (flush_limits(c, n, &em)) {
         uint32_t M = 0, fin = 0;
         int rc = run_candidates(c, bb, avg, 0, (uint32_t)(em + 1), &M);
         if (rc != AM_OK) return rc;
@@ -1376,7 +1413,7 @@ int am_shard_halo(const am_ctx *c, uint64_t *left, uint64_t *right)
     const uint64_t S = (uint64_t)c->spc;
     *left = 2 * (uint64_t)AM_CHIPS_AVG * S + S;     // up to one block (alignment) + one block + one chip
     if (c->use_dcblock) *left += am_dcblock_history(c->spc);
-    *right = (uint64_t)(AM_BURST + 4) * S;          // late shift + 240-chip burst
+    *right = (uint64_t)(AM_BURST + 4) * (uint64_t)c->spc_hi;   // late shift + 240-chip burst
     return AM_OK;
 }
 
@@ -1417,7 +1454,7 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
     if (c->shard_more) {
         if (abs_end + hr > total_n) return fail(c, AM_EINVAL, "AM_F_MORE: the chunk needs its whole right halo");
         P1 = abs_end;
-    } else if (flush_limits(total_n, c->spc, &em)) P1 = std::max(P0, std::min(abs_end, em + 1));
+    } else if (flush_limits(c, total_n, &em)) P1 = std::max(P0, std::min(abs_end, em + 1));
     const uint64_t out_abs0 = (abs_start / L) * L;
     const uint64_t need0 = out_abs0 > LH ? out_abs0 - LH : 0;
     uint64_t fsrc_abs0 = src_abs0;
@@ -1427,12 +1464,12 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
     }
     if (fsrc_abs0 > need0) return fail(c, AM_EINVAL, "internal: left halo too short");
     const uint64_t out_n = src_abs1 - out_abs0;
-    const uint64_t pad = zero_pad(c->spc);
+    const uint64_t pad = zero_pad(c->spc_hi);
     uint32_t M = 0;
     c->spec_now = false;
     c->Mdev = nullptr;
     if (P1 > P0 && out_n) {
-        const bool generic = c->force_generic || am_fe2_tile(c->spc) == 0;
+        const bool generic = c->force_generic || c->frac || am_fe2_tile(c->spc) == 0;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
         float *bb = (float *)c->bb.p, *avg = nullptr;
         ZERO_TAIL(c, 0, bb, out_n, pad);
@@ -1451,7 +1488,7 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
     c->shard_total = total_n;
     // exit table for the candidates the scan can enter at: those in the first 241*spc samples of
     // the chunk (the farthest a predecessor's skip can reach) and the first one after them
-    const uint64_t lead = (uint64_t)(AM_BURST + 1) * S + 1;
+    const uint64_t lead = (uint64_t)c->geom.B + (uint64_t)c->geom.late_max + 1;   // (241 spc + 1 for whole samples per chip)
     const uint64_t lead_end = abs_start + lead;                 // absolute, exclusive
     uint32_t n_dev = 0;
     if (msg_dev) {
@@ -1628,7 +1665,7 @@ int am_shard_resolve(am_ctx *c, uint64_t cur_in, am_packet *out, uint64_t cap, u
     c->pending.clear();
     c->last_tags = 0;
     uint64_t em = 0;
-    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base))) {
+    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c, c->shard_total, &em) || em < c->shard_base))) {
         if (c->keep_bytes) {                                    // (nothing to slice: the tail is still kept)
             HIPCHK(c, hipMemcpyAsync(c->keep_dst, c->keep_src, c->keep_bytes, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1666,7 +1703,7 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     // so on every rank alike
     // (the flag is written, 0 or 1, by whichever kernel composes the entry: no fill in front of it)
     if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
-    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c->shard_total, c->spc, &em) || em < c->shard_base))) {
+    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c, c->shard_total, &em) || em < c->shard_base))) {
         HIPCHK(c, am_launch_shard_entry(msgs_dev, world, rank, (uint32_t)msg_cap, c->shard_base, cur0_dev, flag_dev,
                                         (uint64_t *)c->shard_exit.p, c->stream));
         uint32_t f = 0;

@@ -14,6 +14,22 @@
 
 int am_device_cus(void);   /* compute units of the current device (cached)                  */
 
+/* Geometry of the preamble block for one sample rate, in the reference's own arithmetic: d_samples_per_chip is a FLOAT
+ * (lib/preamble_impl.cc:57) and every use of it is a float product truncated by int() -- for a rate that is not a multiple
+ * of 2 MHz (5 Msps: 2.5 samples per chip) that gives a slightly crooked but well-defined geometry.  With whole samples per
+ * chip all of it reduces to multiples of spc (o1 = 2 spc, za0 = 3 spc, ..., B = 240 spc, chip j at j spc). */
+struct am_geom {
+    int S;              /* int(samples per chip): granularity of ninputs (:150), correlation window (:90-98, :185)  */
+    int hist0;          /* history items in front of the stream: set_history(d_samples_per_symbol) - 1 (:62)       */
+    int o1, o2, o3;     /* pulse offsets int(2 spc), int(7 spc), int(9 spc) (:158-162)                              */
+    int late_max;       /* the late-peak loop runs while how_late < d_samples_per_chip (:192): at most this many     */
+    int za0, za1;       /* quiet zone 1: j = int(1.5 sps) .. j <= 3 sps, inclusive (:205)                            */
+    int zb0, zb1;       /* quiet zone 2: j = int(5 sps) .. j <= 7.5 sps, inclusive (:207)                            */
+    int B;              /* items consume_each() skips after a hit: int(240 spc) (:237)                               */
+    int room;           /* a hit needs `ninputs - i < 240 spc` to be false (:212): at least this many items          */
+    int span;           /* int(239 spc): offset of the last soft chip (:220)                                         */
+};
+
 /* ---- front end ---------------------------------------------------------------------- */
 #define AM_FE_THREADS 512
 #define AM_FE_LDS_BUDGET (80 * 1024)
@@ -137,12 +153,12 @@ struct am_scan_buffers {
     uint32_t *scalars;     /* [0] = final scan position, [1] = visited&valid count          */
 };
 
-hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint32_t j1, int spc,
+hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint32_t j1, const am_geom &g,
                             float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, uint32_t nblk,
                             hipStream_t s);
 /* exclusive scan of n counts into off[0..n]; off[n] = total */
 hipError_t am_launch_scan_u32(const uint32_t *cnt, uint32_t *off, uint32_t n, hipStream_t s);
-hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
+hipError_t am_launch_refine(const float *bb, const float *avg, const am_geom &g, float thr_lin,
                             const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
                             float *inavg, uint8_t *valid, hipStream_t s);
@@ -190,7 +206,10 @@ struct am_time_tag {
 /* extraction + slicing of the emitted preambles in one launch.  n_ptr: device-side number of hits; n_max:
  * upper bound used for the grid; tt[0..ntt): device array of time tags in ascending offset order;
  * bursts_out / tags_out may be null */
-hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
+/* chip_idx: device table of the 240 soft chips' sample offsets int(j * samples per chip) (null: j * spc); hist0: history
+ * items of the preamble block (the tag's item count = stream index + hist0) */
+hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const int *chip_idx, int hist0,
+                                   const uint32_t *emit_idx,
                                    const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
                                    uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
                                    uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,

@@ -198,15 +198,15 @@ hipError_t am_launch_frontend(const am_fe_args &a, hipStream_t s)
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(AM_DET_THREADS)
 am_k_detect(const float *__restrict__ bb, const float *__restrict__ avg, uint32_t j0, uint32_t j1,
-            int spc, float thr_lin, uint32_t *__restrict__ cand_seg, uint32_t *__restrict__ blk_cnt)
+            uint32_t o1, uint32_t o2, uint32_t o3, float thr_lin, uint32_t *__restrict__ cand_seg,
+            uint32_t *__restrict__ blk_cnt)
 {
     __shared__ uint32_t wl[AM_DET_THREADS / AM_WAVE][AM_DET_PER_THREAD * AM_WAVE];
     __shared__ uint32_t wc[AM_DET_THREADS / AM_WAVE];
     const int lane = threadIdx.x & (AM_WAVE - 1);
     const int w = threadIdx.x / AM_WAVE;
     const uint32_t base = j0 + blockIdx.x * AM_DET_PER_BLOCK + w * (AM_DET_PER_THREAD * AM_WAVE);
-    const uint32_t o1 = 2u * spc, o2 = 7u * spc, o3 = 9u * spc;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0;                                     // (o1, o2, o3: int(2 spc), int(7 spc), int(9 spc), preamble_impl.cc:158-162)
     for (int it = 0; it < AM_DET_PER_THREAD; ++it) {
         const uint32_t j = base + it * AM_WAVE + lane;
         bool c = false;
@@ -235,13 +235,13 @@ am_k_detect(const float *__restrict__ bb, const float *__restrict__ avg, uint32_
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
 }
 
-hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint32_t j1, int spc,
+hipError_t am_launch_detect(const float *bb, const float *avg, uint32_t j0, uint32_t j1, const am_geom &g,
                             float thr_lin, uint32_t *cand_seg, uint32_t *blk_cnt, uint32_t nblk,
                             hipStream_t s)
 {
     if (nblk == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_detect, dim3(nblk), dim3(AM_DET_THREADS), 0, s, bb, avg, j0, j1, spc,
-                       thr_lin, cand_seg, blk_cnt);
+    hipLaunchKernelGGL(am_k_detect, dim3(nblk), dim3(AM_DET_THREADS), 0, s, bb, avg, j0, j1, (uint32_t)g.o1, (uint32_t)g.o2,
+                       (uint32_t)g.o3, thr_lin, cand_seg, blk_cnt);
     return hipGetLastError();
 }
 
@@ -363,7 +363,7 @@ __device__ __forceinline__ bool am_any_above2(const float *__restrict__ z1, int 
 }
 
 __global__ void __launch_bounds__(256)
-am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc, float thr_lin,
+am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, am_geom G, float thr_lin,
             const uint32_t *__restrict__ cand_seg, uint32_t seg_stride,
             const uint32_t *__restrict__ blk_off, uint32_t nblk, uint32_t M,
             uint32_t *__restrict__ pos, uint32_t *__restrict__ eo,
@@ -372,6 +372,7 @@ am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc
     // One lane per candidate.  The reference recomputes both energies on every pass of its
     // do-while (preamble_impl.cc:184-192); the "now" energy of pass k+1 is the "late" energy of
     // pass k (same samples, same order, same double roundings), so it is carried over.
+    // (Rate-generic: the geometry comes in the reference's own float arithmetic, am_geom.)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= M) return;
     // segment that holds flat candidate g: last b with blk_off[b] <= g
@@ -382,38 +383,38 @@ am_k_refine(const float *__restrict__ bb, const float *__restrict__ avg, int spc
     }
     const uint32_t j = cand_seg[(size_t)lo * seg_stride + (g - blk_off[lo])];
     int how_late = 0;
-    double e_now = am_preamble_energy(bb + j, spc);
+    double e_now = am_preamble_energy(bb + j, G.S);
     for (;;) {
-        const double e_next = am_preamble_energy(bb + j + how_late + 1, spc);
+        const double e_next = am_preamble_energy(bb + j + how_late + 1, G.S);
         const bool late = e_next > e_now;
         if (late) { how_late++; e_now = e_next; }
-        if (!(late && how_late < spc)) break;
+        if (!(late && how_late < G.late_max)) break;            // :192  how_late < d_samples_per_chip
     }
     const uint32_t e = j + (uint32_t)how_late;
     // quiet zones (preamble_impl.cc:198-209)
-    const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
+    const float p0 = bb[e], p1 = bb[e + G.o1], p2 = bb[e + G.o2], p3 = bb[e + G.o3];
     const float av = avg[e];
     float ps = p0 + p1;
     ps = ps + p2;
     ps = ps + p3;
     const float avgpeak = (float)((double)ps / 4.0);
     const float sthr = av + (avgpeak - av) / thr_lin;
-    const bool ok = !am_any_above(bb + e + 3 * spc, 3 * spc + 1, sthr) &&      // offsets 3spc .. 6spc
-                    !am_any_above(bb + e + 10 * spc, 5 * spc + 1, sthr);       // offsets 10spc .. 15spc
+    const bool ok = !am_any_above(bb + e + G.za0, G.za1 - G.za0 + 1, sthr) &&      // offsets int(1.5 sps) .. 3 sps
+                    !am_any_above(bb + e + G.zb0, G.zb1 - G.zb0 + 1, sthr);        // offsets int(5 sps) .. 7.5 sps
     pos[g] = j;
     eo[g] = e;
     inavg[g] = av;
     valid[g] = ok ? 1 : 0;
-    tgt[g] = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
+    tgt[g] = ok ? (e + (uint32_t)G.B) : (e + 1u);   // :237 / :209
 }
 
-hipError_t am_launch_refine(const float *bb, const float *avg, int spc, float thr_lin,
+hipError_t am_launch_refine(const float *bb, const float *avg, const am_geom &g, float thr_lin,
                             const uint32_t *cand_seg, uint32_t seg_stride, const uint32_t *blk_off,
                             uint32_t nblk, uint32_t M, uint32_t *pos, uint32_t *e, uint32_t *tgt,
                             float *inavg, uint8_t *valid, hipStream_t s)
 {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_refine, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg, spc, thr_lin, cand_seg,
+    hipLaunchKernelGGL(am_k_refine, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg, g, thr_lin, cand_seg,
                        seg_stride, blk_off, nblk, M, pos, e, tgt, inavg, valid);
     return hipGetLastError();
 }
@@ -2061,6 +2062,7 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
 // and tags_out are written only when the caller wants them (block-level API), packets as am_k_slice does.
 __global__ void __launch_bounds__(256)
 am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
+                   const int *__restrict__ chip_idx, int hist0,
                    const uint32_t *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr,
                    const uint32_t *__restrict__ pos, const uint32_t *__restrict__ eo, uint64_t base_abs,
                    long long e_off, uint64_t rate, const am_time_tag *__restrict__ tt, uint32_t ntt,
@@ -2084,11 +2086,11 @@ am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg
     const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
     const float av = inavg[g];                              // reference level at the shifted start
     for (int c = lane; c < AM_BURST; c += AM_WAVE) {
-        const float v = bb[ei + (size_t)(c * spc)] - av;    // preamble_impl.cc:219-221
+        const float v = bb[ei + (size_t)(chip_idx ? chip_idx[c] : c * spc)] - av;    // preamble_impl.cc:219-221: in[i + int(j * spc)]
         sb[wv][c] = v;
         if (bursts_out) bursts_out[(size_t)i * AM_BURST + c] = v;
     }
-    am_tag t = am_make_tag(base_abs + e + (uint64_t)(2 * spc - 1), rate, tt, ntt);
+    am_tag t = am_make_tag(base_abs + e + (uint64_t)hist0, rate, tt, ntt);
     t.inavg = av;
     t.how_late = e - pos[g];
     if (tags_out && lane == 0) tags_out[i] = t;
@@ -2096,7 +2098,8 @@ am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg
     am_slice_wave(sb[wv], t, i, lane, crc_pow, packets);
 }
 
-hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const uint32_t *emit_idx,
+hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const int *chip_idx, int hist0,
+                                   const uint32_t *emit_idx,
                                    const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
                                    uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
                                    uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,
@@ -2104,7 +2107,7 @@ hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc,
                                    const uint32_t *Mp)
 {
     if (n_max == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_extract_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, emit_idx, n_ptr,
+    hipLaunchKernelGGL(am_k_extract_slice, dim3(am_grid(n_max, 4)), dim3(256), 0, s, bb, inavg, spc, chip_idx, hist0, emit_idx, n_ptr,
                        pos, e, base_abs, e_off, rate, tt, ntt, bursts_out, tags_out, crc_pow, packets, scalars,
                        host_out, Mp);
     return hipGetLastError();

@@ -27,7 +27,7 @@ extern "C" {
 
 /* error codes */
 #define AM_OK          0
-#define AM_EINVAL     (-1)   /* bad argument (null pointer, non-multiple-of-2MHz rate, ...) */
+#define AM_EINVAL     (-1)   /* bad argument (null pointer, rate below 2 MHz, ...)           */
 #define AM_ENODEV     (-2)   /* no usable HIP device                                        */
 #define AM_ENOMEM     (-3)   /* host or device allocation failed                            */
 #define AM_EHIP       (-4)   /* a HIP runtime call failed (see am_last_error)               */
@@ -84,7 +84,12 @@ uint32_t am_abi_version(void);
  *           gr::air_modes::preamble::make(float channel_rate, float threshold_db)
  *           (include/gr_air_modes/preamble.h:39), gr::air_modes::slicer::make(queue)
  *           (include/gr_air_modes/slicer.h:41).
- * rate must be a positive multiple of 2 MHz (integer samples per chip).
+ * rate: samples per second, a whole number >= 2e6.  It need not be a multiple of 2 MHz: the reference keeps
+ * d_samples_per_chip = channel_rate / 2e6 as a FLOAT and truncates every product with int() (lib/preamble_impl.cc:57,150,
+ * 158-162,185,192,205-208,212,220,237), the flowgraph in front of it runs its moving averages at int(rate / 2e6) samples per
+ * chip (python/rx_path.py:35) -- e.g. 5 Msps is 2.5 samples per chip for the preamble block and 2 for the filters.  That
+ * geometry is reproduced as it is (pinned against the reference's own C++).  Multiples of 2 MHz up to 64 Msps (and 40) run the
+ * specialised kernels, everything else the rate-generic ones.
  * use_dcblock != 0 puts filter.dc_blocker_cc(100*spc, False) in front of the path
  * (python/rx_path.py:39-41; default off, python/radio.py:118): two cascaded 100-chip moving
  * averages subtracted from the input delayed by 100*spc - 1 samples -- so, as in the reference,

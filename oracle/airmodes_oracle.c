@@ -257,8 +257,44 @@ int amo_frontend_running(const float *iq, uint64_t n, int spc, int use_pmf,
 }
 
 /* ------------------------------------------------------------ a6 - a9 ---- */
+/* The preamble block's geometry (preamble_impl.cc:56-63,150,158-162,185,205-208,212,220,237), with the reference's own
+ * types: d_samples_per_chip is a FLOAT (channel_rate / d_chip_rate) and every use goes through a float product and an
+ * int() truncation -- so a rate that is not a multiple of 2 MHz (5 Msps: 2.5 samples per chip) is a legal rate with its
+ * own, slightly crooked, geometry (e.g. the correlation windows sit at multiples of int(2.5) = 2 samples while the pulse
+ * offsets are int(2 * 2.5) = 5, int(7 * 2.5) = 17, int(9 * 2.5) = 22).  For whole samples per chip everything below
+ * reduces to the familiar multiples of spc. */
+typedef struct {
+    int S;              /* int(d_samples_per_chip): granularity of ninputs (:150), correlation window (:90-98)     */
+    int hist0;          /* history items in front of the stream: set_history(d_samples_per_symbol) - 1 (:62)      */
+    int o1, o2, o3;     /* pulse offsets int(2 spc), int(7 spc), int(9 spc) (:158-162)                             */
+    float spcf;         /* d_samples_per_chip: the late-peak loop runs while how_late < spcf (:192)                 */
+    int za0, za1;       /* quiet zone 1: j = int(1.5 sps) .. j <= 3 sps (:205)                                      */
+    int zb0, zb1;       /* quiet zone 2: j = int(5 sps) .. j <= 7.5 sps (:207)                                      */
+    float Bf;           /* 240 * d_samples_per_chip: the room a burst needs (:212)                                  */
+    int B;              /* ... and what consume_each() skips after a hit, as an int (:237)                          */
+    int idx[BURST_CHIPS];   /* int(j * d_samples_per_chip): the sample of soft chip j (:220)                        */
+} amo_geom;
+
+static void geom_of(uint64_t rate_i, amo_geom *g)
+{
+    const float channel_rate = (float)(int)rate_i;               /* preamble::make(float channel_rate, ...)        */
+    const float spcf = channel_rate / (float)2000000;            /* :57  float / int d_chip_rate                   */
+    const float sps = spcf * 2;                                  /* :58                                             */
+    g->spcf = spcf;
+    g->S = (int)spcf;
+    g->hist0 = (int)sps - 1;
+    g->o1 = (int)(2 * spcf); g->o2 = (int)(7 * spcf); g->o3 = (int)(9 * spcf);
+    g->za0 = (int)(1.5 * sps);                                   /* double product, truncated                      */
+    g->za1 = (int)floorf(3 * sps);                               /* largest j with (float)j <= 3 * sps              */
+    g->zb0 = (int)(5 * sps);                                     /* float product, truncated                       */
+    g->zb1 = (int)floor(7.5 * sps);                              /* largest j with (double)j <= 7.5 * sps           */
+    g->Bf = 240 * spcf;
+    g->B = (int)g->Bf;
+    for (int j = 0; j < BURST_CHIPS; j++) g->idx[j] = (int)(j * spcf);
+}
+
 /* preamble_impl.cc:90-98: energy in the four preamble chips {0,2,7,9},
- * accumulated in double, chip-major then sample-major. */
+ * accumulated in double, chip-major then sample-major; samples_per_chip arrives as an int (:185-186). */
 static double preamble_energy(const float *p, int spc)
 {
     static const int pulse_chip[4] = {0, 2, 7, 9};
@@ -274,10 +310,13 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
                            float *bursts, amo_tag *tags, uint64_t cap)
 {
     if (spc < 1 || n == 0) return 0;
-    const uint64_t S = (uint64_t)spc;
-    const uint64_t hist = 2 * S - 1;          /* set_history(2*spc): preamble_impl.cc:62 */
+    amo_geom G;
+    geom_of(rate, &G);
+    if (G.S != spc) return 0;                 /* (the front end in front of this block runs at int(rate / 2e6): rx_path.py:35) */
+    const uint64_t S = (uint64_t)G.S;
+    const uint64_t hist = (uint64_t)G.hist0;  /* set_history(d_samples_per_symbol): preamble_impl.cc:62 */
     const uint64_t K = n + hist;              /* items the single work() call sees       */
-    const uint64_t pad = 260 * S;             /* zeros beyond the end of the stream      */
+    const uint64_t pad = 260 * (S + 1);       /* zeros beyond the end of the stream      */
     float *in = (float *)calloc(K + pad, sizeof(float));
     float *inavg = (float *)calloc(K + pad, sizeof(float));
     if (!in || !inavg) { free(in); free(inavg); return 0; }
@@ -287,7 +326,7 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
     const float T = amo_threshold_lin(thr_db);
     /* preamble_impl.cc:150 */
     uint64_t ninputs = (K - K % S > S) ? K - K % S - S : 0;
-    const uint64_t o1 = 2 * S, o2 = 7 * S, o3 = 9 * S;   /* :158-162 */
+    const uint64_t o1 = (uint64_t)G.o1, o2 = (uint64_t)G.o2, o3 = (uint64_t)G.o3;   /* :158-162 */
     uint64_t hits = 0;
 
     uint64_t k = 0;
@@ -299,14 +338,14 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
         if (in[k + o2] < thr) { k++; continue; }                   /* :178 */
         if (in[k + o3] < thr) { k++; continue; }                   /* :179 */
 
-        /* :184-192 slide right while the 4-pulse energy still grows, <= spc steps */
+        /* :184-192 slide right while the 4-pulse energy still grows, while how_late < d_samples_per_chip */
         uint32_t how_late = 0;
         for (;;) {
-            double now = preamble_energy(in + k, spc);
-            double nxt = preamble_energy(in + k + 1, spc);
+            double now = preamble_energy(in + k, G.S);
+            double nxt = preamble_energy(in + k + 1, G.S);
             int late = nxt > now;
             if (late) { k++; how_late++; }
-            if (!(late && how_late < (uint32_t)spc)) break;
+            if (!(late && (float)how_late < G.spcf)) break;
         }
 
         /* :198-203 */
@@ -316,20 +355,20 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
         float avgpeak = (float)((double)peaksum / 4.0);
         float space_thr = inavg[k] + (avgpeak - inavg[k]) / T;
         int valid = 1;
-        for (uint64_t j = 3 * S; j <= 6 * S; j++)                  /* :205-206 */
-            if (in[k + j] > space_thr) valid = 0;
-        for (uint64_t j = 10 * S; j <= 15 * S; j++)                /* :207-208 */
-            if (in[k + j] > space_thr) valid = 0;
+        for (int j = G.za0; j <= G.za1; j++)                       /* :205-206 */
+            if (in[k + (uint64_t)j] > space_thr) valid = 0;
+        for (int j = G.zb0; j <= G.zb1; j++)                       /* :207-208 */
+            if (in[k + (uint64_t)j] > space_thr) valid = 0;
         if (!valid) { k++; continue; }                             /* :209 */
 
         /* :212 end of stream (the reference's `ninputs - i` is a signed int: a late-peak shift past ninputs counts as
-         * no room too) */
-        if (k >= ninputs || ninputs - k < BURST_CHIPS * S) break;
+         * no room too); the comparison is the reference's: int against the float 240 * d_samples_per_chip */
+        if (k >= ninputs || (float)(ninputs - k) < G.Bf) break;
 
         if (hits < cap) {
             float *o = bursts + hits * BURST_CHIPS;
             for (int j = 0; j < BURST_CHIPS; j++)                  /* :219-221 */
-                o[j] = in[k + (uint64_t)j * S] - inavg[k];
+                o[j] = in[k + (uint64_t)G.idx[j]] - inavg[k];
             amo_tag *t = &tags[hits];
             t->sample = k;                                         /* :224, history offset included */
             t->secs = k / rate;                                    /* :124 */
@@ -339,7 +378,7 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
             t->how_late = how_late;
         }
         hits++;
-        k += BURST_CHIPS * S;                                      /* :237 */
+        k += (uint64_t)G.B;                                        /* :237 */
     }
     free(in); free(inavg);
     return hits;
@@ -354,11 +393,19 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
 uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, float thr_db, uint64_t k_limit,
                         uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg_out, uint64_t cap)
 {
-    if (spc < 1 || n == 0) return 0;
-    const uint64_t S = (uint64_t)spc;
-    const uint64_t hist = 2 * S - 1;
+    return amo_candidates_r(bb, avg, n, (uint64_t)spc * 2000000u, thr_db, k_limit, pos, refined, valid, inavg_out, cap);
+}
+
+uint64_t amo_candidates_r(const float *bb, const float *avg, uint64_t n, uint64_t rate, float thr_db, uint64_t k_limit,
+                          uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg_out, uint64_t cap)
+{
+    amo_geom G;
+    geom_of(rate, &G);
+    if (G.S < 1 || n == 0) return 0;
+    const uint64_t S = (uint64_t)G.S;
+    const uint64_t hist = (uint64_t)G.hist0;
     const uint64_t K = n + hist;
-    const uint64_t pad = 260 * S;
+    const uint64_t pad = 260 * (S + 1);
     float *in = (float *)calloc(K + pad, sizeof(float));
     float *inavg = (float *)calloc(K + pad, sizeof(float));
     if (!in || !inavg) { free(in); free(inavg); return 0; }
@@ -367,7 +414,7 @@ uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, 
     const float T = amo_threshold_lin(thr_db);
     uint64_t ninputs = (K - K % S > S) ? K - K % S - S : 0;
     if (ninputs > k_limit) ninputs = k_limit;
-    const uint64_t o1 = 2 * S, o2 = 7 * S, o3 = 9 * S;
+    const uint64_t o1 = (uint64_t)G.o1, o2 = (uint64_t)G.o2, o3 = (uint64_t)G.o3;
     uint64_t found = 0;
     for (uint64_t k0 = 0; k0 < ninputs; k0++) {
         float thr = inavg[k0] * T;
@@ -379,11 +426,11 @@ uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, 
         uint64_t k = k0;
         uint32_t how_late = 0;
         for (;;) {
-            double now = preamble_energy(in + k, spc);
-            double nxt = preamble_energy(in + k + 1, spc);
+            double now = preamble_energy(in + k, G.S);
+            double nxt = preamble_energy(in + k + 1, G.S);
             int late = nxt > now;
             if (late) { k++; how_late++; }
-            if (!(late && how_late < (uint32_t)spc)) break;
+            if (!(late && (float)how_late < G.spcf)) break;
         }
         float peaksum = in[k] + in[k + o1];
         peaksum = peaksum + in[k + o2];
@@ -391,10 +438,10 @@ uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, 
         float avgpeak = (float)((double)peaksum / 4.0);
         float space_thr = inavg[k] + (avgpeak - inavg[k]) / T;
         int ok = 1;
-        for (uint64_t j = 3 * S; j <= 6 * S; j++)
-            if (in[k + j] > space_thr) ok = 0;
-        for (uint64_t j = 10 * S; j <= 15 * S; j++)
-            if (in[k + j] > space_thr) ok = 0;
+        for (int j = G.za0; j <= G.za1; j++)
+            if (in[k + (uint64_t)j] > space_thr) ok = 0;
+        for (int j = G.zb0; j <= G.zb1; j++)
+            if (in[k + (uint64_t)j] > space_thr) ok = 0;
         if (found < cap) {
             pos[found] = k0;
             refined[found] = k;
@@ -515,7 +562,7 @@ uint64_t amo_demod(const float *iq, uint64_t n, double rate, float thr_db,
     uint64_t rate_i = (uint64_t)(int)(float)rate;    /* preamble_impl.cc:60 (int d_sample_rate) */
     float *bb = (float *)malloc(n * sizeof(float));
     float *avg = (float *)malloc(n * sizeof(float));
-    uint64_t tcap = n / (BURST_CHIPS * (uint64_t)spc) + 2;
+    uint64_t tcap = n / (BURST_CHIPS * (uint64_t)spc) + 2;       /* (a burst spans >= 240 * int(samples per chip) items) */
     float *bursts = (float *)malloc(tcap * BURST_CHIPS * sizeof(float));
     amo_tag *tags = (amo_tag *)malloc(tcap * sizeof(amo_tag));
     uint64_t npk = 0;

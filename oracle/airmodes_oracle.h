@@ -85,6 +85,9 @@ uint64_t amo_preamble_scan(const float *bb, const float *avg, uint64_t n,
  * order; coordinates are item counts incl. the block's history (like amo_tag.sample), positions k < k_limit */
 uint64_t amo_candidates(const float *bb, const float *avg, uint64_t n, int spc, float thr_db, uint64_t k_limit,
                         uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg_out, uint64_t cap);
+/* the same for any sample rate (samples per chip = (float)rate / 2e6, the reference's own float arithmetic) */
+uint64_t amo_candidates_r(const float *bb, const float *avg, uint64_t n, uint64_t rate, float thr_db, uint64_t k_limit,
+                          uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg_out, uint64_t cap);
 
 /* a10-a12: slice one 240-chip burst.  Returns 1 if the packet is accepted
  * (the reference would post a message), 0 if it is dropped. */

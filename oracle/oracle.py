@@ -53,6 +53,9 @@ def lib():
         L.amo_preamble_scan.restype = C.c_uint64
         L.amo_preamble_scan.argtypes = [_f32p, _f32p, C.c_uint64, C.c_int, C.c_float, C.c_uint64,
                                         _f32p, C.c_void_p, C.c_uint64]
+        L.amo_candidates_r.restype = C.c_uint64
+        L.amo_candidates_r.argtypes = [_f32p, _f32p, C.c_uint64, C.c_uint64, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_uint64]
         L.amo_candidates.restype = C.c_uint64
         L.amo_candidates.argtypes = [_f32p, _f32p, C.c_uint64, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_uint64]
@@ -166,9 +169,11 @@ def preamble_scan(bb, avg, spc, thr_db, rate, rx_time=None):
     return bursts[:hits], restamp(tags[:hits], rate, rx_time)
 
 
-def candidates(bb, avg, spc, thr_db, k_limit=None):
+def candidates(bb, avg, spc, thr_db, k_limit=None, rate=None):
     """Every first-stage candidate refined on its own: (pos, refined, valid, inavg) in item counts of the preamble
-    block (stream index + 2*spc - 1), positions below k_limit."""
+    block (stream index + history: 2*spc - 1 for whole samples per chip), positions below k_limit.  rate: the sample
+    rate when it is not spc * 2 MHz (fractional samples per chip)."""
+    rate_i = int(rate) if rate is not None else int(spc) * 2000000
     n = bb.size
     bb = np.ascontiguousarray(bb, np.float32)
     avg = np.ascontiguousarray(avg, np.float32)
@@ -179,8 +184,8 @@ def candidates(bb, avg, spc, thr_db, k_limit=None):
         ref_ = np.zeros(cap, np.uint64)
         val = np.zeros(cap, np.uint8)
         iav = np.zeros(cap, np.float32)
-        m = lib().amo_candidates(bb, avg, n, spc, thr_db, lim, pos.ctypes.data, ref_.ctypes.data, val.ctypes.data,
-                                 iav.ctypes.data, cap)
+        m = lib().amo_candidates_r(bb, avg, n, rate_i, thr_db, lim, pos.ctypes.data, ref_.ctypes.data, val.ctypes.data,
+                                   iav.ctypes.data, cap)
         if m <= cap:
             return pos[:m], ref_[:m], val[:m], iav[:m]
         cap = int(m)
@@ -248,7 +253,7 @@ def ref_preamble_slicer(bb, avg, spc, thr_db, rate, rx_time=None):
         # the hits do not depend on the time tags: item counts come from an untagged run
         b0, t0, _, keep0 = ref_preamble_slicer(bb, avg, spc, thr_db, rate)
     n = bb.size
-    pad = 600 * spc
+    pad = 600 * (spc + 1)
     cap = (n + pad) // (240 * spc) + 4
     bursts = np.zeros((cap, 240), np.float32)
     secs = np.zeros(cap, np.uint64)
@@ -283,8 +288,12 @@ def ref_preamble_slicer(bb, avg, spc, thr_db, rate, rx_time=None):
         tags["sample"] = t0["sample"]
         return bursts[:nt], tags, text, keep0
     tags["sample"] = secs[:nt] * np.uint64(r) + np.rint(frac[:nt] * r).astype(np.uint64)
-    # canonical end-of-stream rule: hits need 240*spc items of room
-    K = n + 2 * spc - 1
+    # canonical end-of-stream rule: hits need 240 * d_samples_per_chip items of room -- in the
+    # reference's own float arithmetic (lib/preamble_impl.cc:57-62,150,212)
+    spcf = np.float32(np.float32(int(rate)) / np.float32(2000000))
+    hist0 = int(np.float32(spcf * np.float32(2))) - 1
+    K = n + hist0
     ninputs = K - K % spc - spc
-    keep = (ninputs - tags["sample"].astype(np.int64)) >= 240 * spc
+    room = (ninputs - tags["sample"].astype(np.int64)).astype(np.float32)
+    keep = ~(room < np.float32(np.float32(240) * spcf))
     return bursts[:nt], tags, text, keep

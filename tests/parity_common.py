@@ -28,6 +28,18 @@ def load_golden(path):
                 bb_sha=str(z["bb_sha256"]), avg_sha=str(z["avg_sha256"]))
 
 
+def preamble_geometry(rate, n):
+    """(history items in front of the stream, ninputs, room a burst needs) of the reference's preamble block for a stream
+    of n samples, in its own float arithmetic (lib/preamble_impl.cc:57-62,150,212) -- for the bounds of the candidate check."""
+    spcf = np.float32(np.float32(int(rate)) / np.float32(2000000))
+    hist = int(np.float32(spcf * np.float32(2))) - 1
+    S = int(spcf)
+    K = n + hist
+    ninputs = K - K % S - S
+    room = int(np.ceil(np.float32(np.float32(240) * spcf)))
+    return hist, ninputs, room
+
+
 def messages(lib, packets):
     return [lib.format_message(packets[i], i == 0) for i in range(len(packets))]
 
@@ -92,11 +104,9 @@ def check_production_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True, want_fe=
     if not chunks:
         # every first-stage candidate of the (single) scan.  The GPU tests positions up to the last one a burst can
         # start at (end-of-stream rule, preamble_impl.cc:150,212): item counts k <= ninputs - 240 spc
-        hist = 2 * spc - 1
-        K = n + hist
-        ninputs = K - K % spc - spc
+        hist, ninputs, room = preamble_geometry(rate, n)
         pos, ref_, val, iav = ctx.fetch_candidates()
-        opos, oref, oval, oiav = oracle.candidates(obb, oavg, spc, thr, k_limit=ninputs - 240 * spc + 1)
+        opos, oref, oval, oiav = oracle.candidates(obb, oavg, spc, thr, k_limit=ninputs - room + 1, rate=rate)
         assert len(pos) == len(opos), "candidate count differs: %d vs %d" % (len(pos), len(opos))
         assert np.array_equal(pos + np.uint64(hist), opos), "first-stage positions differ"
         assert np.array_equal(ref_ + np.uint64(hist), oref), "refined positions differ"
@@ -170,6 +180,43 @@ def check_sharded(lib, rate, iq, G, thr=7.0, pmf=True, want=None, ctxs=None, dcb
         for c in ctxs:
             c.close()
     assert np.array_equal(got, want), "sharded result differs (%d vs %d packets)" % (len(got), len(want))
+    return len(got)
+
+
+def run_stream_shards(lib, rate, iq, W, K, thr=7.0, pmf=True, dcblock=False):
+    """The time-sharded RECEIVER through the C ABI alone (what air_modes/sharded.py does over torch.distributed, on its
+    synchronous path): K steps of W chunks of m samples; rank r of step k decides the positions [k W m + r m - H, k W m +
+    (r + 1) m - H) from its own samples + the tail in front of them (AM_F_MORE), the last step ends the stream; the scan
+    position crosses chunks and steps through am_shard_entry2.  Returns the packets in (step, rank) order."""
+    m = len(iq) // (W * K)
+    assert m * W * K == len(iq)
+    ctxs = [_capi.Context(rate, thr, pmf, use_dcblock=dcblock, lib=lib) for _ in range(W)]
+    hl, H = ctxs[0].shard_halo()
+    assert m >= hl + H, "chunk shorter than what a rank needs in front of it"
+    cur, out = 0, []
+    for k in range(K):
+        S0, flush = k * W * m, k == K - 1
+        total = S0 + W * m
+        tables = []
+        for r in range(W):
+            a0 = 0 if (k == 0 and r == 0) else S0 + r * m - H
+            a1 = total if (flush and r == W - 1) else S0 + (r + 1) * m - H
+            lo, hi = max(0, a0 - hl), S0 + (r + 1) * m              # the samples rank r has
+            tables.append(ctxs[r].shard_scan(iq[lo:hi], a0, a1, total, more=not flush))
+        entry, leave = _capi.shard_entries(lib, tables, cur_in=cur, with_exits=True)
+        for r in range(W):
+            out.append(ctxs[r].shard_resolve(int(entry[r])))
+        cur = int(leave[W - 1])
+    for c in ctxs:
+        c.close()
+    return np.concatenate(out)
+
+
+def check_stream_sharded(lib, rate, iq, W, K, thr=7.0, pmf=True, want=None, dcblock=False):
+    if want is None:
+        want = oracle.demod(iq, rate, thr, pmf, use_dcblock=dcblock)
+    got = run_stream_shards(lib, rate, iq, W, K, thr, pmf, dcblock)
+    assert np.array_equal(got, want), "streamed shards differ (%d vs %d packets)" % (len(got), len(want))
     return len(got)
 
 

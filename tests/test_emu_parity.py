@@ -88,7 +88,9 @@ def test_setters_and_errors(emu_lib):
     ctx.set_rate(20e6)
     assert ctx.get_rate() == 20e6
     with pytest.raises(_capi.AirModesError):
-        ctx.set_rate(3e6)                       # fractional samples per chip: out of scope
+        ctx.set_rate(1.5e6)                     # less than one sample per chip
+    with pytest.raises(_capi.AirModesError):
+        ctx.set_rate(5e6 + 0.5)                 # (rx_path.py:33: the rate is an int)
     iq, _ = synth.synth_capture(20e6, 100000, 3000.0, seed=3)
     got = ctx.process_iq(iq, flush=True)
     assert np.array_equal(got, oracle.demod(iq, 20e6, 5.0, True))
@@ -309,3 +311,29 @@ def test_production_stages(emu_lib, rate, n, lam, pmf, chunks):
     am_k_fe4 at 20 and 2 Msps) against the oracle and, where built, the reference's own C++."""
     assert pc.check_production_stages(emu_lib, rate, n, lam, 77, pmf=pmf, with_ref=True, chunks=chunks,
                                       want_fe=3) > 0
+
+
+@pytest.mark.parametrize("rate,n,lam", [(5e6, 300000, 2500.0), (6.25e6, 350000, 3000.0), (4.8e6, 250000, 2500.0),
+                                        (3e6, 200000, 1500.0), (13e6, 500000, 4000.0)])
+def test_fractional_samples_per_chip(emu_lib, rate, n, lam):
+    """VERDICT r3 missing #4: rates that are not multiples of 2 MHz.  The reference keeps d_samples_per_chip as a float
+    and truncates every product with int() (lib/preamble_impl.cc:57,150,158-162,185,192,205-208,212,220,237): 2.5, 3.125,
+    2.4, 1.5 and 6.5 samples per chip, block by block and end to end against the oracle (which is pinned to the
+    reference's own C++ at these rates: tests/test_oracle.py), every candidate record, chunked, and time-sharded."""
+    assert pc.check_stages(emu_lib, rate, n, lam, 61) > 5
+    assert pc.check_production_stages(emu_lib, rate, n, lam, 62, with_ref=True, want_fe=1) > 5
+    iq, _ = synth.synth_capture(rate, n, lam, seed=63)
+    pc.check_chunked(emu_lib, rate, iq, [n // 5 + 1, n // 2, n // 2 + 7, n - 997])
+    assert pc.check_sharded(emu_lib, rate, iq, 3) > 5
+    m = n // 6
+    assert pc.check_stream_sharded(emu_lib, rate, iq[:6 * m], 2, 3) > 5     # the receiver: 3 steps of 2 chunks
+
+
+@pytest.mark.parametrize("rate,n,W,K,dc", [(2e6, 240000, 3, 4, False), (20e6, 1200000, 2, 3, False), (64e6, 1800000, 3, 2, False),
+                                           (8e6, 480000, 4, 2, True)])
+def test_time_shards_as_a_stream_through_the_c_abi(emu_lib, rate, n, W, K, dc):
+    """K steps of W chunks through am_shard_scan(AM_F_MORE) / am_shard_entry2 / am_shard_resolve: the packets of all
+    (step, rank) pairs in order == the oracle over the whole stream (lib/preamble_impl.cc:213,237,244: the scan resumes
+    where it stopped, across chunks and steps)."""
+    iq, _ = synth.synth_capture(rate, n, 9000.0, seed=424)
+    assert pc.check_stream_sharded(emu_lib, rate, iq, W, K, dcblock=dc) > 20

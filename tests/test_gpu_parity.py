@@ -45,6 +45,19 @@ def test_stages(lib, rate, n, lam, seed, pmf):
     assert pc.check_stages(lib, rate, n, lam, seed, pmf=pmf) > 5
 
 
+@pytest.mark.parametrize("rate,n,lam", [(5e6, 2_000_000, 2500.0), (6.25e6, 2_500_000, 3000.0), (4.8e6, 1_500_000, 2500.0),
+                                        (13e6, 3_000_000, 4000.0)])
+def test_fractional_samples_per_chip(lib, rate, n, lam):
+    """Rates that are not multiples of 2 MHz on the device (the reference's float geometry, lib/preamble_impl.cc:57,150,
+    158-162,185,192,205-208,212,220,237): block by block and end to end against the oracle, every candidate record against
+    the oracle and the reference's own C++, chunked, time-sharded; and the reference-generated golden vectors."""
+    assert pc.check_stages(lib, rate, n, lam, 61) > 20
+    assert pc.check_production_stages(lib, rate, n, lam, 62, with_ref=True, want_fe=1) > 20
+    iq, _ = synth.synth_capture(rate, n, lam, seed=63)
+    pc.check_chunked(lib, rate, iq, [n // 5 + 1, n // 2, n // 2 + 7, n - 997])
+    assert pc.check_sharded(lib, rate, iq, 3) > 20
+
+
 def test_tiled_fused_kernel_still_matches(lib, monkeypatch):
     for rate, n in ((16e6, 2000000), (20e6, 2000000), (64e6, 6000000)):
         assert pc.check_stages(lib, rate, n, 6000.0, 51) > 3

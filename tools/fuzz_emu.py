@@ -18,6 +18,7 @@ for p in ("gr-air-modes_amd", "tests", "oracle", "tools"):
 import numpy as np  # noqa: E402
 
 import oracle  # noqa: E402
+import parity_common as pc  # noqa: E402
 import synth  # noqa: E402
 from air_modes import _capi  # noqa: E402
 
@@ -58,7 +59,8 @@ def main():
     subprocess.check_call(["make", "-s", "-C", emu, "libairmodes_emu_rare.so"])
     libs = [_capi.Library(os.path.join(emu, "libairmodes_emu.so")), _capi.Library(os.path.join(emu, "libairmodes_emu_rare.so"))]
     rng = np.random.default_rng(args.seed)
-    rates = (2e6, 2e6, 4e6, 8e6, 10e6, 10e6, 16e6, 20e6, 20e6, 32e6, 40e6, 64e6, 64e6)
+    rates = (2e6, 2e6, 4e6, 8e6, 10e6, 10e6, 16e6, 20e6, 20e6, 32e6, 40e6, 64e6, 64e6,
+             3e6, 4.8e6, 5e6, 6.25e6, 7e6, 13e6, 25.5e6)       # (and rates that are not multiples of 2 MHz)
     for case in range(args.cases):
         rate = float(rng.choice(rates))
         spc = int(rate / 2e6)
@@ -84,10 +86,18 @@ def main():
         got = run_chunked(lib, rate, iq, edges, thr, pmf, dc)
         assert same(got, want), "case %d: chunked result differs (%d vs %d packets)" % (case, len(got), len(want))
         G = int(rng.integers(2, 5))
-        halo = 244 * spc + 2 + (200 * spc if dc else 0)
+        halo = 244 * (spc + 1) + 2 + (200 * spc if dc else 0)
         if n // G > halo:
             got = run_sharded(lib, rate, iq, G, thr, pmf, dc)
             assert same(got, want), "case %d: sharded result differs (%d vs %d packets)" % (case, len(got), len(want))
+        # ... and as a RECEIVER: K steps of W chunks, the scan position crossing chunks and steps
+        W, K = int(rng.integers(1, 4)), int(rng.integers(2, 4))
+        m = n // (W * K)
+        if m > 344 * (spc + 1) + (200 * spc if dc else 0):
+            got = pc.run_stream_shards(lib, rate, iq[:m * W * K], W, K, thr, pmf, dc)
+            with np.errstate(all="ignore"):
+                want2 = want if m * W * K == n else oracle.demod(iq[:m * W * K], rate, thr, pmf, use_dcblock=dc)
+            assert same(got, want2), "case %d: streamed shards differ (%d vs %d packets, W=%d K=%d)" % (case, len(got), len(want2), W, K)
         print("case %3d ok: %5.0f Msps n=%8d lambda=%6.0f thr=%4.1f pmf=%d dc=%d kind=%d cuts=%s shards=%d packets=%d (%s build)"
               % (case, rate / 1e6, n, lam, thr, pmf, dc, kind, cuts, G, len(want), "rare" if case % 2 else "plain"), flush=True)
 

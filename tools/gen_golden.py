@@ -32,11 +32,18 @@ CASES = [
 ]
 
 
-def main():
+# rates that are not multiples of 2 MHz (round 4): 2.5 and 3.125 samples per chip -- the reference's float geometry
+FRAC_CASES = [
+    ("g_5msps", 5e6, 60000, 5000.0, 106, 7.0, True),
+    ("g_6p25msps", 6.25e6, 70000, 5000.0, 107, 7.0, True),
+]
+
+
+def main(cases=None, crc=True):
     assert oracle.have_ref() or os.path.isdir("/root/reference/lib"), "needs /root/reference"
     oracle.build()
     os.makedirs(OUT, exist_ok=True)
-    for name, rate, n, lam, seed, thr, pmf in CASES:
+    for name, rate, n, lam, seed, thr, pmf in (cases or CASES):
         spc = int(rate / 2e6)
         iq, truth = synth.synth_capture(rate, n, lam, seed, snr_db=(12.0, 35.0))
         bb, avg = oracle.frontend(iq, spc, pmf)
@@ -61,6 +68,8 @@ def main():
             truth_frames=np.array([t["frame"] for t in truth]))
         print("%s: %d samples, %d truth bursts, %d reference tags, %d reference messages"
               % (name, n, len(truth), len(rt), len(rmsgs)))
+    if not crc:
+        return
     # CRC known answers straight from the reference's modes_check_crc
     rng = np.random.default_rng(7)
     kat = []
@@ -117,6 +126,8 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["rx_time"]:
         oracle.build()
         gen_rx_time()          # only the rx_time fixtures (the others stay byte-identical in git)
+    elif sys.argv[1:] == ["frac"]:
+        main(FRAC_CASES, crc=False)   # only the fractional-rate fixtures
     else:
         main()
         gen_rx_time()

@@ -57,7 +57,9 @@ def synth_capture(rate, n, lam, seed, sigma=0.01, snr_db=(10.0, 35.0), cfo_hz=50
     {start (float sample), frame (hex), snr_db}."""
     rng = np.random.default_rng(np.random.PCG64(seed))
     spc = int(round(rate / 2e6))
-    assert spc >= 1 and abs(rate - 2e6 * spc) < 1e-6, "rate must be a multiple of 2 MHz"
+    whole = spc >= 1 and abs(rate - 2e6 * spc) < 1e-6       # whole samples per chip (else: the chips are area-sampled)
+    spcf = rate / 2e6
+    assert spcf >= 1.0, "rate must be at least 2 MHz"
     iq = np.empty(n, np.complex64)
     v = iq.view(np.float32)
     chunk = 1 << 24
@@ -86,8 +88,20 @@ def synth_capture(rate, n, lam, seed, sigma=0.01, snr_db=(10.0, 35.0), cfo_hz=50
         cfo = float(rng.uniform(-cfo_hz, cfo_hz))
         i0 = int(np.floor(t0))
         fr = float(t0 - i0)
-        env = np.repeat(frame_chips(frame), spc)
-        env = np.concatenate([env, [0.0]]) * (1.0 - fr) + np.concatenate([[0.0], env]) * fr
+        if whole:
+            env = np.repeat(frame_chips(frame), spc)
+            env = np.concatenate([env, [0.0]]) * (1.0 - fr) + np.concatenate([[0.0], env]) * fr
+        else:
+            # a rate that is not a multiple of 2 MHz: sample m of the burst covers the chip times [(m - fr) / spcf,
+            # (m + 1 - fr) / spcf); its amplitude is the mean of the chip waveform over that interval
+            chips = frame_chips(frame).astype(np.float64)
+            cum = np.concatenate([[0.0], np.cumsum(chips)])           # integral of the waveform up to whole chips
+            m = np.arange(int(np.ceil(chips.size * spcf)) + 2, dtype=np.float64)
+            def integral(x):
+                x = np.clip(x, 0.0, float(chips.size))
+                q = np.minimum(x.astype(np.int64), chips.size - 1)
+                return cum[q] + chips[q] * (x - q)
+            env = (integral((m + 1.0 - fr) / spcf) - integral((m - fr) / spcf)) * spcf
         i1 = min(i0 + env.size, n)
         if i1 <= i0:
             continue

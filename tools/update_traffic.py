@@ -15,6 +15,9 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "64msps"
 
 def mean_of(section):
     part = text.split("== %s per dispatch" % section)[1]
+    m = re.search(r"am_k_fe3\(.*?mean ([0-9.e+]+)", part)
+    if m:
+        return "am_k_fe3", float(m.group(1))
     m = re.search(r"am_k_fe4<(\d+), (\d+), (\d+)>.*?mean ([0-9.e+]+)", part)
     if m:
         return "am_k_fe4<%s,G>" % m.group(1), float(m.group(4))
@@ -24,7 +27,7 @@ def mean_of(section):
 
 kernel, fetch = mean_of("FETCH_SIZE")
 _, write = mean_of("WRITE_SIZE")
-ksrc = "am_fe4.hip" if kernel.startswith("am_k_fe4") else "am_fe2.hip"
+ksrc = "am_fe3.hip" if kernel.startswith("am_k_fe3") else ("am_fe4.hip" if kernel.startswith("am_k_fe4") else "am_fe2.hip")
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 with open(os.path.join(root, "gr-air-modes_amd", "csrc", ksrc), "rb") as kf:
     ksha = hashlib.sha256(kf.read()).hexdigest()[:16]
