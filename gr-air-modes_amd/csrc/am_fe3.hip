@@ -108,7 +108,7 @@ struct fe3_prof { };
 struct fe3_smem {
     float *X;                 // [FE3_CR * FE3_XS] ring: |.|^2 of a step's chips while it is staged, then bb
     float *RTOT, *PT, *ST;    // [FE3_CR] per chip: right->left sum of its bb; in-block exclusive prefix / suffix of the chip totals
-    float *SB0;               // [2][32] in-chip suffix sums of |.|^2 of a step's last chip (by step parity)
+    float *MP;                // [2][32] |.|^2 of a step's last chip (by step parity): the chip before the next step's first
     float *M47;               // [32] |.|^2 of chip 47 (the chip before wave 1's first)
     uint32_t *CARRY;          // [2] chips at the start of the next step whose bb must be written (bit mask, by step parity)
     uint32_t *TAB;            // [2][64] per wave: lane of the r-th chip whose bb / reference level is written
@@ -118,7 +118,7 @@ struct fe3_smem {
 
 struct fe3_raw { float4 v[12]; };      // a thread's 12 pieces of a step's raw IQ (piece tid + 128 j)
 
-// unguarded loads of a step (wave-uniform 64-bit base + 32-bit lane offset): issued early, consumed by fe3_store_step
+// unguarded loads of a step (wave-uniform 64-bit base + 32-bit lane offset): issued back to back, consumed by fe3_store_step
 template <int J0 = 0>
 __device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0, int tid, fe3_raw &r)
 {
@@ -127,36 +127,63 @@ __device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0
 #pragma unroll
     for (int j = J0; j < 12; ++j) r.v[j] = fes_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
 }
-template <int J0 = 0>
-__device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int tid, const fe3_raw &r)
+
+// where a thread's pieces go: piece j = samples 2k, 2k+1 (k = tid & 15) of the step's chip c0 + 8 j (c0 = tid >> 4), ring
+// slot slot0 + c0 + 8 j, wrapped from piece jw on -- one compare and one select per piece, the rest is the
+// instruction's immediate offset (the compiler's form of the same arithmetic was ~20 VALU instructions per piece, three of
+// them quarter-rate multiplies: a third of the kernel's VALU time)
+struct fe3_dest { float *row, *roww; int jw; bool last8; float *m47, *mp; };
+static_assert(FE3_SPC == 32 && FE3_NT / 16 == 8 && AM_CHIPS_AVG % 8 == 0, "eight chips per round of pieces");
+__device__ __forceinline__ fe3_dest fe3_dest_of(const fe3_smem &L, int slot0, int par, int tid)
 {
     const int c0 = tid >> 4, k = tid & 15;
+    const int sc = slot0 + c0;                                        // < FE3_CR + 8
+    fe3_dest d;
+    d.jw = (FE3_CR + 7 - sc) >> 3;                                    // slot0 + c0 + 8 j >= FE3_CR  <=>  j >= jw
+    d.row = L.X + fes_mul24(sc, FE3_XS) + 2 * k;
+    d.roww = d.row - FE3_CR * FE3_XS;
+    d.last8 = c0 == 7;                                                // this thread's chips are 7, 15, ... : 47 and 95 among them
+    d.m47 = L.M47 + 2 * k;
+    d.mp = L.MP + par * 32 + 2 * k;
+    return d;
+}
+__device__ __forceinline__ void fe3_store_piece(const fe3_dest &d, int j, float2 mm)
+{
+    float *dst = (j >= d.jw) ? d.roww : d.row;
+    *reinterpret_cast<float2 *>(dst + j * (8 * FE3_XS)) = mm;
+    // the chip before a later wave's first is stored a second time (M47: that wave needs it after the chip's own slot holds
+    // bb), and so is the step's last chip (MP: the next step's wave 0 needs it)
+    if ((8 * j + 8) % AM_CHIPS_AVG == 0 && d.last8) {
+        if (8 * j + 8 < FE3_S) *reinterpret_cast<float2 *>(d.m47 + ((8 * j + 8) / AM_CHIPS_AVG - 1) * 32) = mm;
+        else *reinterpret_cast<float2 *>(d.mp) = mm;
+    }
+}
+template <int J0 = 0>
+__device__ __forceinline__ void fe3_store_step(const fe3_smem &L, int slot0, int par, int tid, const fe3_raw &r)
+{
+    const fe3_dest d = fe3_dest_of(L, slot0, par, tid);
 #pragma unroll
     for (int j = J0; j < 12; ++j) {
-        const float r0 = r.v[j].x * r.v[j].x, i0 = r.v[j].y * r.v[j].y, r1 = r.v[j].z * r.v[j].z, i1 = r.v[j].w * r.v[j].w;
+        const fes_f2 q0 = fes_pk_mul(fes_mk2(r.v[j].x, r.v[j].y), fes_mk2(r.v[j].x, r.v[j].y));
+        const fes_f2 q1 = fes_pk_mul(fes_mk2(r.v[j].z, r.v[j].w), fes_mk2(r.v[j].z, r.v[j].w));
         float2 mm;
-        mm.x = r0 + i0;                                               // a1: fl(fl(I*I) + fl(Q*Q))
-        mm.y = r1 + i1;
-        const int cc = c0 + (FE3_NT / 16) * j;                        // chip of the piece
-        const int slot = fe3_wrap_up(slot0 + cc);
-        *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
-        if ((cc + 1) % AM_CHIPS_AVG == 0 && cc + 1 < FE3_S)           // the chip before a later wave's first
-            *reinterpret_cast<float2 *>(L.M47 + ((cc + 1) / AM_CHIPS_AVG - 1) * 32 + 2 * k) = mm;
+        mm.x = q0.x + q0.y;                                           // a1: fl(fl(I*I) + fl(Q*Q))
+        mm.y = q1.x + q1.y;
+        fe3_store_piece(d, j, mm);
     }
 }
 
 // |iq|^2 of one step straight into the ring slots of its chips (they hold chips nobody needs any more): piece
 // p = tid + 128 j (16 bytes = samples 2k, 2k+1 of chip p >> 4, k = p & 15 = tid & 15) -> X[slot][2k .. 2k+1].
 // Coalesced loads (consecutive lanes, consecutive pieces), 8-byte LDS stores (16 lanes = one chip's 128 bytes).
-// chip 47's values are stored a second time (M47): wave 1 needs them after chip 47's slot holds bb.
 // J0 > 0: only pieces J0.. (chips 8 J0 ..) -- the step that rebuilds the rings needs its last 57 chips only
 template <bool GUARD, int J0 = 0>
-__device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_smem &L, long long A0, int slot0, int tid)
+__device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_smem &L, long long A0, int slot0, int par, int tid)
 {
-    const int c0 = tid >> 4, k = tid & 15;
     if constexpr (GUARD) {
         // stream edges / unaligned input: one piece at a time, zeros outside the stream (rare: kept small)
         const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
+        const fe3_dest d = fe3_dest_of(L, slot0, par, tid);
 #pragma unroll 1
         for (int j = 0; j < 12; ++j) {
             const long long n = A0 + 2 * (long long)(tid + FE3_NT * j);
@@ -168,17 +195,13 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
             float2 mm;
             mm.x = r0 + i0;
             mm.y = r1 + i1;
-            const int cc = c0 + (FE3_NT / 16) * j;
-            const int slot = fe3_wrap_up(slot0 + cc);
-            *reinterpret_cast<float2 *>(L.X + slot * FE3_XS + 2 * k) = mm;
-            if ((cc + 1) % AM_CHIPS_AVG == 0 && cc + 1 < FE3_S)
-                *reinterpret_cast<float2 *>(L.M47 + ((cc + 1) / AM_CHIPS_AVG - 1) * 32 + 2 * k) = mm;
+            fe3_store_piece(d, j, mm);
         }
         return;
     }
     fe3_raw v;
     fe3_load_step<J0>(a, A0, tid, v);
-    fe3_store_step<J0>(L, slot0, tid, v);
+    fe3_store_step<J0>(L, slot0, par, tid, v);
 }
 
 // One step (its |.|^2 is staged).
@@ -191,18 +214,25 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                                          bool &badrun, uint32_t &ncand, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
-    const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
+    const int lane = tid & (AM_WAVE - 1), wv = tid >> 6;
     const bool chip_thread = lane < AM_CHIPS_AVG;
-    const int t = wv * AM_CHIPS_AVG + (chip_thread ? lane : AM_CHIPS_AVG - 1);   // chip of the step (spare lanes shadow the last one, never write)
+    const int lc = chip_thread ? lane : AM_CHIPS_AVG - 1;             // chip inside the wave's block (spare lanes shadow the last one, never write)
+    const int t = fes_mul24(wv, AM_CHIPS_AVG) + lc;                   // chip of the step
     const long long A0 = a.out_abs0 + (long long)step * FE3_T;      // absolute index of the step's first sample
     const int slotA = fe3_wrap_up(slot0 + t);
+    const int offA = fes_mul24(slotA, FE3_XS);
     const bool do_pmf = a.use_pmf != 0;
 
     // ---- phase A: pulse matched filter of the own chip, chip totals, in-block scans -------------------------------
     float bb[SPC];
     {
         float m[SPC];
-        const float4 *mp = reinterpret_cast<const float4 *>(L.X + slotA * FE3_XS);
+        // lane 63 stands in for the chip before the wave's first one (wave 0: the previous step's last chip, wave 1: chip
+        // 47 -- their |.|^2 was stored a second time, the ring slots hold bb by now): lane 0 takes its suffix sums from
+        // there with the same lane rotation that hands every other lane its left neighbour's
+        const float *mrow = L.X + offA;
+        if (lane == AM_WAVE - 1) mrow = (wv == 0) ? (L.MP + (par ^ 1) * 32) : (L.M47 + (wv - 1) * 32);
+        const float4 *mp = reinterpret_cast<const float4 *>(mrow);
 #pragma unroll
         for (int k = 0; k < SPC / 4; ++k) {
             const float4 u = mp[k];
@@ -220,36 +250,14 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                     ap = ap + m[i]; pp[i] = ap;
                 }
             }
-            // the step's last chip hands its sums to the next step's first chip
-            if (tid == (FE3_NW - 1) * AM_WAVE + AM_CHIPS_AVG - 1) {
-                float4 *dst = reinterpret_cast<float4 *>(L.SB0 + par * 32);
+            float tt[SPC];
 #pragma unroll
-                for (int k = 0; k < SPC / 4; ++k) {
-                    float4 u;
-                    u.x = sx[4 * k]; u.y = sx[4 * k + 1]; u.z = sx[4 * k + 2]; u.w = sx[4 * k + 3];
-                    dst[k] = u;
-                }
-            }
-            // suffix sums of the chip before: lane-1; lane 0 of wave 0: the previous step's last chip (LDS), lane 0 of
-            // wave 1: chip 47, recomputed from its staged |.|^2 (every lane reads them: a broadcast)
-            float pv[SPC];
-            {
-                const float4 *src = reinterpret_cast<const float4 *>((wv == 0) ? (L.SB0 + (par ^ 1) * 32) : (L.M47 + (wv - 1) * 32));
+            for (int i = 0; i < SPC - 1; ++i) tt[i] = fes_from_prev_lane_ror(sx[i + 1], lane) + pp[i];
+            tt[SPC - 1] = pp[SPC - 1];                                // the window is the chip
 #pragma unroll
-                for (int k = 0; k < SPC / 4; ++k) {
-                    const float4 u = src[k];
-                    pv[4 * k] = u.x; pv[4 * k + 1] = u.y; pv[4 * k + 2] = u.z; pv[4 * k + 3] = u.w;
-                }
-                if (wv != 0) {                                        // (uniform)
-                    float acc2 = 0.0f;
-#pragma unroll
-                    for (int i = SPC - 1; i >= 0; --i) { acc2 = acc2 + pv[i]; pv[i] = acc2; }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < SPC; ++i) {
-                if (i == SPC - 1) bb[i] = pp[i] * a.s1;               // the window is the chip
-                else bb[i] = (fes_from_prev_lane(sx[i + 1], pv[i + 1], lane) + pp[i]) * a.s1;
+            for (int i = 0; i < SPC; i += 2) {
+                const fes_f2 v = fes_pk_mul(fes_mk2(tt[i], tt[i + 1]), fes_mk2(a.s1, a.s1));
+                bb[i] = v.x; bb[i + 1] = v.y;
             }
         } else {
 #pragma unroll
@@ -266,10 +274,11 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     }
     {
         // chip totals in both directions (canonical level-1 sums); spare lanes contribute zeros to the scans
-        float f = 0.0f, b = 0.0f;
+        float f = 0.0f, b = 0.0f, mx = 0.0f;
 #pragma unroll
-        for (int i = 0; i < SPC; ++i) { f = f + bb[i]; b = b + bb[SPC - 1 - i]; mxrun = fmaxf(mxrun, bb[i]); }
-        if (!chip_thread) f = 0.0f;
+        for (int i = 0; i < SPC; ++i) { f = f + bb[i]; b = b + bb[SPC - 1 - i]; mx = fmaxf(mx, bb[i]); }
+        if (!chip_thread) { f = 0.0f; mx = 0.0f; }                    // (lane 63 formed something that is no chip's bb)
+        mxrun = fmaxf(mxrun, mx);
         badrun = badrun || !(f < __builtin_inff());                   // a sample that is not finite makes its chip's total so (all terms >= 0 or NaN)
         // exclusive prefix / suffix of the 48 chip totals of this wave's block, strictly sequential (canonical
         // order): x <- x(lane-1) + f repeated 47 times leaves lane j with ((f0 + f1) + ...) + fj (a lane's value is
@@ -288,7 +297,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             L.RTOT[slotA] = b;
             L.PT[slotA] = pt;
             L.ST[slotA] = st;
-            float4 *xp = reinterpret_cast<float4 *>(L.X + slotA * FE3_XS);
+            float4 *xp = reinterpret_cast<float4 *>(L.X + offA);
 #pragma unroll
             for (int k = 0; k < SPC / 4; ++k) {
                 float4 u;
@@ -303,14 +312,19 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     if (!test) return;                                                // (uniform) ring rebuild only
 
     // ---- phase B on chip q = (this thread's phase-A chip) - 9: reference level (a4) + first-stage test (a6) --------
-    const int slotB = fe3_wrap_dn(slotA - FE3_LAG);
-    const int slotS = fe3_wrap_dn(slotB - AM_CHIPS_AVG);              // the chip 48 chips back
-    float x[SPC], avgv[SPC];
+    // (ring offsets by add / compare / select from the phase-A chip's: slot * 36 is a multiply only once per step)
+    const bool lowA = slotA < FE3_LAG;
+    const int slotB = slotA - FE3_LAG + (lowA ? FE3_CR : 0);
+    const int offB = offA - FE3_LAG * FE3_XS + (lowA ? FE3_CR * FE3_XS : 0);
+    const bool lowB = slotB < AM_CHIPS_AVG;
+    const int slotS = slotB - AM_CHIPS_AVG + (lowB ? FE3_CR : 0);     // the chip 48 chips back
+    const int offS = offB - AM_CHIPS_AVG * FE3_XS + (lowB ? FE3_CR * FE3_XS : 0);
+    float x[SPC], avgv[SPC], thrv[SPC];
     float nxt;
     {
         float scv[SPC];
-        const float4 *xp = reinterpret_cast<const float4 *>(L.X + slotB * FE3_XS);
-        const float4 *sp = reinterpret_cast<const float4 *>(L.X + slotS * FE3_XS);
+        const float4 *xp = reinterpret_cast<const float4 *>(L.X + offB);
+        const float4 *sp = reinterpret_cast<const float4 *>(L.X + offS);
 #pragma unroll
         for (int k = 0; k < SPC / 4; ++k) {
             const float4 u = xp[k];
@@ -321,29 +335,38 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             const float4 u = sp[k];
             scv[4 * k] = u.x; scv[4 * k + 1] = u.y; scv[4 * k + 2] = u.z; scv[4 * k + 3] = u.w;
         }
-        nxt = L.X[fe3_wrap_up(slotB + 1) * FE3_XS];
-        const int slotS1 = fe3_wrap_up(slotS + 1);
+        const bool topB = slotB == FE3_CR - 1;
+        nxt = L.X[offB + FE3_XS - (topB ? FE3_CR * FE3_XS : 0)];
+        const int slotS1 = slotS + 1 - ((slotS == FE3_CR - 1) ? FE3_CR : 0);
         const float pt = L.PT[slotB];
         const float st_a = L.ST[slotS];
         const float suf_last = L.RTOT[slotS1] + L.ST[slotS1];
-        const int jb = (t + AM_CHIPS_AVG - FE3_LAG) % AM_CHIPS_AVG;   // chip index inside its 48-chip block
+        const int jb = lc - FE3_LAG + ((lc < FE3_LAG) ? AM_CHIPS_AVG : 0);   // chip index inside its 48-chip block
         // in-chip suffix sums of the chip 48 back (right->left) and prefix sums of the own chip (left->right): two
         // independent chains per iteration
-        float pre[SPC];
+        float ap_[SPC];
         {
             float as = 0.0f, ap = 0.0f;
 #pragma unroll
             for (int i = 0; i < SPC; ++i) {
                 as = as + scv[SPC - 1 - i]; scv[SPC - 1 - i] = as;
-                ap = ap + x[i]; pre[i] = pt + ap;
+                ap = ap + x[i]; ap_[i] = ap;
             }
         }
+        // s[i] = (scv[i + 1] + st_a) + (pt + ap[i]); the chip's last position: (suf_last + pre), or pre alone where the
+        // window ends with the block (x + (-0) == x for every x, NaN included) -- two positions per instruction
+        const float q32 = (jb == AM_CHIPS_AVG - 1) ? -0.0f : suf_last;
 #pragma unroll
-        for (int i = 0; i < SPC; ++i) {
-            float s;
-            if (i == SPC - 1) s = (jb == AM_CHIPS_AVG - 1) ? pre[i] : (suf_last + pre[i]);
-            else s = (scv[i + 1] + st_a) + pre[i];
-            avgv[i] = s * a.sL;
+        for (int i = 0; i < SPC; i += 2) {
+            const fes_f2 pre = fes_pk_add(fes_mk2(pt, pt), fes_mk2(ap_[i], ap_[i + 1]));
+            fes_f2 q;
+            if (i + 2 < SPC) q = fes_pk_add(fes_mk2(scv[i + 1], scv[i + 2]), fes_mk2(st_a, st_a));
+            else q = fes_mk2(scv[i + 1] + st_a, q32);
+            const fes_f2 sv = fes_pk_add(q, pre);
+            const fes_f2 av = fes_pk_mul(sv, fes_mk2(a.sL, a.sL));
+            const fes_f2 th = fes_pk_mul(av, fes_mk2(a.thr_lin, a.thr_lin));            // preamble_impl.cc:173
+            avgv[i] = av.x; avgv[i + 1] = av.y;
+            thrv[i] = th.x; thrv[i + 1] = th.y;
         }
     }
     // array coordinate of x[0]
@@ -352,13 +375,14 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     uint32_t cm = 0u;
     {
         constexpr int CH = 16;
-        const int s2 = fe3_wrap_up(slotB + 2), s7 = fe3_wrap_up(slotB + 7), s9 = fe3_wrap_up(slotB + 9);
+        // the later pulses' chips: 2, 7 and 9 chips on = 7, 2 and 0 chips before the phase-A chip
+        const int off9 = offA;
+        const int off7 = offA - 2 * FE3_XS + ((slotA < 2) ? FE3_CR * FE3_XS : 0);
+        const int off2 = offA - 7 * FE3_XS + ((slotA < 7) ? FE3_CR * FE3_XS : 0);
 #if defined(FE2_CMPX)
         auto pass = [&](auto hc) __attribute__((always_inline)) {
             constexpr int H = decltype(hc)::value;
-            float thr[CH];
-#pragma unroll
-            for (int i = 0; i < CH; ++i) thr[i] = avgv[H + i] * a.thr_lin;            // preamble_impl.cc:173
+            const float *thr = &thrv[H];
             uint32_t part = 0u;
             fe2_peak8<H>(part, &x[H], x[H + 8], &thr[0]);
             fe2_peak8<H + 8>(part, &x[H + 8], (H + 16 < SPC) ? x[(H + 16 < SPC) ? H + 16 : 0] : nxt, &thr[8]);
@@ -368,9 +392,9 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                 float t2[CH], t7[CH], t9[CH];
 #pragma unroll
                 for (int k = 0; k < CH / 4; ++k) {
-                    const float4 u = reinterpret_cast<const float4 *>(L.X + s2 * FE3_XS + H)[k];
-                    const float4 v = reinterpret_cast<const float4 *>(L.X + s7 * FE3_XS + H)[k];
-                    const float4 w = reinterpret_cast<const float4 *>(L.X + s9 * FE3_XS + H)[k];
+                    const float4 u = reinterpret_cast<const float4 *>(L.X + off2 + H)[k];
+                    const float4 v = reinterpret_cast<const float4 *>(L.X + off7 + H)[k];
+                    const float4 w = reinterpret_cast<const float4 *>(L.X + off9 + H)[k];
                     t2[4 * k] = u.x; t2[4 * k + 1] = u.y; t2[4 * k + 2] = u.z; t2[4 * k + 3] = u.w;
                     t7[4 * k] = v.x; t7[4 * k + 1] = v.y; t7[4 * k + 2] = v.z; t7[4 * k + 3] = v.w;
                     t9[4 * k] = w.x; t9[4 * k + 1] = w.y; t9[4 * k + 2] = w.z; t9[4 * k + 3] = w.w;
@@ -391,12 +415,11 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
 #pragma unroll
         for (int h = 0; h < SPC; h += CH) {
             bool c[CH];
-            float thr[CH];
+            const float *thr = &thrv[h];
             bool any = false;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const float xv = x[h + i];
-                thr[i] = avgv[h + i] * a.thr_lin;                        // preamble_impl.cc:173
                 const float nx = (h + i + 1 < SPC) ? x[(h + i + 1 < SPC) ? h + i + 1 : h + i] : nxt;
                 c[i] = (xv > thr[i]) & !(nx > xv);                       // :174, :175
                 any = any | c[i];
@@ -404,8 +427,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             if (__ballot(any) != 0ull) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
-                    const float weakest = fminf(fminf(L.X[s2 * FE3_XS + h + i], L.X[s7 * FE3_XS + h + i]),
-                                                L.X[s9 * FE3_XS + h + i]);
+                    const float weakest = fminf(fminf(L.X[off2 + h + i], L.X[off7 + h + i]), L.X[off9 + h + i]);
                     c[i] = c[i] & !(weakest < thr[i]);
                 }
             }
@@ -461,9 +483,9 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             __builtin_amdgcn_wave_barrier();
             const int r = r0 + sub;
             if (sub < 4 && r < nav) {
-                const int tc = wv * AM_CHIPS_AVG + (int)tab[r];
+                const int tc = fes_mul24(wv, AM_CHIPS_AVG) + (int)tab[r];
                 const float4 u = *reinterpret_cast<const float4 *>(avs + sub * FE3_XS + 4 * piece);
-                const int rel = tc * SPC + 4 * piece;
+                const int rel = (tc << 5) + 4 * piece;
                 if (!edge || (rel >= lo && rel + 4 <= hi)) fe3_gstore16(dst + rel, u);
                 else {
                     if (rel >= lo && rel < hi) dst[rel] = u.x;
@@ -503,10 +525,11 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         for (int r0 = 0; r0 < nflag; r0 += 8) {                       // (uniform trip count)
             const int r = r0 + sub;
             if (r < nflag) {
-                const int tc = wv * AM_CHIPS_AVG + (int)tab[r];       // test index of the chip, <= 103
-                const int slot = fe3_wrap_dn(fe3_wrap_up(slot0 + tc) - FE3_LAG);
-                const float4 u = *reinterpret_cast<const float4 *>(L.X + slot * FE3_XS + 4 * piece);
-                const int rel = tc * SPC + 4 * piece;
+                const int tc = fes_mul24(wv, AM_CHIPS_AVG) + (int)tab[r];       // test index of the chip, <= 103
+                int slot = slot0 + tc - FE3_LAG;                      // in [-9, 2 CR)
+                slot += (slot < 0) ? FE3_CR : ((slot >= FE3_CR) ? -FE3_CR : 0);
+                const float4 u = *reinterpret_cast<const float4 *>(L.X + fes_mul24(slot, FE3_XS) + 4 * piece);
+                const int rel = (tc << 5) + 4 * piece;
                 if (!edge || (rel >= lo && rel + 4 <= hi)) fe3_gstore16(dst + rel, u);
                 else {
                     if (rel >= lo && rel < hi) dst[rel] = u.x;
@@ -525,8 +548,8 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     fe3_smem L;
     // (arrays read or written 16 bytes at a time first: their sizes are multiples of 16 bytes)
     L.X = reinterpret_cast<float *>(smem);
-    L.SB0 = L.X + FE3_CR * FE3_XS;
-    L.M47 = L.SB0 + 64;
+    L.MP = L.X + FE3_CR * FE3_XS;
+    L.M47 = L.MP + 64;
     L.AVS = L.M47 + 32 * (FE3_NW - 1);
     L.RTOT = L.AVS + FE3_NW * 4 * FE3_XS;
     L.PT = L.RTOT + FE3_CR;
@@ -566,10 +589,10 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         // load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is chip
         // FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
         if (have) {
-            if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
-            else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+            if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
+            else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
         } else
-            fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, tid);
+            fe3_stage_step<true>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
         FE3_STAMP(5);
         fes_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
@@ -587,14 +610,14 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         uint32_t wcnt = ncand;
         for (int o = 32; o >= 1; o >>= 1) wcnt += (uint32_t)__shfl_xor((int)wcnt, o, AM_WAVE);
         if ((tid0 & (AM_WAVE - 1)) == 0) {
-            L.SB0[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
+            L.MP[tid0 / AM_WAVE] = bad ? __builtin_inff() : wmx;
             L.TAB[tid0 / AM_WAVE] = wcnt;
         }
         fes_barrier();
         if (tid0 == 0) {
-            float v = L.SB0[0];
+            float v = L.MP[0];
             uint32_t n = L.TAB[0];
-            for (int w = 1; w < FE3_NW; ++w) { v = fmaxf(v, L.SB0[w]); n += L.TAB[w]; }
+            for (int w = 1; w < FE3_NW; ++w) { v = fmaxf(v, L.MP[w]); n += L.TAB[w]; }
             a.wg_max[blockIdx.x] = v;
             a.wg_cnt[blockIdx.x] = n;
         }

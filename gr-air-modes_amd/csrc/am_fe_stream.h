@@ -39,6 +39,41 @@ __device__ __forceinline__ float fes_from_next_lane(float v, float last, int lan
 #endif
 }
 
+// value of lane-1, lane 0 gets lane 63's (DPP wave_ror:1: every lane has a source, so the move folds into the consumer)
+__device__ __forceinline__ float fes_from_prev_lane_ror(float v, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x13C, 0xf, 0xf, true));
+#else
+    return __shfl(v, (lane + AM_WAVE - 1) & (AM_WAVE - 1), AM_WAVE);
+#endif
+}
+
+// Two independent fp32 operations per instruction (v_pk_add_f32 / v_pk_mul_f32: same rounding as the scalar forms; the
+// streaming front ends are bound by VALU issue, not by HBM).  On the host (CPU-fiber tests) a plain pair.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float fes_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ fes_f2 fes_mk2(float a, float b) { fes_f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ fes_f2 fes_pk_add(fes_f2 a, fes_f2 b) { return a + b; }
+__device__ __forceinline__ fes_f2 fes_pk_mul(fes_f2 a, fes_f2 b) { return a * b; }
+#else
+struct fes_f2 { float x, y; };
+__device__ __forceinline__ fes_f2 fes_mk2(float a, float b) { fes_f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ fes_f2 fes_pk_add(fes_f2 a, fes_f2 b) { fes_f2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+__device__ __forceinline__ fes_f2 fes_pk_mul(fes_f2 a, fes_f2 b) { fes_f2 r; r.x = a.x * b.x; r.y = a.y * b.y; return r; }
+#endif
+
+// 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate): operands are ring slots, lane and chip indices
+__device__ __forceinline__ int fes_mul24(int a, int b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
+
 // 16 bytes of raw IQ with the streaming (nt) policy: every sample is read once
 #if defined(__clang__)
 typedef float fes_f4 __attribute__((ext_vector_type(4)));
