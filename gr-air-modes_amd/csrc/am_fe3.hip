@@ -59,6 +59,10 @@
 #define FE3_NT (AM_WAVE * FE3_NW)         /* lanes 0..47 of a wave = its block's chips; all threads stage the loads */
 #define FE3_T (FE3_S * FE3_SPC)           /* samples per step                                          */
 #define FE3_LAG 9                         /* phase B runs this many chips behind phase A               */
+#ifndef FE3_EARLY
+#define FE3_EARLY 0                       /* 1: the next step's loads are issued when phase B's registers are free, under the sparse
+                                             outputs (no spills; measured 0.1229-0.1308 against 0.1262-0.1285 ms on two boxes: a tie) */
+#endif
 #ifndef FE3_CR_EXTRA
 #define FE3_CR_EXTRA 0
 #endif
@@ -125,7 +129,15 @@ __device__ __forceinline__ void fe3_load_step(const am_fe3_args &a, long long A0
     const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
     const unsigned off = (unsigned)tid * 16u;
 #pragma unroll
-    for (int j = J0; j < 12; ++j) r.v[j] = fes_gload16(gb + (off + (unsigned)j * (FE3_NT * 16u)));
+    for (int j = J0; j < 12; ++j) {
+        // scalar base per pair of pieces + the lane's 32-bit offset (+ 2 KB as the instruction's immediate): the address
+        // arithmetic stays on the scalar unit
+        unsigned long long g = reinterpret_cast<unsigned long long>(gb + (size_t)(j & ~1) * (FE3_NT * 16u));
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+s"(g));
+#endif
+        r.v[j] = fes_gload16_at(g, off + (unsigned)(j & 1) * (FE3_NT * 16u));
+    }
 }
 
 // where a thread's pieces go: piece j = samples 2k, 2k+1 (k = tid & 15) of the step's chip c0 + 8 j (c0 = tid >> 4), ring
@@ -204,6 +216,31 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
     fe3_store_step<J0>(L, slot0, par, tid, v);
 }
 
+// The next step's loads, issued by the current step (FE3_EARLY).  Where they are not issued the registers are defined
+// all the same: a variable that keeps its old contents on one path is live across the whole loop body -- 48 VGPRs
+// through phase B, which has none to spare.
+__device__ __forceinline__ void fe3_next_loads(const am_fe3_args &a, long long A1, int tid, bool next_fast, fe3_raw &nx)
+{
+    if (!FE3_EARLY) return;
+    if (next_fast) {
+        int t2 = tid;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(t2));                                  // (the addresses are formed here, not hoisted)
+#endif
+        fe3_load_step<0>(a, A1, t2, nx);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // ("some value", at no cost: zeros were hoisted in front of the branch, 48 moves on the path that loads)
+            asm volatile("" : "=v"(nx.v[j].x), "=v"(nx.v[j].y), "=v"(nx.v[j].z), "=v"(nx.v[j].w));
+#else
+            nx.v[j].x = 0.0f; nx.v[j].y = 0.0f; nx.v[j].z = 0.0f; nx.v[j].w = 0.0f;
+#endif
+        }
+    }
+}
+
 // One step (its |.|^2 is staged).
 //   step     global step index (may be -1: history before the first wanted block)
 //   test     false for a workgroup's first step (it only rebuilds the rings from the previous segment's tail)
@@ -211,7 +248,7 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
 __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const int step, const bool test,
                                          const int slot0, const int par, const bool edge, const int tid, float &mxrun,
-                                         bool &badrun, uint32_t &ncand, fe3_prof &PR)
+                                         bool &badrun, uint32_t &ncand, fe3_prof &PR, const bool next_fast, fe3_raw &nx)
 {
     constexpr int SPC = FE3_SPC;
     const int lane = tid & (AM_WAVE - 1), wv = tid >> 6;
@@ -309,7 +346,10 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     FE3_STAMP(1);
     fes_barrier();                                                    // B3: ring, totals and scans of this step complete
     FE3_STAMP(2);
-    if (!test) return;                                                // (uniform) ring rebuild only
+    if (!test) {                                                      // (uniform) ring rebuild only
+        fe3_next_loads(a, A0 + FE3_T, tid, next_fast, nx);
+        return;
+    }
 
     // ---- phase B on chip q = (this thread's phase-A chip) - 9: reference level (a4) + first-stage test (a6) --------
     // (ring offsets by add / compare / select from the phase-A chip's: slot * 36 is a multiply only once per step)
@@ -319,7 +359,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     const bool lowB = slotB < AM_CHIPS_AVG;
     const int slotS = slotB - AM_CHIPS_AVG + (lowB ? FE3_CR : 0);     // the chip 48 chips back
     const int offS = offB - AM_CHIPS_AVG * FE3_XS + (lowB ? FE3_CR * FE3_XS : 0);
-    float x[SPC], avgv[SPC], thrv[SPC];
+    float x[SPC], avgv[SPC];
     float nxt;
     {
         float scv[SPC];
@@ -364,9 +404,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
             else q = fes_mk2(scv[i + 1] + st_a, q32);
             const fes_f2 sv = fes_pk_add(q, pre);
             const fes_f2 av = fes_pk_mul(sv, fes_mk2(a.sL, a.sL));
-            const fes_f2 th = fes_pk_mul(av, fes_mk2(a.thr_lin, a.thr_lin));            // preamble_impl.cc:173
             avgv[i] = av.x; avgv[i + 1] = av.y;
-            thrv[i] = th.x; thrv[i + 1] = th.y;
         }
     }
     // array coordinate of x[0]
@@ -382,27 +420,35 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
 #if defined(FE2_CMPX)
         auto pass = [&](auto hc) __attribute__((always_inline)) {
             constexpr int H = decltype(hc)::value;
-            const float *thr = &thrv[H];
+            float thr[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i += 2) {
+                const fes_f2 th = fes_pk_mul(fes_mk2(avgv[H + i], avgv[H + i + 1]), fes_mk2(a.thr_lin, a.thr_lin));   // preamble_impl.cc:173
+                thr[i] = th.x; thr[i + 1] = th.y;
+            }
             uint32_t part = 0u;
             fe2_peak8<H>(part, &x[H], x[H + 8], &thr[0]);
             fe2_peak8<H + 8>(part, &x[H + 8], (H + 16 < SPC) ? x[(H + 16 < SPC) ? H + 16 : 0] : nxt, &thr[8]);
             // the three later pulses must not be below the threshold (:177-179): one test on the smallest
             // (v_min3 ignores a NaN operand exactly as `NaN < thr` is false); only where some lane has a survivor
             if (!(FE3_ABLATE & 2) && __ballot(part != 0u) != 0ull) {
-                float t2[CH], t7[CH], t9[CH];
 #pragma unroll
-                for (int k = 0; k < CH / 4; ++k) {
-                    const float4 u = reinterpret_cast<const float4 *>(L.X + off2 + H)[k];
-                    const float4 v = reinterpret_cast<const float4 *>(L.X + off7 + H)[k];
-                    const float4 w = reinterpret_cast<const float4 *>(L.X + off9 + H)[k];
-                    t2[4 * k] = u.x; t2[4 * k + 1] = u.y; t2[4 * k + 2] = u.z; t2[4 * k + 3] = u.w;
-                    t7[4 * k] = v.x; t7[4 * k + 1] = v.y; t7[4 * k + 2] = v.z; t7[4 * k + 3] = v.w;
-                    t9[4 * k] = w.x; t9[4 * k + 1] = w.y; t9[4 * k + 2] = w.z; t9[4 * k + 3] = w.w;
+                for (int g = 0; g < CH; g += 8) {                     // (eight positions at a time: 24 registers in flight, not 48)
+                    float t2[8], t7[8], t9[8];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float4 u = reinterpret_cast<const float4 *>(L.X + off2 + H + g)[k];
+                        const float4 v = reinterpret_cast<const float4 *>(L.X + off7 + H + g)[k];
+                        const float4 w = reinterpret_cast<const float4 *>(L.X + off9 + H + g)[k];
+                        t2[4 * k] = u.x; t2[4 * k + 1] = u.y; t2[4 * k + 2] = u.z; t2[4 * k + 3] = u.w;
+                        t7[4 * k] = v.x; t7[4 * k + 1] = v.y; t7[4 * k + 2] = v.z; t7[4 * k + 3] = v.w;
+                        t9[4 * k] = w.x; t9[4 * k + 1] = w.y; t9[4 * k + 2] = w.z; t9[4 * k + 3] = w.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) t2[i] = fminf(fminf(t2[i], t7[i]), t9[i]);
+                    if (g == 0) fe2_weak8<H>(part, &t2[0], &thr[0]);
+                    else fe2_weak8<H + 8>(part, &t2[0], &thr[8]);
                 }
-#pragma unroll
-                for (int i = 0; i < CH; ++i) t2[i] = fminf(fminf(t2[i], t7[i]), t9[i]);
-                fe2_weak8<H>(part, &t2[0], &thr[0]);
-                fe2_weak8<H + 8>(part, &t2[8], &thr[8]);
             }
             cm |= part;
         };
@@ -415,11 +461,12 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
 #pragma unroll
         for (int h = 0; h < SPC; h += CH) {
             bool c[CH];
-            const float *thr = &thrv[h];
+            float thr[CH];
             bool any = false;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const float xv = x[h + i];
+                thr[i] = avgv[h + i] * a.thr_lin;                        // preamble_impl.cc:173
                 const float nx = (h + i + 1 < SPC) ? x[(h + i + 1 < SPC) ? h + i + 1 : h + i] : nxt;
                 c[i] = (xv > thr[i]) & !(nx > xv);                       // :174, :175
                 any = any | c[i];
@@ -452,6 +499,8 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     ncand += (uint32_t)__popcll((unsigned long long)cm);
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
     FE3_STAMP(3);
+    // phase B's registers are free: the next step's raw samples start their way here and arrive under the sparse outputs
+    fe3_next_loads(a, A0 + FE3_T, tid, next_fast, nx);
     if (FE3_ABLATE & 1) return;
     // ---- sparse outputs ---------------------------------------------------------------------------------------------
     // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
@@ -576,6 +625,8 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     float mxrun = 0.0f;                                               // largest bb this thread has formed
     bool badrun = false;                                              // ... or one that is not finite
     uint32_t ncand = 0;                                               // candidates this thread's chips held
+    fe3_raw nx;                                                       // the next step's raw samples on their way (FE3_EARLY)
+    bool staged = false;
     for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
         const bool have = step >= a.raw_lo && step < a.raw_hi;        // the step's raw samples are all present and 16-byte aligned
@@ -588,7 +639,8 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
         // load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is chip
         // FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
-        if (have) {
+        if (FE3_EARLY && staged) fe3_store_step<0>(L, slot0, par, tid, nx);   // (loaded under the previous step's sparse outputs)
+        else if (have) {
             if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
             else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
         } else
@@ -596,7 +648,10 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         FE3_STAMP(5);
         fes_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
-        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR);
+        // the next step is a tested step of this segment whose samples are all present
+        const bool next_fast = FE3_EARLY && step + 1 < se && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
+        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR, next_fast, nx);
+        staged = next_fast;
         slot0 = fe3_wrap_up(slot0 + FE3_S);
         par ^= 1;
         FE3_STAMP(6);
