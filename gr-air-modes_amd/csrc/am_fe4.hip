@@ -109,6 +109,8 @@ struct fe4_cfg {
     static constexpr int NLD = (PIECES + NT - 1) / NT;                 // loads per thread and step
     static constexpr int LPR = R / 2;                                  // lanes that move one row (8 bytes each)
     static constexpr int RPI = AM_WAVE / LPR;                          // rows per wave instruction
+    static constexpr int UPR = NT / LPR;                               // staging: rows (units) per round of the workgroup's threads
+    static constexpr int ROUNDS = (US + UPR - 1) / UPR;                // staging: rounds (= loads per thread) per step
     static_assert(AM_CHIPS_AVG % G == 0 && R % 2 == 0 && R <= 32 && RS % 2 == 0, "unit shape");
     // straddling blocks (see the head of the file).  Wave w's first s0(w) lanes continue a block of wave w - 1; its last
     // t0(w) lanes belong to a block that ends in wave w + 1.  (A step is a whole number of blocks: s0(0) = t0(NW - 1) = 0.)
@@ -178,54 +180,90 @@ __device__ __forceinline__ int fe4_wrap_up(int s) { return s >= C::CRU ? s - C::
 template <class C>
 __device__ __forceinline__ int fe4_wrap_dn(int s) { return s < 0 ? s + C::CRU : s; }
 
-// |iq|^2 of one step into the ring rows of its units: piece p = tid + NT j holds samples 2p, 2p+1 of the step
-// = unit (2p) / R, offset (2p) % R (R is even: a piece never straddles two units).  GUARD: stream edges / unaligned
-// input, one sample at a time, zeros outside the stream.  P0: pieces below it are not loaded (ring rebuild).
-template <int SPC, int G, int NW, bool GUARD>
-__device__ __forceinline__ void fe4_stage_step(const am_fe4_args &a, const fe4_smem<SPC, G, NW> &L, long long A0, int slot0, int tid,
-                                               int p0)
+// |iq|^2 of one step into the ring rows of its units.  GUARD: stream edges / unaligned input, one sample at a time, zeros
+// outside the stream: piece p = tid + NT j holds samples 2p, 2p+1 of the step = unit (2p) / R, offset (2p) % R (R is even: a
+// piece never straddles two units).
+template <int SPC, int G, int NW>
+__device__ __forceinline__ void fe4_put_piece(const fe4_smem<SPC, G, NW> &L, int slot0, int u, int o, float m0, float m1)
 {
     using C = fe4_cfg<SPC, G, NW>;
-    auto put = [&](int p, float m0, float m1) __attribute__((always_inline)) {
-        const int u = (2 * p) / C::R, o = (2 * p) % C::R;
-        float2 mm; mm.x = m0; mm.y = m1;
-        *reinterpret_cast<float2 *>(L.X + fe4_wrap_up<C>(slot0 + u) * C::RS + o) = mm;
-        // the last chip of a wave's last unit a second time: the next wave needs it after the row holds bb
-        if ((u + 1) % C::LU == 0 && u + 1 < C::US && o >= C::R - SPC - (SPC & 1)) {
-            float *d = L.MLW + ((u + 1) / C::LU - 1) * SPC;
-            const int k = o - (C::R - SPC);
-            if (k >= 0) d[k] = m0;
-            if (k + 1 >= 0 && k + 1 < SPC) d[k + 1] = m1;
-        }
-    };
-    if constexpr (GUARD) {
-        const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
+    float2 mm; mm.x = m0; mm.y = m1;
+    *reinterpret_cast<float2 *>(L.X + fe4_wrap_up<C>(slot0 + u) * C::RS + o) = mm;
+    // the last chip of a wave's last unit a second time: the next wave needs it after the row holds bb
+    if ((u + 1) % C::LU == 0 && u + 1 < C::US && o >= C::R - SPC - (SPC & 1)) {
+        float *d = L.MLW + ((u + 1) / C::LU - 1) * SPC;
+        const int k = o - (C::R - SPC);
+        if (k >= 0) d[k] = m0;
+        if (k + 1 >= 0 && k + 1 < SPC) d[k + 1] = m1;
+    }
+}
+template <int SPC, int G, int NW>
+__device__ __forceinline__ void fe4_stage_guarded(const am_fe4_args &a, const fe4_smem<SPC, G, NW> &L, long long A0, int slot0, int tid)
+{
+    using C = fe4_cfg<SPC, G, NW>;
+    const float2 *iq2 = reinterpret_cast<const float2 *>(a.iq);
 #pragma unroll 1
-        for (int j = 0; j < C::NLD; ++j) {
-            const int p = tid + C::NT * j;
-            if (p >= C::PIECES) break;
-            const long long n = A0 + 2 * (long long)p;
-            float2 u0, u1;
-            u0.x = 0.0f; u0.y = 0.0f; u1 = u0;
-            if (n >= a.src_abs0 && n < a.src_abs1) u0 = iq2[n - a.src_abs0];
-            if (n + 1 >= a.src_abs0 && n + 1 < a.src_abs1) u1 = iq2[n + 1 - a.src_abs0];
-            const float r0 = u0.x * u0.x, i0 = u0.y * u0.y, r1 = u1.x * u1.x, i1 = u1.y * u1.y;
-            put(p, r0 + i0, r1 + i1);
-        }
-    } else {
-        const unsigned char *gb = reinterpret_cast<const unsigned char *>(a.iq) + (size_t)(A0 - a.src_abs0) * 8;
-        float4 v[C::NLD];
+    for (int j = 0; j < C::NLD; ++j) {
+        const int p = tid + C::NT * j;
+        if (p >= C::PIECES) break;
+        const long long n = A0 + 2 * (long long)p;
+        float2 u0, u1;
+        u0.x = 0.0f; u0.y = 0.0f; u1 = u0;
+        if (n >= a.src_abs0 && n < a.src_abs1) u0 = iq2[n - a.src_abs0];
+        if (n + 1 >= a.src_abs0 && n + 1 < a.src_abs1) u1 = iq2[n + 1 - a.src_abs0];
+        const float r0 = u0.x * u0.x, i0 = u0.y * u0.y, r1 = u1.x * u1.x, i1 = u1.y * u1.y;
+        fe4_put_piece<SPC, G, NW>(L, slot0, (2 * p) / C::R, (2 * p) % C::R, r0 + i0, r1 + i1);
+    }
+}
+// The same for a step whose samples are all present and aligned, in ROUNDS of whole rows: R / 2 lanes move one row, a
+// round is as many rows as the workgroup's threads hold (UPR; at 30 or 24 samples per unit eight threads of 128 sit
+// out), so a thread's unit advances by UPR per round and its place in the row never changes: one compare and one select
+// per piece for the ring's wrap-around, the rest is the instructions' immediate offsets.  (The division and the remainder by
+// R per piece, the 32-bit multiply by the row stride -- quarter rate -- and the select chains around them were a quarter of
+// the kernel's VALU time, which is what bounds it: DESIGN.md 5.1a.)  J0: rounds below it are not loaded (ring rebuild).
+template <int SPC, int G, int NW, int J0>
+__device__ __forceinline__ void fe4_stage_rows(const am_fe4_args &a, const fe4_smem<SPC, G, NW> &L, long long A0, int slot0, int tid)
+{
+    using C = fe4_cfg<SPC, G, NW>;
+    constexpr int LPR = C::LPR, UPR = C::UPR, USED = UPR * LPR, ROUNDS = C::ROUNDS;
+    if (USED < C::NT && tid >= USED) return;
+    const int c0 = fes_div_small<LPR>(tid);                           // unit inside the round
+    const int k = tid - fes_mul24(c0, LPR);                           // piece inside the row
+    const int sc = slot0 + c0;
+    float *const row = L.X + fes_mul24(sc, C::RS) + 2 * k;            // round 0's destination
+    float *const roww = row - C::CRU * C::RS;
+    const unsigned long long gb = reinterpret_cast<unsigned long long>(a.iq) + (unsigned long long)(A0 - a.src_abs0) * 8ull;
+    const unsigned off = (unsigned)tid * 16u;
+    float4 v[ROUNDS];
 #pragma unroll
-        for (int j = 0; j < C::NLD; ++j) {
-            const int p = tid + C::NT * j;
-            if (p < C::PIECES && p >= p0) v[j] = fes_gload16(gb + (size_t)p * 16u);
-        }
+    for (int j = J0; j < ROUNDS; ++j) {
+        if (UPR * (j + 1) > C::US && c0 + UPR * j >= C::US) continue; // (the last round may be short)
+        unsigned long long g = gb + (unsigned long long)(j & ~1) * (USED * 16u);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+s"(g));                                            // (scalar base per pair of rounds + the lane's offset)
+#endif
+        v[j] = fes_gload16_at(g, off + (unsigned)(j & 1) * (USED * 16u));
+    }
 #pragma unroll
-        for (int j = 0; j < C::NLD; ++j) {
-            const int p = tid + C::NT * j;
-            if (p < C::PIECES && p >= p0) {
-                const float r0 = v[j].x * v[j].x, i0 = v[j].y * v[j].y, r1 = v[j].z * v[j].z, i1 = v[j].w * v[j].w;
-                put(p, r0 + i0, r1 + i1);                                 // a1: fl(fl(I*I) + fl(Q*Q))
+    for (int j = J0; j < ROUNDS; ++j) {
+        if (UPR * (j + 1) > C::US && c0 + UPR * j >= C::US) continue;
+        const fes_f2 q0 = fes_pk_mul(fes_mk2(v[j].x, v[j].y), fes_mk2(v[j].x, v[j].y));
+        const fes_f2 q1 = fes_pk_mul(fes_mk2(v[j].z, v[j].w), fes_mk2(v[j].z, v[j].w));
+        float2 mm;
+        mm.x = q0.x + q0.y;                                           // a1: fl(fl(I*I) + fl(Q*Q))
+        mm.y = q1.x + q1.y;
+        float *dst = (sc >= C::CRU - UPR * j) ? roww : row;
+        *reinterpret_cast<float2 *>(dst + j * (UPR * C::RS)) = mm;
+        // the last chip of a wave's last unit a second time: the next wave needs it after the row holds bb
+#pragma unroll
+        for (int m = 1; m < NW; ++m) {
+            constexpr int LUc = C::LU;
+            const int cstar = LUc * m - 1 - UPR * j;                  // (compile time after unrolling)
+            if (cstar >= 0 && cstar < UPR && c0 == cstar && 2 * k >= C::R - SPC - (SPC & 1)) {
+                float *d = L.MLW + (m - 1) * SPC;
+                const int kk = 2 * k - (C::R - SPC);
+                if (kk >= 0) d[kk] = mm.x;
+                if (kk + 1 >= 0 && kk + 1 < SPC) d[kk + 1] = mm.y;
             }
         }
     }
@@ -243,15 +281,16 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
 {
     using C = fe4_cfg<SPC, G, NW>;
     constexpr int R = C::R, RS = C::RS, LPB = C::LPB, LAGU = C::LAGU;
-    const int lane = tid & (AM_WAVE - 1), wv = tid / AM_WAVE;
+    const int lane = tid & (AM_WAVE - 1), wv = tid >> 6;
     constexpr int LU = C::LU;
     const bool unit_thread = lane < LU;
-    const int t = wv * LU + (unit_thread ? lane : LU - 1);    // unit of the step (spare lanes shadow the last one, never write)
+    const int t = fes_mul24(wv, LU) + (unit_thread ? lane : LU - 1);    // unit of the step (spare lanes shadow the last one, never write)
     const long long A0 = a.out_abs0 + (long long)step * C::T;
     const int slotA = fe4_wrap_up<C>(slot0 + t);
     const bool do_pmf = a.use_pmf != 0 && SPC > 1;
     // position of the unit inside its 48-chip block (a step is a whole number of blocks; with 48 lanes per wave so is a wave)
-    const int lb = (LU == AM_WAVE ? (wv * AM_WAVE + lane) : lane) % LPB;
+    const int lb0 = (LU == AM_WAVE ? ((wv << 6) + lane) : lane);
+    const int lb = lb0 - fes_mul24(fes_div_small<LPB>(lb0), LPB);
     // straddling blocks: this wave's leading lanes that continue a block of the wave before / trailing lanes whose block
     // ends in the next wave (wave-uniform)
     const int s0 = C::STRADDLE ? (LPB - (AM_WAVE * wv) % LPB) % LPB : 0;
@@ -261,7 +300,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     float bb[R];
     {
         float m[R];
-        const float2 *mp = reinterpret_cast<const float2 *>(L.X + slotA * RS);
+        const float2 *mp = reinterpret_cast<const float2 *>(L.X + fes_mul24(slotA, RS));
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) { const float2 u = mp[k]; m[2 * k] = u.x; m[2 * k + 1] = u.y; }
         if (do_pmf) {
@@ -295,15 +334,21 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                     for (int i = SPC - 1; i >= 0; --i) { acc2 = acc2 + pv[i]; pv[i] = acc2; }
                 }
             }
+            float tt[R];
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
                 for (int i = 0; i < SPC; ++i) {
                     const int j = g * SPC + i;
-                    if (i == SPC - 1) bb[j] = pp[j] * a.s1;           // the window is the chip
-                    else if (g == 0) bb[j] = (fes_from_prev_lane(sx[(G - 1) * SPC + i + 1], pv[i + 1], lane) + pp[j]) * a.s1;
-                    else bb[j] = (sx[(g - 1) * SPC + i + 1] + pp[j]) * a.s1;
+                    if (i == SPC - 1) tt[j] = pp[j];                  // the window is the chip
+                    else if (g == 0) tt[j] = fes_from_prev_lane(sx[(G - 1) * SPC + i + 1], pv[i + 1], lane) + pp[j];
+                    else tt[j] = sx[(g - 1) * SPC + i + 1] + pp[j];
                 }
+#pragma unroll
+            for (int j = 0; j < R; j += 2) {                          // (two products per instruction)
+                const fes_f2 v = fes_pk_mul(fes_mk2(tt[j], tt[j + 1]), fes_mk2(a.s1, a.s1));
+                bb[j] = v.x; bb[j + 1] = v.y;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < R; ++j) bb[j] = m[j];
@@ -340,9 +385,15 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
             float xe = xin, ye = yin;
 #pragma unroll
             for (int g = 0; g < G; ++g) { xe = xe + f[g]; ye = ye + f[G - 1 - g]; }
-            const float xp = fes_from_prev_lane(xe, 0.0f, lane), yn = fes_from_next_lane(ye, 0.0f, lane);
-            xin = (lb == 0) ? 0.0f : xp;
-            yin = (lb == LPB - 1) ? 0.0f : yn;
+            if constexpr (LPB == 16 && LU == AM_WAVE) {
+                // (a block is a row of 16 lanes: the DPP row shift zero-fills where a block starts / ends)
+                xin = fes_from_prev_lane_row16(xe, lane);
+                yin = fes_from_next_lane_row16(ye, lane);
+            } else {
+                const float xp = fes_from_prev_lane(xe, 0.0f, lane), yn = fes_from_next_lane(ye, 0.0f, lane);
+                xin = (lb == 0) ? 0.0f : xp;
+                yin = (lb == LPB - 1) ? 0.0f : yn;
+            }
         }
         if (unit_thread) {
             float st0 = yin;                                          // ST of the unit's first chip: the later chips of the unit, right -> left
@@ -353,7 +404,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                 L.UST[slotA] = yin;
                 L.USL[slotA] = b0 + st0;
             }
-            float2 *xp = reinterpret_cast<float2 *>(L.X + slotA * RS);
+            float2 *xp = reinterpret_cast<float2 *>(L.X + fes_mul24(slotA, RS));
 #pragma unroll
             for (int k = 0; k < R / 2; ++k) { float2 u; u.x = bb[2 * k]; u.y = bb[2 * k + 1]; xp[k] = u; }
         }
@@ -434,8 +485,8 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     float x[R], avgv[R];
     {
         float sc[R];
-        const float2 *xp = reinterpret_cast<const float2 *>(L.X + slotB * RS);
-        const float2 *sp = reinterpret_cast<const float2 *>(L.X + slotS * RS);
+        const float2 *xp = reinterpret_cast<const float2 *>(L.X + fes_mul24(slotB, RS));
+        const float2 *sp = reinterpret_cast<const float2 *>(L.X + fes_mul24(slotS, RS));
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) { const float2 u = xp[k]; x[2 * k] = u.x; x[2 * k + 1] = u.y; }
 #pragma unroll
@@ -443,7 +494,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         const float xinB = L.UPT[slotB], yinS = L.UST[slotS];
         const float sl_next = L.USL[fe4_wrap_up<C>(slotS + 1)];       // RTOT + ST of the chip after the back unit's last
         // position of the unit's first chip inside its block (phase B's unit is LAGU behind: (lb - LAGU) mod LPB)
-        const int lbB = (lb + LPB * 8 - LAGU) % LPB;
+        const int lbB = lb - (LAGU % LPB) + ((lb < LAGU % LPB) ? LPB : 0);
         // back unit: forward chip totals (for ST), right -> left in-chip suffix sums (their first value is RTOT)
         float fS[G], stS[G], rtS[G];
 #pragma unroll
@@ -470,15 +521,34 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
             // (the block's last chip: lbB == LPB - 1 and g == G - 1)
             const bool blk_last = (lbB == LPB - 1) && (g == G - 1);
             const float suf_last = (g + 1 < G) ? (rtS[(g + 1 < G) ? g + 1 : g] + stS[(g + 1 < G) ? g + 1 : g]) : sl_next;
+            if constexpr (SPC % 2 == 0) {
+                // two positions per instruction; the chip's last position: (suf_last + pre), or pre alone where the window ends
+                // with the block (x + (-0) == x for every x, NaN included)
+                float apv[SPC];
 #pragma unroll
-            for (int i = 0; i < SPC; ++i) {
-                const int j = g * SPC + i;
-                ap = ap + x[j];
-                const float pre = pt + ap;
-                float s;
-                if (i == SPC - 1) s = blk_last ? pre : (suf_last + pre);
-                else s = (sc[j + 1] + stS[g]) + pre;
-                avgv[j] = s * a.sL;
+                for (int i = 0; i < SPC; ++i) { ap = ap + x[g * SPC + i]; apv[i] = ap; }
+                const float q_last = blk_last ? -0.0f : suf_last;
+#pragma unroll
+                for (int i = 0; i < SPC; i += 2) {
+                    const int j = g * SPC + i;
+                    const fes_f2 pre = fes_pk_add(fes_mk2(pt, pt), fes_mk2(apv[i], apv[i + 1]));
+                    fes_f2 q;
+                    if (i + 2 < SPC) q = fes_pk_add(fes_mk2(sc[j + 1], sc[j + 2]), fes_mk2(stS[g], stS[g]));
+                    else q = fes_mk2(sc[j + 1] + stS[g], q_last);
+                    const fes_f2 av = fes_pk_mul(fes_pk_add(q, pre), fes_mk2(a.sL, a.sL));
+                    avgv[j] = av.x; avgv[j + 1] = av.y;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SPC; ++i) {
+                    const int j = g * SPC + i;
+                    ap = ap + x[j];
+                    const float pre = pt + ap;
+                    float s;
+                    if (i == SPC - 1) s = blk_last ? pre : (suf_last + pre);
+                    else s = (sc[j + 1] + stS[g]) + pre;
+                    avgv[j] = s * a.sL;
+                }
             }
             pt = pt + ap;                                             // PT of the next chip: + this chip's forward total
         }
@@ -493,19 +563,20 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         auto ahead = [&](int j, int chips) __attribute__((always_inline)) {
             const int g = j / SPC + chips, i = j % SPC;
             const int d = g / G, gg = g % G;
-            return d == 0 ? x[gg * SPC + i] : L.X[fe4_wrap_up<C>(slotB + d) * RS + gg * SPC + i];
+            return d == 0 ? x[gg * SPC + i] : L.X[fes_mul24(fe4_wrap_up<C>(slotB + d), RS) + gg * SPC + i];
         };
-        const float nxt = L.X[fe4_wrap_up<C>(slotB + 1) * RS];
+        const float nxt = L.X[fes_mul24(fe4_wrap_up<C>(slotB + 1), RS)];
         // eight samples at a time (the partial results of more would not fit the scalar registers: they are lane masks)
 #pragma unroll
         for (int h = 0; h < R; h += 8) {
             constexpr int CH = 8;
             float thr[CH], xs[CH + 1];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int j = (h + k < R) ? h + k : R - 1;
-                thr[k] = avgv[j] * a.thr_lin;                            // :173
-                xs[k] = x[j];
+            for (int k = 0; k < CH; k += 2) {                         // (R is even: a pair is inside the unit or beyond it)
+                const int j = (h + k < R) ? h + k : R - 2;
+                const fes_f2 th = fes_pk_mul(fes_mk2(avgv[j], avgv[j + 1]), fes_mk2(a.thr_lin, a.thr_lin));   // :173
+                thr[k] = th.x; thr[k + 1] = th.y;
+                xs[k] = x[j]; xs[k + 1] = x[j + 1];
             }
             xs[CH] = (h + CH < R) ? x[(h + CH < R) ? h + CH : R - 1] : nxt;
             uint32_t part = 0u;
@@ -528,9 +599,9 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
                 float wk[CH];
                 if constexpr (G == 1 && SPC % 8 == 0) {
                     // (one chip per unit: the pulses are the same offsets of the rows 2, 7 and 9 units on -- 8-byte reads)
-                    const float2 *q2 = reinterpret_cast<const float2 *>(L.X + fe4_wrap_up<C>(slotB + 2) * RS + h);
-                    const float2 *q7 = reinterpret_cast<const float2 *>(L.X + fe4_wrap_up<C>(slotB + 7) * RS + h);
-                    const float2 *q9 = reinterpret_cast<const float2 *>(L.X + fe4_wrap_up<C>(slotB + 9) * RS + h);
+                    const float2 *q2 = reinterpret_cast<const float2 *>(L.X + fes_mul24(fe4_wrap_up<C>(slotB + 2), RS) + h);
+                    const float2 *q7 = reinterpret_cast<const float2 *>(L.X + fes_mul24(fe4_wrap_up<C>(slotB + 7), RS) + h);
+                    const float2 *q9 = reinterpret_cast<const float2 *>(L.X + fes_mul24(fe4_wrap_up<C>(slotB + 9), RS) + h);
 #pragma unroll
                     for (int k = 0; k < CH / 2; ++k) {
                         const float2 u = q2[k], v = q7[k], w = q9[k];
@@ -581,7 +652,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     const long long lo64 = -jstep, hi64 = a.out_n - jstep;            // elements [lo, hi) of this step's coordinates exist
     const int lo = lo64 <= 0 ? 0 : (lo64 > 0x7FFFFFF ? 0x7FFFFFF : (int)lo64);
     const int hi = hi64 <= 0 ? 0 : (hi64 > 0x7FFFFFF ? 0x7FFFFFF : (int)hi64);
-    const int sub = lane / C::LPR, piece = lane % C::LPR;
+    const int sub = fes_div_small<C::LPR>(lane), piece = lane - fes_mul24(sub, C::LPR);
     auto put2 = [&](float *dst, int rel, float2 u) __attribute__((always_inline)) {
         if (!edge || (rel >= lo && rel + 2 <= hi)) *reinterpret_cast<float2 *>(dst + rel) = u;
         else {
@@ -602,15 +673,15 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         float *const dst = a.avg_sparse + jstep;
         for (int r0 = 0; r0 < nav; r0 += 4) {                         // (uniform trip count)
             if (mine && my_rank >= r0 && my_rank < r0 + 4) {
-                float2 *d = reinterpret_cast<float2 *>(avs + (my_rank - r0) * RS);
+                float2 *d = reinterpret_cast<float2 *>(avs + fes_mul24(my_rank - r0, RS));
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) { float2 u; u.x = avgv[2 * k]; u.y = avgv[2 * k + 1]; d[k] = u; }
             }
             __builtin_amdgcn_wave_barrier();
             const int r = r0 + sub;
             if (sub < 4 && sub < C::RPI && r < nav) {
-                const int tu = wv * LU + (int)tab[r];
-                put2(dst, tu * R + 2 * piece, *reinterpret_cast<const float2 *>(avs + sub * RS + 2 * piece));
+                const int tu = fes_mul24(wv, LU) + (int)tab[r];
+                put2(dst, fes_mul24(tu, R) + 2 * piece, *reinterpret_cast<const float2 *>(avs + fes_mul24(sub, RS) + 2 * piece));
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -650,9 +721,9 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
         for (int r0 = 0; r0 < nflag; r0 += C::RPI) {                  // (uniform trip count)
             const int r = r0 + sub;
             if (sub < C::RPI && r < nflag) {
-                const int tu = wv * LU + (int)tab[r];                 // test index of the unit
+                const int tu = fes_mul24(wv, LU) + (int)tab[r];       // test index of the unit
                 const int slot = fe4_wrap_dn<C>(fe4_wrap_up<C>(slot0 + tu) - LAGU);
-                put2(dst, tu * R + 2 * piece, *reinterpret_cast<const float2 *>(L.X + slot * RS + 2 * piece));
+                put2(dst, fes_mul24(tu, R) + 2 * piece, *reinterpret_cast<const float2 *>(L.X + fes_mul24(slot, RS) + 2 * piece));
             }
         }
     }
@@ -684,7 +755,7 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
     uint32_t ncand = 0;                                               // candidates this thread's units held
     // the step before the segment only rebuilds the rings: its first tested unit is unit US - LAGU, whose reference level
     // reaches back LPB units
-    constexpr int WARM_P0 = ((C::US - C::LAGU - C::LPB - 1) * C::R / 2 / C::NT) * C::NT;
+    constexpr int WARM_J0 = (C::US - C::LAGU - C::LPB - 1) / C::UPR;
     for (int step = sb - 1; step < se; ++step) {
         const bool test = step >= sb;
         const bool have = step >= a.raw_lo && step < a.raw_hi;        // the step's raw samples are all present and 16-byte aligned
@@ -694,8 +765,11 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
         asm volatile("" : "+v"(tid));
 #endif
         FE4_STAMP(4);
-        if (have) fe4_stage_step<SPC, G, NW, false>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid, test ? 0 : WARM_P0);
-        else fe4_stage_step<SPC, G, NW, true>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid, 0);
+        if (have) {
+            if (test) fe4_stage_rows<SPC, G, NW, 0>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid);
+            else fe4_stage_rows<SPC, G, NW, WARM_J0>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid);
+        } else
+            fe4_stage_guarded<SPC, G, NW>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid);
         FE4_STAMP(5);
         fes_barrier();                                                // B1: |.|^2 of this step staged
         FE4_STAMP(0);

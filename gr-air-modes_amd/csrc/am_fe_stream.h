@@ -39,6 +39,29 @@ __device__ __forceinline__ float fes_from_next_lane(float v, float last, int lan
 #endif
 }
 
+// the same inside rows of 16 lanes: the first / last lane of a row gets 0 (DPP row_shr:1 / row_shl:1 with bound_ctrl: the
+// move folds into the addition that follows)
+__device__ __forceinline__ float fes_from_prev_lane_row16(float v, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+#else
+    const float s = __shfl_up(v, 1, AM_WAVE);
+    return (lane & 15) == 0 ? 0.0f : s;
+#endif
+}
+__device__ __forceinline__ float fes_from_next_lane_row16(float v, int lane)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+#else
+    const float s = __shfl_down(v, 1, AM_WAVE);
+    return (lane & 15) == 15 ? 0.0f : s;
+#endif
+}
+
 // value of lane-1, lane 0 gets lane 63's (DPP wave_ror:1: every lane has a source, so the move folds into the consumer)
 __device__ __forceinline__ float fes_from_prev_lane_ror(float v, int lane)
 {
@@ -72,6 +95,14 @@ __device__ __forceinline__ int fes_mul24(int a, int b)
 #else
     return a * b;
 #endif
+}
+
+// x / D for small non-negative x (x * D < 65536: thread and lane indices) without the quarter-rate 32-bit multiply
+template <int D>
+__device__ __forceinline__ int fes_div_small(int x)
+{
+    static_assert(D >= 1 && D <= 256, "divisor");
+    return fes_mul24(x, (65536 + D - 1) / D) >> 16;
 }
 
 // 16 bytes of raw IQ with the streaming (nt) policy: every sample is read once
