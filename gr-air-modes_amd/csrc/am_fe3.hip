@@ -695,7 +695,7 @@ static int fe3_wgs_for_device() { return FE3_WG_PER_CU * am_device_cus(); }   //
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps, unsigned *steps_per_wg,
-                         hipStream_t s)
+                         hipStream_t s, int wgs_per_cu)
 {
     am_fe3_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
@@ -719,6 +719,7 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
     // persistent workgroups: as many as are resident at once, each with a contiguous run of steps; short inputs
     // get at least 4 steps per workgroup (the ring rebuild costs one)
     unsigned resident = (unsigned)fe3_wgs_for_device();
+    if (wgs_per_cu > 0 && wgs_per_cu < FE3_WG_PER_CU) resident = (unsigned)(wgs_per_cu * am_device_cus());   // (am_pipe: room for other batches' tails)
 #if defined(AM_TEST_KNOBS)
     if (const char *e = getenv("AIRMODES_FE3_WGS_PER_CU"))            // tuning: leave room on every CU for another batch's tail
         if (atoi(e) > 0) resident = (unsigned)(atoi(e) * am_device_cus());

@@ -74,7 +74,7 @@ unsigned am_fe3_steps(long long out_n);
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
-                         unsigned *steps_per_wg, hipStream_t s);
+                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu);
 int am_fe4_supported(int spc);
 unsigned am_fe4_unit(int spc);
 unsigned am_fe4_words(int spc);
@@ -85,7 +85,9 @@ unsigned am_fe4_steps(long long out_n, int spc);
 hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
-                         unsigned *steps_per_wg, hipStream_t s);
+                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu);
+/* (wgs_per_cu: 0 = as many persistent workgroups as are resident at once; n > 0 = at most n per CU -- am_pipe leaves room on
+ * every CU for the small kernels of the other batches in flight; honoured by am_k_fe3) */
 /* flat candidate positions from the bitmap, one workgroup per front-end workgroup: workgroup g owns the words
  * [g * words_per_wg, (g + 1) * words_per_wg) (nwords in all) and starts its part of pos[] at the sum of wg_cnt[0 .. g)
  * -- no scan launch, no chain.  Entries at or beyond Mcap are dropped; *total_out = the number of candidates. */
