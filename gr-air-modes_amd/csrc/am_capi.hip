@@ -1579,10 +1579,20 @@ int am_shard_scan(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_e
     return shard_scan_core(c, iq, abs_start, abs_end, total_n, flags, table, cap, n_table, nullptr, 0);
 }
 
+// Is p memory the device can address (device, managed, or pinned / registered host memory)?  Pageable host memory handed to
+// the host-free calls would be a GPU memory fault, not an error code.
+static bool device_addressable(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged || a.type == hipMemoryTypeHost;
+}
+
 int am_shard_scan_async(am_ctx *c, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
                         uint32_t flags, am_shard_exit *msg_dev, uint64_t msg_cap)
 {
     if (!c || !msg_dev || msg_cap == 0) return AM_EINVAL;
+    if (!device_addressable(msg_dev)) return fail(c, AM_EINVAL, "am_shard_scan_async: msg_dev is not device-addressable memory");
     return shard_scan_core(c, iq, abs_start, abs_end, total_n, flags, nullptr, 0, nullptr, msg_dev, msg_cap);
 }
 
@@ -1693,6 +1703,7 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     if (n_out) *n_out = 0;
     *redo = 0;
     if (!c->shard_ready) return fail(c, AM_EINVAL, "am_shard_scan_async has not been called");
+    if (!device_addressable(msgs_dev)) return fail(c, AM_EINVAL, "am_shard_resolve_async: msgs_dev is not device-addressable memory");
     HIPCHK(c, hipSetDevice(c->device));
     c->pending.clear();
     c->last_tags = 0;

@@ -2,18 +2,22 @@
 // (64 Msps), the rate BASELINE.json's metric is quoted on.  Same results as am_k_fe2 / the oracle
 // (canonical summation order), different machine mapping:
 //
-//   * PERSISTENT workgroups, six per CU (128 threads = 2 waves, 26 KB of LDS, <= 168 VGPRs).  A workgroup owns a
+//   * PERSISTENT workgroups, six per CU (128 threads = 2 waves, 26 KB of LDS, 156 VGPRs: three waves per SIMD).  A workgroup owns a
 //     contiguous segment of the stream and walks it in steps of 96 chips (two 48-chip blocks, 3072 samples).  What a
 //     step needs from the past -- the pulse-matched power bb of the last 57 chips and their per-chip sums -- stays in
 //     LDS rings, so nothing is loaded twice (the tile kernel re-read a 49-chip halo per tile and could not shrink its
 //     tiles for that reason).
 //   * raw IQ arrives by plain coalesced 16-byte loads with the streaming (nt) policy, 12 per thread, issued back to
 //     back and waited for; |.|^2 goes straight into the ring slots of the step's chips.  No prefetch: while one
-//     workgroup waits for its loads the other five of the CU compute.  (LDS-DMA staging and register prefetch were
-//     built and measured in round 2 -- DESIGN.md 5.1: the staging buffer / the registers cost the occupancy this
-//     arithmetic needs; those variants are gone from the source.)
-//   * thread = one chip (32 samples in registers).  The chip before it belongs to lane-1: its in-chip
-//     suffix sums come over with DPP wave_shr:1 (no LDS traffic for the pulse-matched filter).
+//     workgroup waits for its loads the other five of the CU compute.  (LDS-DMA staging and register prefetch -- also the
+//     next step's loads under the current step's sparse outputs, which fit the registers -- were built and measured in
+//     rounds 2 and 4, DESIGN.md 5.1 / profiles/r4_valu: none is faster; those variants are gone from the source.)
+//   * thread = one chip (32 samples in registers).  The chip before it belongs to lane-1: its in-chip suffix sums come
+//     over inside the addition (v_add_f32_dpp wave_ror:1); lane 63 stands in for the chip before the wave's first.
+//   * THE KERNEL IS PRICED AGAINST HBM BUT WAS BOUND BY VALU ISSUE (a wave64 instruction holds the SIMD for four cycles;
+//     ~85 % busy until round 4): every instruction per sample counts.  Address arithmetic is kept off the vector ALU (scalar
+//     bases, immediate offsets, 24-bit multiplies, compare + select for the ring's wrap-around), products and sums of
+//     neighbouring positions are packed (v_pk_mul_f32 / v_pk_add_f32: same rounding as the scalar forms).
 //   * phase B (reference level + first-stage test) runs 9 chips BEHIND phase A, so the pulses 2, 7 and 9
 //     chips ahead are already in the ring: no right halo, no redundant arithmetic.
 //   * outputs are sparse: one candidate bit per position (a dense bitmap, 1/64 of the input bytes) and,
@@ -59,10 +63,6 @@
 #define FE3_NT (AM_WAVE * FE3_NW)         /* lanes 0..47 of a wave = its block's chips; all threads stage the loads */
 #define FE3_T (FE3_S * FE3_SPC)           /* samples per step                                          */
 #define FE3_LAG 9                         /* phase B runs this many chips behind phase A               */
-#ifndef FE3_EARLY
-#define FE3_EARLY 0                       /* 1: the next step's loads are issued when phase B's registers are free, under the sparse
-                                             outputs (no spills; measured 0.1229-0.1308 against 0.1262-0.1285 ms on two boxes: a tie) */
-#endif
 #ifndef FE3_CR_EXTRA
 #define FE3_CR_EXTRA 0
 #endif
@@ -216,31 +216,6 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
     fe3_store_step<J0>(L, slot0, par, tid, v);
 }
 
-// The next step's loads, issued by the current step (FE3_EARLY).  Where they are not issued the registers are defined
-// all the same: a variable that keeps its old contents on one path is live across the whole loop body -- 48 VGPRs
-// through phase B, which has none to spare.
-__device__ __forceinline__ void fe3_next_loads(const am_fe3_args &a, long long A1, int tid, bool next_fast, fe3_raw &nx)
-{
-    if (!FE3_EARLY) return;
-    if (next_fast) {
-        int t2 = tid;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(t2));                                  // (the addresses are formed here, not hoisted)
-#endif
-        fe3_load_step<0>(a, A1, t2, nx);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            // ("some value", at no cost: zeros were hoisted in front of the branch, 48 moves on the path that loads)
-            asm volatile("" : "=v"(nx.v[j].x), "=v"(nx.v[j].y), "=v"(nx.v[j].z), "=v"(nx.v[j].w));
-#else
-            nx.v[j].x = 0.0f; nx.v[j].y = 0.0f; nx.v[j].z = 0.0f; nx.v[j].w = 0.0f;
-#endif
-        }
-    }
-}
-
 // One step (its |.|^2 is staged).
 //   step     global step index (may be -1: history before the first wanted block)
 //   test     false for a workgroup's first step (it only rebuilds the rings from the previous segment's tail)
@@ -248,7 +223,7 @@ __device__ __forceinline__ void fe3_next_loads(const am_fe3_args &a, long long A
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
 __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const int step, const bool test,
                                          const int slot0, const int par, const bool edge, const int tid, float &mxrun,
-                                         bool &badrun, uint32_t &ncand, fe3_prof &PR, const bool next_fast, fe3_raw &nx)
+                                         bool &badrun, uint32_t &ncand, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
     const int lane = tid & (AM_WAVE - 1), wv = tid >> 6;
@@ -346,10 +321,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     FE3_STAMP(1);
     fes_barrier();                                                    // B3: ring, totals and scans of this step complete
     FE3_STAMP(2);
-    if (!test) {                                                      // (uniform) ring rebuild only
-        fe3_next_loads(a, A0 + FE3_T, tid, next_fast, nx);
-        return;
-    }
+    if (!test) return;                                                // (uniform) ring rebuild only
 
     // ---- phase B on chip q = (this thread's phase-A chip) - 9: reference level (a4) + first-stage test (a6) --------
     // (ring offsets by add / compare / select from the phase-A chip's: slot * 36 is a multiply only once per step)
@@ -499,8 +471,6 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     ncand += (uint32_t)__popcll((unsigned long long)cm);
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
     FE3_STAMP(3);
-    // phase B's registers are free: the next step's raw samples start their way here and arrive under the sparse outputs
-    fe3_next_loads(a, A0 + FE3_T, tid, next_fast, nx);
     if (FE3_ABLATE & 1) return;
     // ---- sparse outputs ---------------------------------------------------------------------------------------------
     // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
@@ -625,8 +595,6 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     float mxrun = 0.0f;                                               // largest bb this thread has formed
     bool badrun = false;                                              // ... or one that is not finite
     uint32_t ncand = 0;                                               // candidates this thread's chips held
-    fe3_raw nx;                                                       // the next step's raw samples on their way (FE3_EARLY)
-    bool staged = false;
     for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
         const bool have = step >= a.raw_lo && step < a.raw_hi;        // the step's raw samples are all present and 16-byte aligned
@@ -639,8 +607,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
         // load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is chip
         // FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
-        if (FE3_EARLY && staged) fe3_store_step<0>(L, slot0, par, tid, nx);   // (loaded under the previous step's sparse outputs)
-        else if (have) {
+        if (have) {
             if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
             else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
         } else
@@ -648,10 +615,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         FE3_STAMP(5);
         fes_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
-        // the next step is a tested step of this segment whose samples are all present
-        const bool next_fast = FE3_EARLY && step + 1 < se && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
-        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR, next_fast, nx);
-        staged = next_fast;
+        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR);
         slot0 = fe3_wrap_up(slot0 + FE3_S);
         par ^= 1;
         FE3_STAMP(6);

@@ -117,6 +117,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+// (every pointer is "device memory" here)
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer; void *hostPointer; };
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) { a->type = hipMemoryTypeDevice; a->device = 0; a->devicePointer = (void *)p; a->hostPointer = (void *)p; return hipSuccess; }
 enum { hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }

@@ -352,6 +352,30 @@ def test_production_stages_chunked_and_no_pmf(lib):
         assert pc.check_production_stages(lib, rate, n // 2, 3000.0, 14, pmf=False, want_fe=3) > 0
 
 
+def test_host_free_calls_refuse_pageable_message_buffers(lib):
+    """am_shard_scan_async / am_shard_resolve_async write and read their message buffers on the device: handed pageable host
+    memory (a numpy array) they return AM_EINVAL instead of faulting the GPU."""
+    import torch
+    rate, n = 4e6, 200_000
+    iq, _ = synth.synth_capture(rate, n, 2000.0, 77)
+    d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+    ctx = _capi.Context(rate, 7.0, True, lib=lib)
+    words = 2 * (_capi.SHARD_MSG_HEADER + 512)
+    host_msg = np.zeros(words, np.uint64)
+    with pytest.raises(_capi.AirModesError) as ei:
+        ctx.shard_scan_async(d.data_ptr(), 0, n, n, host_msg.ctypes.data, 512)
+    assert ei.value.code == _capi.AM_EINVAL
+    dev_msg = torch.zeros(words, dtype=torch.int64, device="cuda:0")
+    ctx.shard_scan_async(d.data_ptr(), 0, n, n, dev_msg.data_ptr(), 512)          # (device memory: accepted)
+    with pytest.raises(_capi.AirModesError) as ei:
+        ctx.shard_resolve_async(host_msg.ctypes.data, 1, 0, 512)
+    assert ei.value.code == _capi.AM_EINVAL
+    pk, redo = ctx.shard_resolve_async(dev_msg.data_ptr(), 1, 0, 512)
+    assert not redo and np.array_equal(pk, oracle.demod(iq, rate))
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_host_free_sharded_step_on_device(lib):
     """The host-free time-shard step (am_shard_scan_async -> device-side entry composition -> am_shard_resolve_async) on the
     device: one chunk = the whole stream (world 1: no collective), three steps, none falls back to the synchronous path, and
