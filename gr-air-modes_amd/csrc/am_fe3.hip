@@ -50,10 +50,10 @@
 #define FE3_ABLATE 0
 #endif
 #ifndef FE3_WPS
-#define FE3_WPS 3                         /* launch bound, waves per SIMD (<= 168 VGPRs)               */
+#define FE3_WPS 3                         /* launch bound, waves per SIMD (<= 168 VGPRs; it uses 156)  */
 #endif
 #ifndef FE3_WG_PER_CU
-#define FE3_WG_PER_CU 6                   /* resident workgroups per CU (26 KB of LDS, 2 waves of <= 168 VGPRs each) */
+#define FE3_WG_PER_CU 6                   /* resident workgroups per CU (26 KB of LDS each: the limit; 2 waves of <= 168 VGPRs) */
 #endif
 #define FE3_SPC 32
 #ifndef FE3_NW
@@ -116,7 +116,7 @@ struct fe3_smem {
     float *M47;               // [32] |.|^2 of chip 47 (the chip before wave 1's first)
     uint32_t *CARRY;          // [2] chips at the start of the next step whose bb must be written (bit mask, by step parity)
     uint32_t *TAB;            // [2][64] per wave: lane of the r-th chip whose bb / reference level is written
-    float *AVS;               // [2][4 * FE3_XS] per wave: four chips of reference level on their way out
+    float *AVS;               // [8 * FE3_XS] eight chips of wave 1's reference level on their way out (wave 0 parks its rows in the ring)
 };
 #define FE3_LDS_BYTES (FE3_CR * FE3_XS * 4 + (64 + 32 * (FE3_NW - 1)) * 4 + FE3_NW * 4 * FE3_XS * 4 + 3 * FE3_CR * 4 + 2 * 4 + FE3_NW * 64 * 4)
 
@@ -226,7 +226,12 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                                          bool &badrun, uint32_t &ncand, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
-    const int lane = tid & (AM_WAVE - 1), wv = tid >> 6;
+    const int lane = tid & (AM_WAVE - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // (wave-uniform, and known to be: scalar arithmetic, uniform branches)
+#else
+    const int wv = tid >> 6;
+#endif
     const bool chip_thread = lane < AM_CHIPS_AVG;
     const int lc = chip_thread ? lane : AM_CHIPS_AVG - 1;             // chip inside the wave's block (spare lanes shadow the last one, never write)
     const int t = fes_mul24(wv, AM_CHIPS_AVG) + lc;                   // chip of the step
@@ -474,13 +479,17 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     if (FE3_ABLATE & 1) return;
     // ---- sparse outputs ---------------------------------------------------------------------------------------------
     // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
-    // always).  The values exist only in registers: the flagged lanes park them in a small LDS buffer, four chips at
-    // a time, and the wave writes them out with coalesced stores like bb above.
+    // always).  The values exist only in registers: the flagged lanes park them in LDS rows and the wave writes them out
+    // with coalesced stores like bb below, eight rows per instruction.  Where they park: wave 0 in the ring rows of the
+    // chips 57 .. 10 before the step -- its own phase B (behind it in program order) was their last reader, wave 1 never
+    // reads them, and the next step's staging overwrites them after barrier B5 -- all of its rows at once; wave 1 in the
+    // eight rows of the small buffer, eight at a time.  (Round 4: both waves went through four buffer rows at a time,
+    // 8 LDS writes with four active lanes per four rows: 8.5 us of the kernel at the stress density.)
     if (!(FE3_ABLATE & 16)) {
+        static_assert(FE3_NW == 2 && FE3_CR >= FE3_S + FE3_LAG + AM_CHIPS_AVG + 1, "who may reuse which ring rows");
         const unsigned long long wa = (cand | (cand << 1) | 1ull) & ((1ull << AM_CHIPS_AVG) - 1ull);
         const int nav = __popcll(wa);
         uint32_t *tab = L.TAB + wv * AM_WAVE;
-        float *avs = L.AVS + wv * (4 * FE3_XS);
         const bool mine = ((wa >> lane) & 1ull) != 0ull;
         const int my_rank = __popcll(wa & ((1ull << lane) - 1ull));
         if (mine) tab[my_rank] = (uint32_t)lane;
@@ -489,9 +498,19 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
         const int lo = lo64 <= 0 ? 0 : (lo64 > 0x7FFFFFF ? 0x7FFFFFF : (int)lo64);
         const int hi = hi64 <= 0 ? 0 : (hi64 > 0x7FFFFFF ? 0x7FFFFFF : (int)hi64);
         const int sub = lane >> 3, piece = lane & 7;
-        for (int r0 = 0; r0 < nav; r0 += 4) {                         // (uniform trip count)
-            if (mine && my_rank >= r0 && my_rank < r0 + 4) {
-                float4 *d = reinterpret_cast<float4 *>(avs + (my_rank - r0) * FE3_XS);
+        const int RB = (wv == 0) ? AM_CHIPS_AVG : 2 * 4;              // (uniform) rows parked per batch
+        // row r of a batch: wave 0 -> ring slot of chip r - 57 of the step; wave 1 -> buffer row r
+        auto park_row = [&](int r) __attribute__((always_inline)) -> float * {
+            if (wv == 0) {
+                int slot = slot0 - (FE3_LAG + AM_CHIPS_AVG) + r;      // >= -57, < FE3_CR
+                slot += (slot < 0) ? FE3_CR : 0;
+                return L.X + fes_mul24(slot, FE3_XS);
+            }
+            return L.AVS + fes_mul24(r, FE3_XS);
+        };
+        for (int b0 = 0; b0 < nav; b0 += RB) {                        // (uniform trip count: one batch in wave 0)
+            if (mine && my_rank >= b0 && my_rank < b0 + RB) {
+                float4 *d = reinterpret_cast<float4 *>(park_row(my_rank - b0));
 #pragma unroll
                 for (int k = 0; k < SPC / 4; ++k) {
                     float4 u;
@@ -500,17 +519,20 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            const int r = r0 + sub;
-            if (sub < 4 && r < nav) {
-                const int tc = fes_mul24(wv, AM_CHIPS_AVG) + (int)tab[r];
-                const float4 u = *reinterpret_cast<const float4 *>(avs + sub * FE3_XS + 4 * piece);
-                const int rel = (tc << 5) + 4 * piece;
-                if (!edge || (rel >= lo && rel + 4 <= hi)) fe3_gstore16(dst + rel, u);
-                else {
-                    if (rel >= lo && rel < hi) dst[rel] = u.x;
-                    if (rel + 1 >= lo && rel + 1 < hi) dst[rel + 1] = u.y;
-                    if (rel + 2 >= lo && rel + 2 < hi) dst[rel + 2] = u.z;
-                    if (rel + 3 >= lo && rel + 3 < hi) dst[rel + 3] = u.w;
+            const int bend = (b0 + RB < nav) ? b0 + RB : nav;
+            for (int r0 = b0; r0 < bend; r0 += 8) {                   // (uniform)
+                const int r = r0 + sub;
+                if (r < bend) {
+                    const int tc = fes_mul24(wv, AM_CHIPS_AVG) + (int)tab[r];
+                    const float4 u = *reinterpret_cast<const float4 *>(park_row(r - b0) + 4 * piece);
+                    const int rel = (tc << 5) + 4 * piece;
+                    if (!edge || (rel >= lo && rel + 4 <= hi)) fe3_gstore16(dst + rel, u);
+                    else {
+                        if (rel >= lo && rel < hi) dst[rel] = u.x;
+                        if (rel + 1 >= lo && rel + 1 < hi) dst[rel + 1] = u.y;
+                        if (rel + 2 >= lo && rel + 2 < hi) dst[rel + 2] = u.z;
+                        if (rel + 3 >= lo && rel + 3 < hi) dst[rel + 3] = u.w;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
