@@ -135,7 +135,8 @@ struct fe4_smem {
                               // from the right (= ST of its last chip); RTOT + ST of its first chip
     float *SBL;               // [2][SPC] in-chip suffix sums of |.|^2 of a step's last chip (by step parity)
     float *MLW;               // [NW-1][SPC] |.|^2 of the last chip of wave w's last unit (the chip before wave w+1's first)
-    float *AVS;               // [NW][4 * RS] four units of reference level on their way out
+    float *AVS;               // [NW][4 * RS] units of reference level on their way out (four per wave; with two waves and wave 0
+                              // parking in the ring, all eight rows are wave 1's)
     uint32_t *CARRY;          // [2] units at the start of the next step whose bb must be written (by step parity)
     uint32_t *TAB;            // [NW][64] lane of the r-th unit whose bb / reference level is written
     float *WMX;               // [NW] the waves' largest samples at the end
@@ -281,7 +282,12 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
 {
     using C = fe4_cfg<SPC, G, NW>;
     constexpr int R = C::R, RS = C::RS, LPB = C::LPB, LAGU = C::LAGU;
-    const int lane = tid & (AM_WAVE - 1), wv = tid >> 6;
+    const int lane = tid & (AM_WAVE - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);          // (wave-uniform, and known to be)
+#else
+    const int wv = tid >> 6;
+#endif
     constexpr int LU = C::LU;
     const bool unit_thread = lane < LU;
     const int t = fes_mul24(wv, LU) + (unit_thread ? lane : LU - 1);    // unit of the step (spare lanes shadow the last one, never write)
@@ -662,26 +668,40 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
     };
     if (!(FE4_ABLATE & 16)) {
         // reference level: the unit of a candidate and the one after it (a wave's lane 0 cannot see the unit before it: always).
-        // The values exist only in registers: the flagged lanes park them in a small LDS buffer, four units at a time.
+        // The values exist only in registers: the flagged lanes park them in LDS rows, a batch at a time, and the wave writes
+        // the batch out RPI rows per instruction.  Where they park (as in am_k_fe3): wave 0 in the ring rows of the LPB units
+        // before unit -LAGU of the step -- its own phase B, behind it in program order, was their last reader (the rows 48
+        // chips back of its units), no other wave reads them, the next step's staging overwrites them after barrier B5;
+        // the other waves in the small buffer (with two waves, wave 1 has all eight of its rows).
+        constexpr bool PARK_RING = LPB >= 8;                          // (2 .. 8 Msps: a block is 2 .. 6 units, the buffer is larger)
+        constexpr int BUF_ROWS = (PARK_RING && NW == 2) ? 8 : 4;
         const unsigned long long wa = (cand | (cand << 1) | 1ull) & C::LUMASK;
         const int nav = __popcll(wa);
         uint32_t *tab = L.TAB + wv * AM_WAVE;
-        float *avs = L.AVS + wv * (4 * RS);
+        const bool ring = PARK_RING && wv == 0;                       // (uniform)
+        const int RB = ring ? LPB : BUF_ROWS;
         const bool mine = ((wa >> lane) & 1ull) != 0ull;
         const int my_rank = __popcll(wa & ((1ull << lane) - 1ull));
         if (mine) tab[my_rank] = (uint32_t)lane;
         float *const dst = a.avg_sparse + jstep;
-        for (int r0 = 0; r0 < nav; r0 += 4) {                         // (uniform trip count)
-            if (mine && my_rank >= r0 && my_rank < r0 + 4) {
-                float2 *d = reinterpret_cast<float2 *>(avs + fes_mul24(my_rank - r0, RS));
+        auto park_row = [&](int r) __attribute__((always_inline)) -> float * {
+            if (ring) return L.X + fes_mul24(fe4_wrap_dn<C>(slot0 - (LAGU + LPB) + r), RS);
+            return L.AVS + fes_mul24(((PARK_RING && NW == 2) ? 0 : wv * 4) + r, RS);
+        };
+        for (int b0 = 0; b0 < nav; b0 += RB) {                        // (uniform trip count)
+            if (mine && my_rank >= b0 && my_rank < b0 + RB) {
+                float2 *d = reinterpret_cast<float2 *>(park_row(my_rank - b0));
 #pragma unroll
                 for (int k = 0; k < R / 2; ++k) { float2 u; u.x = avgv[2 * k]; u.y = avgv[2 * k + 1]; d[k] = u; }
             }
             __builtin_amdgcn_wave_barrier();
-            const int r = r0 + sub;
-            if (sub < 4 && sub < C::RPI && r < nav) {
-                const int tu = fes_mul24(wv, LU) + (int)tab[r];
-                put2(dst, fes_mul24(tu, R) + 2 * piece, *reinterpret_cast<const float2 *>(avs + fes_mul24(sub, RS) + 2 * piece));
+            const int bend = (b0 + RB < nav) ? b0 + RB : nav;
+            for (int r0 = b0; r0 < bend; r0 += C::RPI) {              // (uniform)
+                const int r = r0 + sub;
+                if (sub < C::RPI && r < bend) {
+                    const int tu = fes_mul24(wv, LU) + (int)tab[r];
+                    put2(dst, fes_mul24(tu, R) + 2 * piece, *reinterpret_cast<const float2 *>(park_row(r - b0) + 2 * piece));
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
