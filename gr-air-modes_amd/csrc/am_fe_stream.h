@@ -97,11 +97,12 @@ __device__ __forceinline__ int fes_mul24(int a, int b)
 #endif
 }
 
-// x / D for small non-negative x (x * D < 65536: thread and lane indices) without the quarter-rate 32-bit multiply
+// x / D for 0 <= x < 1024 and D <= 64 (thread and lane indices by lanes per row / per block) without the quarter-rate 32-bit
+// multiply: exact there (x (D - 1) < 65536; tests/test_fe_stream_helpers.py runs the whole domain)
 template <int D>
 __device__ __forceinline__ int fes_div_small(int x)
 {
-    static_assert(D >= 1 && D <= 256, "divisor");
+    static_assert(D >= 1 && D <= 64, "divisor");
     return fes_mul24(x, (65536 + D - 1) / D) >> 16;
 }
 
