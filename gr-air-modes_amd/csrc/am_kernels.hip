@@ -2229,6 +2229,56 @@ __device__ __forceinline__ float am_soft_chip_iq(const float *__restrict__ iq, l
     return v;
 }
 
+// 64 Msps, a hit whose samples are all inside the source (round 4, late): the windows of a burst's soft chips tile its
+// samples -- chip c is the 32 samples that end at ae + 32 c -- so the workgroup loads them as ONE coalesced run (a wave's load is
+// 1 KB of consecutive bytes, not 64 requests 256 bytes apart: the texture addressers were busy 55 % of this kernel's time),
+// leaves |.|^2 in LDS rows of one window each (stride 36 floats: 16-byte row reads of consecutive lanes hit all banks), and a
+// lane reads its window back 16 bytes at a time.  NS samples from absolute sample B0 (NS a multiple of 512: 256 threads x 2).
+// E[(s >> 5) * 36 + (s & 31)] = |.|^2 of sample B0 + s.  The source is read 16 bytes at a time: from the even sample at or
+// before B0 (one more piece, by thread 0, where B0 is odd).
+#define AM_XROW 36
+template <int NS>
+__device__ __forceinline__ void am_stage_energies32(const float *__restrict__ iq, long long src_abs0, long long B0, float *E, int tid)
+{
+    static_assert(NS % 512 == 0, "whole rounds of 256 threads x 2 samples");
+    constexpr int ROUNDS = NS / 512;
+    const int odd = (int)((B0 - src_abs0) & 1);
+    const float4 *src = reinterpret_cast<const float4 *>(iq) + ((B0 - odd - src_abs0) >> 1);
+    const int i0 = 2 * tid - odd, i1 = i0 + 1;                        // samples of the thread's piece in round 0 (i0 = -1: not wanted)
+    float *const e0 = E + (i0 >> 5) * AM_XROW + (i0 & 31);            // (arithmetic shift: -1 -> row -1, column 31: right from round 1 on)
+    float *const e1 = E + (i1 >> 5) * AM_XROW + (i1 & 31);
+    float4 v[ROUNDS], vx;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) v[r] = src[tid + 256 * r];
+    vx.x = vx.y = vx.z = vx.w = 0.0f;
+    if (odd && tid == 0) vx = src[NS / 2];                            // (the last sample's piece)
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const float a = v[r].x * v[r].x, b = v[r].y * v[r].y, c = v[r].z * v[r].z, d = v[r].w * v[r].w;
+        if (r > 0 || i0 >= 0) e0[r * 16 * AM_XROW] = a + b;           // a1: fl(fl(I*I) + fl(Q*Q))
+        e1[r * 16 * AM_XROW] = c + d;
+    }
+    if (odd && tid == 0) { const float a = vx.x * vx.x, b = vx.y * vx.y; E[((NS - 1) >> 5) * AM_XROW + 31] = a + b; }
+}
+// soft chip of the window in LDS row `row` (bb; the reference level comes off later): ii = offset of the burst's first sample
+// inside its canonical chip, the same for all of a burst's windows
+__device__ __forceinline__ float am_soft_chip_row32(const float *E, int row, int ii, float s1)
+{
+    constexpr int SPC = 32;
+    float m[SPC];
+    const float4 *rp = reinterpret_cast<const float4 *>(E + row * AM_XROW);
+#pragma unroll
+    for (int k = 0; k < SPC / 4; ++k) { const float4 u = rp[k]; m[4 * k] = u.x; m[4 * k + 1] = u.y; m[4 * k + 2] = u.z; m[4 * k + 3] = u.w; }
+    const int wb = SPC - 1 - ii;                                      // window index of the chip's first sample
+    float pre = 0.0f, suf = 0.0f;
+#pragma unroll
+    for (int w = 0; w < SPC; ++w) {
+        if (w >= wb) pre = pre + m[w];                                // (uniform conditions)
+        if (SPC - 1 - w < wb) suf = suf + m[SPC - 1 - w];
+    }
+    return (ii == SPC - 1) ? pre * s1 : (suf + pre) * s1;
+}
+
 template <int SPC>
 __global__ void __launch_bounds__(256, 5)
 am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
@@ -2244,6 +2294,7 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     // no filter, the launcher passes use_pmf = 0)
     constexpr int HEAD = 128;                                 // chips of a short packet: 16 + 2 * 56
     __shared__ float sb[AM_BURST];
+    __shared__ float stg[SPC == 32 ? HEAD * AM_XROW : 1];     // 64 Msps: |.|^2 of 128 windows (am_stage_energies32)
     const int tid = threadIdx.x, lane = tid & (AM_WAVE - 1);
 #if defined(AM_XPROF)
     long long xlast = (long long)__builtin_readcyclecounter();
@@ -2276,18 +2327,35 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         const long long xh0 = (long long)__builtin_readcyclecounter();
 #endif
         AM_XSTAMP(0);
+        const bool staged = SPC == 32 && inside;                              // (uniform) coalesced loads through LDS
+        const int ii = (int)(ae % SPC);
+        if constexpr (SPC == 32) {
+            if (staged) {
+                am_stage_energies32<HEAD * 32>(iq, src_abs0, ae - (SPC - 1), stg, tid);
+                __syncthreads();
+            }
+        }
         if (tid < HEAD) {
-            const float v = am_soft_chip_iq<SPC>(iq, src_abs0, src_abs1, pmf, s1, ae, tid, inside) - av;   // preamble_impl.cc:219-221
+            float v;
+            if (staged) v = am_soft_chip_row32(stg, tid, ii, s1) - av;
+            else v = am_soft_chip_iq<SPC>(iq, src_abs0, src_abs1, pmf, s1, ae, tid, inside) - av;   // preamble_impl.cc:219-221
             sb[tid] = v;
             if (bursts_out) bursts_out[(size_t)i * AM_BURST + tid] = v;
         }
         __syncthreads();
         AM_XSTAMP(1);
         const bool all = bursts_out != nullptr || am_burst_is_long(sb);       // (uniform)
+        if constexpr (SPC == 32) {
+            if (staged && all) {                                              // (the rows' readers are behind the barrier above)
+                am_stage_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, stg, tid);
+                __syncthreads();
+            }
+        }
         if (tid >= HEAD && tid < AM_BURST) {
             float v = 0.0f;                                                   // (never looked at in a short packet)
             if (all) {
-                v = am_soft_chip_iq<SPC>(iq, src_abs0, src_abs1, pmf, s1, ae, tid, inside) - av;
+                if (staged) v = am_soft_chip_row32(stg, tid - HEAD, ii, s1) - av;
+                else v = am_soft_chip_iq<SPC>(iq, src_abs0, src_abs1, pmf, s1, ae, tid, inside) - av;
                 if (bursts_out) bursts_out[(size_t)i * AM_BURST + tid] = v;
             }
             sb[tid] = v;
