@@ -58,7 +58,7 @@ REALISTIC_LAMBDA = 2000.0  # bursts per second of the second density
 
 def ctx_messages(ctx, packets):
     """Message texts of a packet array as the library formats them (first message: 6 significant digits)."""
-    return [ctx.lib.format_message(packets[i:i + 1], i == 0) for i in range(len(packets))]
+    return ctx.lib.format_messages(packets, True)          # (am_format_messages: one call per batch)
 
 
 def free_port():
@@ -313,6 +313,12 @@ def main():
         dt = time.perf_counter() - t0
         inflight, nb, per_batch = 1, 1, [len(pk)]
         extra["sharded_sync_steps"] = rx.sync_steps
+        # host time inside the torch.distributed calls of a step (enqueue + whatever the backend makes the host wait for);
+        # a one-rank receiver (--force-sharded) is the floor with no collective at all
+        hs = max(1, rx.host_us["steps"])
+        extra["host_dist_us_per_step"] = {"tail_exchange_batch_isend_irecv": rx.host_us["tail_exchange"] / hs,
+                                          "exit_table_all_gather_into_tensor": rx.host_us["all_gather"] / hs,
+                                          "steps_counted": rx.host_us["steps"], "rank": rank}
         # parity, part 1: a short stream through the same N-rank receiver IN TWO STEPS against the oracle over the WHOLE stream
         import oracle
         ns = max(4 * rx.halo, 30000 * spc)
@@ -367,6 +373,21 @@ def main():
     else:
         npk_total = npk_steps
 
+    # who took part: the driver's SCALE record should prove N ranks on N devices behind the number
+    me = {"rank": rank, "device": str(dev)}
+    if not args.emu and torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(dev)
+        me.update({"name": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None), "pci_device_id": getattr(pr, "pci_device_id", None),
+                   "uuid": str(getattr(pr, "uuid", "")), "hip_visible_devices": os.environ.get("HIP_VISIBLE_DEVICES"),
+                   "local_rank": int(os.environ.get("LOCAL_RANK", "0"))})
+    ranks_info = [me]
+    ranks_seen = 1
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)               # (through the data-path backend itself: RCCL on the GPU box)
+        ranks_seen = int(round(float(one[0].item())))
     if rank == 0:
         total_samples = world * n * args.steps
         value = total_samples / dt
@@ -418,6 +439,15 @@ def main():
                          "kernel_ms_per_rank": {"min": min(fe_ranks), "max": max(fe_ranks)},
                          "algorithmic_bytes_per_launch": 8 * n},
         }
+        coll = None
+        if world > 1:
+            coll = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+            if not args.emu and torch.cuda.is_available():
+                try:
+                    coll["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception as ex:      # (reported, not fatal: the version query is not the data path)
+                    coll["rccl_version"] = "unavailable: %s" % ex
+        res["ranks"] = {"ranks_seen": ranks_seen, "collectives": coll, "per_rank": ranks_info}
         if args.emu:
             res["emulated"] = True
         if parity is not None:
@@ -434,7 +464,7 @@ def main():
             if not args.no_cpu_baseline or args.emu:
                 res["cpu_baseline"] = {"value": n / cpu_dt, "unit": "samples/s", "cores": 1, "kind": "port",
                                        "sample": "one %d-sample batch of this run, one pass of oracle/airmodes_oracle.c "
-                                                 "(scalar C, gcc -O2, 1 thread), %.2f s" % (n, cpu_dt),
+                                                 "(scalar C, gcc -O3, 1 thread), %.2f s" % (n, cpu_dt),
                                        "host_cores_available": os.cpu_count()}
                 res["speedup_vs_cpu_baseline"] = value / (n / cpu_dt)
         if mode == "single" and not args.no_cpu_baseline and not args.emu:
@@ -465,7 +495,7 @@ def main():
             # oracle/_ref, which travels with the repository) behind the port's front end, where it exists:
             # bounded sample, messages compared with the GPU path's
             if oracle.have_ref():
-                nr = min(n, 8 * 1000 * 1000)
+                nr = n                                           # the whole batch
                 t3 = time.perf_counter()
                 rbb, ravg = oracle.frontend(iq_check[:nr], spc, True)
                 rmsgs = oracle.ref_preamble_slicer(rbb, ravg, spc, 7.0, rate)[2]
@@ -473,7 +503,7 @@ def main():
                 sub = ctx.process_iq(iq_check[:nr], flush=True)
                 res["cpu_baseline_reference"] = {
                     "value": nr / ref_dt, "unit": "samples/s", "cores": 1, "kind": "reference",
-                    "sample": "the first %d samples of the batch: port front end (|iq|^2, PMF, reference level) + "
+                    "sample": "the whole batch (%d samples): port front end (|iq|^2, PMF, reference level) + "
                               "the reference's preamble_impl/slicer_impl/modes_crc compiled from /root/reference "
                               "against the GNU Radio API stub, 1 thread, %.2f s" % (nr, ref_dt),
                     # (the reference driver also reports hits past the canonical end of the stream: a prefix match)

@@ -18,7 +18,7 @@ AM_F_FLUSH = 0x2
 AM_F_DEVICE_OUT = 0x4
 AM_F_KEEP_TAGS = 0x8
 AM_F_MORE = 0x10
-ABI_VERSION = 2
+ABI_VERSION = 3
 SHARD_MSG_HEADER = 2          # header entries of a device-side exit-table message (am_shard_scan_async)
 
 AM_OK, AM_EINVAL, AM_ENODEV, AM_ENOMEM, AM_EHIP, AM_ECAPACITY, AM_ENOTSUP = 0, -1, -2, -3, -4, -5, -6
@@ -98,6 +98,8 @@ class Library(object):
         L.am_crc24.restype = u32
         L.am_crc24.argtypes = [vp, ci]
         L.am_format_message.argtypes = [vp, ci, C.c_char_p, C.c_size_t]
+        L.am_format_messages.argtypes = [vp, u64, ci, vp, C.c_size_t, vp, pu64]
+        L.am_is_emulated.restype = ci
         L.am_shard_halo.argtypes = [vp, pu64, pu64]
         L.am_shard_scan.argtypes = [vp, vp, u64, u64, u64, u32, vp, u64, pu64]
         L.am_shard_entry.argtypes = [vp, vp, vp, u32, vp]
@@ -137,6 +139,7 @@ class Library(object):
         self.L = L
         if L.am_abi_version() != ABI_VERSION:
             raise OSError("ABI version mismatch in %s" % path)
+        self.emulated = bool(L.am_is_emulated())      # the test-only CPU build of the same sources (tests/emu)
 
     # host-side helpers that need no context
     def crc24(self, data):
@@ -150,6 +153,25 @@ class Library(object):
         if w < 0:
             raise AirModesError(w, "am_format_message")
         return buf.value.decode()
+
+
+    def format_messages(self, packets, first):
+        """The texts of a batch of accepted packets in ONE call (lib/slicer_impl.cc:186-194); `first`: the precision quirk
+        of the stream's very first message applies to packets[0]."""
+        p = np.ascontiguousarray(np.asarray(packets, PACKET_DTYPE).reshape(-1))
+        n = int(p.size)
+        if n == 0:
+            return []
+        cap = 80 * n
+        buf = C.create_string_buffer(cap)
+        offs = np.zeros(n + 1, np.uint64)
+        need = C.c_uint64(0)
+        rc = self.L.am_format_messages(p.ctypes.data, n, int(bool(first)), C.addressof(buf), cap, offs.ctypes.data,
+                                       C.byref(need))
+        if rc < 0:
+            raise AirModesError(rc, "am_format_messages")
+        raw = buf.raw[:int(offs[n])]
+        return [t.decode() for t in raw.split(b"\0")[:n]]
 
 
 _default = None

@@ -54,11 +54,12 @@ class slicer(object):
 
     def post(self, packets):
         """Format accepted packets exactly like the reference and hand them to the queue."""
-        lib = self._ctx.lib
-        for i in range(len(packets)):
-            text = lib.format_message(packets[i], self._first)
-            self._first = False
+        if len(packets) == 0:
+            return 0
+        # one call into the library per batch (am_format_messages), not one per packet
+        for text in self._ctx.lib.format_messages(packets, self._first):
             self._queue.handle(message.make_from_string(text))
+        self._first = False
         return len(packets)
 
     def work(self, bursts, tags):

@@ -42,6 +42,7 @@ the number of ranks.  "rx_time" tags (ctx.set_rx_time) carry stream-absolute off
 same tags.
 """
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -71,10 +72,13 @@ class ShardedReceiver(object):
         self.full_exchanges = 0                           # steps that needed the full-size message
         self.sync_steps = 0                               # steps the host-free path had to repeat synchronously
         self.k = 0                                        # steps of the current stream so far
+        # host time spent inside the torch.distributed calls of step(), summed over steps (microseconds; bench.py reports
+        # them per step beside the no-collective floor of a one-rank receiver)
+        self.host_us = {"tail_exchange": 0.0, "all_gather": 0.0, "steps": 0}
         self._alloc(device if device is not None else "cpu")
         # the device-side exchange hands device pointers to kernels: only where the buffers live on the GPU (or where
         # "device memory" is host memory: the CPU emulation the tests run on)
-        emulated = "emu" in str(getattr(ctx.lib, "path", ""))
+        emulated = bool(getattr(ctx.lib, "emulated", False))   # (am_is_emulated(): asked of the library, not guessed from its path)
         self.host_free = bool(host_free) and (self._buf.is_cuda or emulated)
         self.chunk = self._buf[self.halo * 2:(self.halo + self.n) * 2]
         # the rank whose tail the next STEP needs (the last one) keeps it inside the resolve call: behind the slicing, which
@@ -115,8 +119,7 @@ class ShardedReceiver(object):
         # host-free step: this rank's message (header + small_cap entries of (pos, exit)), and everybody's
         words = 2 * (_capi.SHARD_MSG_HEADER + self.small_cap)
         self._amsg = t.zeros(words, dtype=t.int64, device=dev)
-        self._agath = t.zeros(self.world * words, dtype=t.int64, device=dev)
-        self._agath_list = list(self._agath.chunk(self.world))
+        self._agath = t.zeros(self.world * words, dtype=t.int64, device=dev)   # (all_gather_into_tensor: no list of views, no copies)
 
     def reset(self):
         """Start a new stream at sample 0 (what step(flush=True) does at its end)."""
@@ -155,8 +158,10 @@ class ShardedReceiver(object):
             elif self.k > 0:
                 ops.append(dist.P2POp(dist.irecv, self._halo_view, world - 1, self.group))
             if ops:
+                tc = time.perf_counter()
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()          # (RCCL: orders the current stream behind the transfer, the host does not block)
+                self.host_us["tail_exchange"] += (time.perf_counter() - tc) * 1e6
         elif self.k > 0:
             # one rank: it is its own predecessor (the kept tail goes in front of the chunk on the context's own stream)
             self.ctx.stream_copy(self._halo_view.data_ptr(), self._tail.data_ptr(), halo * 8)
@@ -183,7 +188,9 @@ class ShardedReceiver(object):
             if world > 1:
                 if on_gpu:
                     self.ctx.signal_stream(cur)              # the collective waits (on the device) for the table
-                dist.all_gather(self._agath_list, self._amsg, group=self.group)
+                tc = time.perf_counter()
+                dist.all_gather_into_tensor(self._agath, self._amsg, group=self.group)
+                self.host_us["all_gather"] += (time.perf_counter() - tc) * 1e6
                 if on_gpu:
                     self.ctx.wait_for_stream(cur)            # ... and the resolve step for the collective
                 msgs = self._agath
@@ -198,6 +205,7 @@ class ShardedReceiver(object):
                 pk = None
         if pk is None:
             pk = self._step_sync(ptr, a0, a1, total, more, cap_pk, on_gpu)
+        self.host_us["steps"] += 1
         # 3. what the next step needs from this one
         if flush:
             self.reset()

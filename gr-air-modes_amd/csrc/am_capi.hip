@@ -286,7 +286,11 @@ am_geom geom_of(uint64_t rate_i, int *idx /* [AM_BURST] */)
     g.zb0 = (int)(5 * sps);
     g.zb1 = (int)floor(7.5 * sps);                       // largest j with (double)j <= 7.5 * sps
     const float Bf = 240 * spcf;
-    g.B = (int)Bf;                                       // consume_each(i + 240 * spc): the float sum as an int
+    // consume_each(i + 240 * spc) (:237): int + float, rounded to float, truncated; i counts from the start of the current
+    // general_work() window.  A whole number wherever 240 * spcf is one (every rate the tests pin against the reference's
+    // C++); elsewhere (2.1 Msps: 251.99998) the sum rounds to i + 252 for all i >= 4: the skip at a representative window
+    // offset, as oracle/airmodes_oracle.c::geom_of
+    g.B = (int)((float)1024 + Bf) - 1024;
     g.room = (int)ceilf(Bf);                             // smallest d with !((float)d < Bf)
     for (int j = 0; j < AM_BURST; j++) idx[j] = (int)(j * spcf);
     g.span = idx[AM_BURST - 1];
@@ -808,6 +812,16 @@ bool flush_limits(const am_ctx *c, uint64_t N, uint64_t *emit_max)
 extern "C" {
 
 uint32_t am_abi_version(void) { return AM_ABI_VERSION; }
+
+// 1 in the test-only CPU build of these sources (tests/emu: "device memory" is host memory there), 0 in the product
+int am_is_emulated(void)
+{
+#if defined(AM_HIP_EMULATION)
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int *err)
 {
@@ -1406,6 +1420,33 @@ int am_format_message(const am_packet *p, int first, char *buf, size_t cap)
     if ((size_t)w + 1 > cap) return AM_ECAPACITY;
     memcpy(buf, tmp, (size_t)w + 1);
     return w;
+}
+
+// A batch of messages per call: text k starts at buf + offsets[k] (NUL-terminated), offsets[n] = bytes used.  `first` applies
+// to packet 0 only (the member ostringstream's precision is 6 until the first message has been formatted, 10 ever after:
+// slicer_impl.cc:186-194, slicer_impl.h:43).  Nothing is written beyond cap; AM_ECAPACITY leaves the bytes needed in *need.
+int am_format_messages(const am_packet *pkts, uint64_t n, int first, char *buf, size_t cap, uint64_t *offsets, uint64_t *need)
+{
+    if (need) *need = 0;
+    if (n && (!pkts || !offsets)) return AM_EINVAL;
+    if (!buf && cap) return AM_EINVAL;
+    uint64_t used = 0;
+    bool fits = true;
+    char tmp[200];
+    for (uint64_t k = 0; k < n; ++k) {
+        const int w = am_format_message(pkts + k, (first && k == 0) ? 1 : 0, tmp, sizeof(tmp));
+        if (w < 0) return w;
+        if (fits && used + (uint64_t)w + 1 <= (uint64_t)cap) {
+            offsets[k] = used;
+            memcpy(buf + used, tmp, (size_t)w + 1);
+        } else
+            fits = false;
+        used += (uint64_t)w + 1;
+    }
+    if (need) *need = used;
+    if (!fits) return AM_ECAPACITY;
+    if (offsets) offsets[n] = used;
+    return AM_OK;
 }
 
 int am_shard_halo(const am_ctx *c, uint64_t *left, uint64_t *right)

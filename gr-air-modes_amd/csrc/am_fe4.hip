@@ -874,7 +874,7 @@ unsigned am_fe4_steps(long long out_n, int spc)
 }
 
 template <int SPC, int G, int NW>
-static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t s)
+static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu)
 {
     using C = fe4_cfg<SPC, G, NW>;
     const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
@@ -899,6 +899,7 @@ static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t
     if (const char *e = getenv("AIRMODES_FE4_WGS_PER_CU"))
         if (atoi(e) > 0) wpc = atoi(e);
 #endif
+    if (wgs_per_cu > 0 && wgs_per_cu < wpc) wpc = wgs_per_cu;         // (am_pipe: room on every CU for other batches' tails, as am_launch_fe3)
     const unsigned resident = (unsigned)(wpc * am_device_cus());
     unsigned spw = (a.nsteps + resident - 1) / resident;
     if (spw < 4) spw = 4;
@@ -972,16 +973,16 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
     a.test_lo = clampi(fes_ceil_div((long long)j0 + lag, T));
     a.test_hi = clampi(fes_floor_div(jhi + lag, T));
     switch (spc) {
-    case 1: return fe4_launch<1, 24, 2>(a, steps_per_wg, s);
-    case 2: return fe4_launch<2, 16, 2>(a, steps_per_wg, s);
-    case 4: return fe4_launch<4, 8, 2>(a, steps_per_wg, s);
-    case 5: return fe4_launch<5, 6, 2>(a, steps_per_wg, s);
-    case 8: return fe4_launch<8, 4, 2>(a, steps_per_wg, s);
-    case 10: return fe4_launch<10, 3, 2>(a, steps_per_wg, s);
-    case 16: return fe4_launch<16, 2, 2>(a, steps_per_wg, s);
-    case 20: return fe4_launch<20, 1, 2>(a, steps_per_wg, s);
+    case 1: return fe4_launch<1, 24, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 2: return fe4_launch<2, 16, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 4: return fe4_launch<4, 8, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 5: return fe4_launch<5, 6, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 8: return fe4_launch<8, 4, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 10: return fe4_launch<10, 3, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 16: return fe4_launch<16, 2, 2>(a, steps_per_wg, s, wgs_per_cu);
+    case 20: return fe4_launch<20, 1, 2>(a, steps_per_wg, s, wgs_per_cu);
 #if defined(FE4_64MSPS)
-    default: return fe4_launch<32, 1, FE4_NW64>(a, steps_per_wg, s);
+    default: return fe4_launch<32, 1, FE4_NW64>(a, steps_per_wg, s, wgs_per_cu);
 #else
     default: return hipErrorInvalidValue;
 #endif

@@ -1064,8 +1064,9 @@ hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n,
     const uint32_t grid = (n + AM_SCAN_BLK - 1) / AM_SCAN_BLK;
     hipLaunchKernelGGL(am_k_exscan_chain, dim3(grid), dim3(256), 0, s, in, out, n, Mp, slots, epoch, total_out, err, ticket,
                        *ticket_base);
-    *ticket_base += grid;                                    // (every workgroup draws one)
-    return hipGetLastError();
+    const hipError_t rc = hipGetLastError();
+    if (rc == hipSuccess) *ticket_base += grid;              // (every workgroup of a launch that happened draws one: the host's
+    return rc;                                               //  count must not run ahead of the device's when a launch fails)
 }
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
@@ -1836,10 +1837,12 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     ea.own_hi = own_hi; ea.emit_idx = emit_idx; ea.n_out = n_out; ea.slots = slots; ea.epoch = epoch; ea.scalars = scalars;
     ea.want_resume = want_resume;
     ea.ticket = ticket; ea.ticket_base = *ticket_base;
-    *ticket_base += L.nblk;                                  // (every workgroup draws one)
+    if (hipError_t rc = hipGetLastError(); rc != hipSuccess) return rc;   // (the walk's launch)
     hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M, ea,
                        Mp);
-    return hipGetLastError();
+    const hipError_t rc = hipGetLastError();
+    if (rc == hipSuccess) *ticket_base += L.nblk;            // (every workgroup of a launch that happened draws one)
+    return rc;
 }
 
 // exit table of a time chunk for its first n candidates (needs am_launch_chain_prepare(want_last = 1))

@@ -23,7 +23,18 @@
 extern "C" {
 #endif
 
-#define AM_ABI_VERSION 2
+#define AM_ABI_VERSION 3
+
+/* Export marker.  The library is built with -fvisibility=hidden: only what carries AM_API leaves the
+ * shared object (the role AIR_MODES_API plays in the reference: include/gr_air_modes/api.h:27-31,
+ * CMakeLists.txt:65 -- hidden by default, exported by annotation). */
+#if defined(_WIN32)
+#  define AM_API
+#elif defined(__GNUC__) || defined(__clang__)
+#  define AM_API __attribute__((visibility("default")))
+#else
+#  define AM_API
+#endif
 
 /* error codes */
 #define AM_OK          0
@@ -76,7 +87,11 @@ typedef struct am_tag {
 
 typedef struct am_ctx am_ctx;
 
-uint32_t am_abi_version(void);
+AM_API uint32_t am_abi_version(void);
+/* 0 for the product library.  1 only in the test-only CPU build of the same sources (tests/emu), where device pointers are
+ * host pointers: callers that must choose between device-side and host-side message buffers ask this instead of guessing from
+ * the library's file name. */
+AM_API int am_is_emulated(void);
 
 /* ---- context = the rx_path hier block ------------------------------------------------
  * Replaces: rx_path.__init__(rate, threshold, queue, use_pmf, use_dcblock)
@@ -97,16 +112,16 @@ uint32_t am_abi_version(void);
  * reference tree (parity unpinned): the window sums use the canonical order of DESIGN.md section 3.
  * device < 0 selects the current HIP device.  Returns NULL on failure; *err (optional)
  * receives the code. */
-am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock,
+AM_API am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock,
                   int *err);
-void am_destroy(am_ctx *ctx);
+AM_API void am_destroy(am_ctx *ctx);
 
 /* Replaces: preamble::set_rate / set_threshold / get_rate / get_threshold
  *           (include/gr_air_modes/preamble.h:41-44; lib/preamble_impl.cc:56-76) and
  *           rx_path.set_rate / set_threshold / get_threshold / get_pmf (rx_path.py:67-87).
  * am_set_rate also drops the carried stream state (window lengths change). */
-int    am_set_rate(am_ctx *ctx, double rate);
-int    am_set_threshold(am_ctx *ctx, float threshold_db);
+AM_API int    am_set_rate(am_ctx *ctx, double rate);
+AM_API int    am_set_threshold(am_ctx *ctx, float threshold_db);
 /* Replaces: the "rx_time" stream tag a live source (UHD, osmosdr) attaches to the sample stream and
  *           preamble_impl::general_work latches (lib/preamble_impl.cc:165-170); tag_to_timestamp
  *           (lib/preamble_impl.cc:100-137) then stamps each preamble with
@@ -120,10 +135,10 @@ int    am_set_threshold(am_ctx *ctx, float threshold_db);
  * tag is latched as soon as the scheduler's current window contains it, i.e. up to a buffer early
  * (the unsigned difference :124 then wraps for preambles in front of it); that scheduler-dependent
  * early latch is not reproduced.  am_reset and am_set_rate drop the pending tags. */
-int    am_set_rx_time(am_ctx *ctx, uint64_t offset, uint64_t secs, double frac);
-double am_get_rate(const am_ctx *ctx);
-float  am_get_threshold(const am_ctx *ctx);
-int    am_get_pmf(const am_ctx *ctx);
+AM_API int    am_set_rx_time(am_ctx *ctx, uint64_t offset, uint64_t secs, double frac);
+AM_API double am_get_rate(const am_ctx *ctx);
+AM_API float  am_get_threshold(const am_ctx *ctx);
+AM_API int    am_get_pmf(const am_ctx *ctx);
 /* ---- batches in flight ---------------------------------------------------------------------------------------
  * Under GNU Radio every block of rx_path runs in its own thread, so the slicer works on burst k while the preamble
  * block scans ahead (thread-per-block scheduler; python/rx_path.py wires five blocks).  The counterpart here: the
@@ -136,34 +151,34 @@ int    am_get_pmf(const am_ctx *ctx);
  *                AM_ECAPACITY + am_fetch_packets) and resets the stream state.
  * am_pipe_*      `depth` contexts behind one handle, used round-robin by ONE host thread: submit up to `depth`
  *                batches, collect them in submission order.  Results are those of am_process_iq on each batch. */
-int am_submit_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags);
-int am_collect(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
+AM_API int am_submit_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags);
+AM_API int am_collect(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
 typedef struct am_pipe am_pipe;
-am_pipe *am_pipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err);
-void am_pipe_destroy(am_pipe *pipe);
-int am_pipe_depth(const am_pipe *pipe);
-int am_pipe_in_flight(const am_pipe *pipe);
+AM_API am_pipe *am_pipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err);
+AM_API void am_pipe_destroy(am_pipe *pipe);
+AM_API int am_pipe_depth(const am_pipe *pipe);
+AM_API int am_pipe_in_flight(const am_pipe *pipe);
 /* AM_ECAPACITY when `depth` batches are already in flight (collect one first) */
-int am_pipe_submit(am_pipe *pipe, const float *iq, uint64_t n_complex, uint32_t flags);
+AM_API int am_pipe_submit(am_pipe *pipe, const float *iq, uint64_t n_complex, uint32_t flags);
 /* packets of the OLDEST batch in flight; AM_EINVAL when there is none */
-int am_pipe_collect(am_pipe *pipe, am_packet *out, uint64_t cap, uint64_t *n_out);
-const char *am_pipe_last_error(const am_pipe *pipe);
-float am_pipe_last_kernel_ms(const am_pipe *pipe);   /* dominant-kernel time of the batch collected last */
+AM_API int am_pipe_collect(am_pipe *pipe, am_packet *out, uint64_t cap, uint64_t *n_out);
+AM_API const char *am_pipe_last_error(const am_pipe *pipe);
+AM_API float am_pipe_last_kernel_ms(const am_pipe *pipe);   /* dominant-kernel time of the batch collected last */
 
 /* Run the context's device work on the caller's HIP stream (hipStream_t passed as a pointer; NULL: back to the
  * context's own stream).  For callers whose input is produced on a stream of their own -- e.g. halo samples that
  * arrive by an RCCL receive on a PyTorch stream: work enqueued here is then ordered behind it without a host
  * synchronisation.  The stream must outlive the context or be replaced before it is destroyed.  (No counterpart in
  * the reference: GNU Radio blocks have no device streams.) */
-int am_set_stream(am_ctx *ctx, void *hip_stream);
+AM_API int am_set_stream(am_ctx *ctx, void *hip_stream);
 /* Order the context's stream behind everything enqueued so far on another stream of the same device (NULL = the legacy
  * default stream, PyTorch's current stream unless the caller changed it): an event recorded there and waited for here,
  * the host does not block.  For inputs another stream produces -- e.g. boundary samples an RCCL receive is still
  * writing (air_modes/sharded.py). */
-int am_wait_for_stream(am_ctx *ctx, void *hip_stream);
+AM_API int am_wait_for_stream(am_ctx *ctx, void *hip_stream);
 
 /* start a new stream: sample counter, carry-over samples and greedy-scan state are cleared */
-int    am_reset(am_ctx *ctx);
+AM_API int    am_reset(am_ctx *ctx);
 
 /* ---- the fused hot path ---------------------------------------------------------------
  * Replaces, for one chunk of the input stream, everything rx_path wires together
@@ -178,16 +193,16 @@ int    am_reset(am_ctx *ctx);
  * out/cap: caller's packet array (host).  *n_out = packets produced by this call, in
  * stream order.  AM_ECAPACITY if cap is too small (nothing is lost: call
  * am_fetch_packets with a larger array). */
-int am_process_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
+AM_API int am_process_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
                   am_packet *out, uint64_t cap, uint64_t *n_out);
-int am_fetch_packets(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
+AM_API int am_fetch_packets(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
 /* preamble hits (tags) seen by the last am_process_iq call, accepted or not */
-uint64_t am_last_num_tags(const am_ctx *ctx);
+AM_API uint64_t am_last_num_tags(const am_ctx *ctx);
 /* The inter-block stream of the last am_process_iq / am_collect call that ran with AM_F_KEEP_TAGS: one 240-float burst
  * and one tag per preamble hit, in stream order, exactly what gr::air_modes::preamble would have produced for the
  * slicer (lib/preamble_impl.cc:219-232), from the SAME kernels that produced the call's packets.  bursts: cap*240
  * floats; tags: cap entries; either may be NULL to skip it.  AM_ECAPACITY (*n_out = needed) if cap is too small. */
-int am_fetch_tags(am_ctx *ctx, float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out);
+AM_API int am_fetch_tags(am_ctx *ctx, float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out);
 
 /* ---- block-level entry points (for block-by-block parity tests) -------------------------
  * am_frontend_work: the three third-party blocks in front of the preamble detector
@@ -198,12 +213,12 @@ int am_fetch_tags(am_ctx *ctx, float *bursts, am_tag *tags, uint64_t cap, uint64
  *   history of 2*spc-1 zeros is implied).  bursts: cap*240 floats; tags: cap entries.
  * am_slicer_work: gr::air_modes::slicer_impl::work over nbursts tagged bursts.
  *   Only accepted packets are written to out. */
-int am_frontend_work(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
+AM_API int am_frontend_work(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
                      float *bb, float *avg);
-int am_preamble_work(am_ctx *ctx, const float *in, const float *inavg, uint64_t n,
+AM_API int am_preamble_work(am_ctx *ctx, const float *in, const float *inavg, uint64_t n,
                      uint32_t flags, float *bursts, am_tag *tags, uint64_t cap,
                      uint64_t *n_out);
-int am_slicer_work(am_ctx *ctx, const float *bursts, const am_tag *tags, uint64_t nbursts,
+AM_API int am_slicer_work(am_ctx *ctx, const float *bursts, const am_tag *tags, uint64_t nbursts,
                    uint32_t flags, am_packet *out, uint64_t cap, uint64_t *n_out);
 
 /* ---- host-side helpers ------------------------------------------------------------------
@@ -214,8 +229,15 @@ int am_slicer_work(am_ctx *ctx, const float *bursts, const am_tag *tags, uint64_
  *   reference level with 6 significant digits (the first message a slicer instance emits),
  *   otherwise 10 (every later one) -- the member ostringstream keeps setprecision(10).
  *   Returns the length written (excluding NUL) or AM_ECAPACITY. */
-uint32_t am_crc24(const uint8_t *data, int nbytes);
-int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
+AM_API uint32_t am_crc24(const uint8_t *data, int nbytes);
+AM_API int am_format_message(const am_packet *pkt, int first, char *buf, size_t cap);
+/* The same for n packets in one call (a binding posts a batch per call instead of crossing the FFI per packet): text k is
+ * the NUL-terminated string at buf + offsets[k]; offsets has n + 1 entries, offsets[n] = bytes used.  `first` applies to
+ * packet 0 only -- the stream's precision is sticky (slicer_impl.cc:186-194; the ostringstream is a member,
+ * slicer_impl.h:43).  AM_ECAPACITY when cap is too small: *need (optional) then holds the bytes required (at most 80 per
+ * packet) and nothing beyond cap was written. */
+AM_API int am_format_messages(const am_packet *pkts, uint64_t n, int first, char *buf, size_t cap, uint64_t *offsets,
+                              uint64_t *need);
 
 /* ---- time-sharded operation (one context per GPU, one contiguous time chunk each) -------
  * The reference's preamble scan is sequential, but the only state that crosses a chunk
@@ -248,13 +270,13 @@ typedef struct am_shard_exit {
                               scan enters the chunk at this candidate                       */
 } am_shard_exit;
 
-int am_shard_halo(const am_ctx *ctx, uint64_t *left, uint64_t *right);
-int am_shard_scan(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end,
+AM_API int am_shard_halo(const am_ctx *ctx, uint64_t *left, uint64_t *right);
+AM_API int am_shard_scan(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end,
                   uint64_t total_n, uint32_t flags, am_shard_exit *table, uint64_t cap,
                   uint64_t *n_table);
-int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, const uint64_t *starts,
+AM_API int am_shard_entry(const am_shard_exit *const *tables, const uint64_t *counts, const uint64_t *starts,
                    uint32_t nranks, uint64_t *entry);
-int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out);
+AM_API int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap, uint64_t *n_out);
 /* A receiver, not a batch (round 4): the scan position crosses STEPS as it crosses chunks (lib/preamble_impl.cc:213,237,244:
  * consume_each -- the reference's scan resumes where the last general_work left off, for ever).  Step k covers the samples
  * [k W n, (k + 1) W n); rank r owns the POSITIONS [k W n + r n - H, k W n + (r + 1) n - H), H = `right` of am_shard_halo (the
@@ -266,7 +288,7 @@ int am_shard_resolve(am_ctx *ctx, uint64_t cur_in, am_packet *out, uint64_t cap,
  * am_shard_get_exit / am_shard_set_exit: where the scan left THIS context's chunk in its last resolved step -- the word the
  *   host-free step keeps on the device and sends along in the next step's message header (below); a step that ran on the
  *   synchronous path sets it (leave[rank]), a caller that falls back to that path reads it. */
-int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *counts, uint32_t nranks, uint64_t cur_in,
+AM_API int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *counts, uint32_t nranks, uint64_t cur_in,
                     uint64_t *entry, uint64_t *leave);
 /* The samples the NEXT step needs in front of a chunk are this step's last ones, and the caller is about to overwrite them:
  * am_shard_keep_tail registers a device-to-device copy (nbytes from src to dst; 0: none) that every following
@@ -275,10 +297,10 @@ int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *counts, 
  * the critical path of the next step).  dst must not be part of what a repeated step would scan.
  * am_stream_copy: a device-to-device copy on the context's stream, ordered with its scans (e.g. the kept tail into the halo
  * in front of the chunk, before the next am_shard_scan_async). */
-int am_shard_keep_tail(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
-int am_stream_copy(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
-int am_shard_get_exit(am_ctx *ctx, uint64_t *pos);
-int am_shard_set_exit(am_ctx *ctx, uint64_t pos);
+AM_API int am_shard_keep_tail(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
+AM_API int am_stream_copy(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
+AM_API int am_shard_get_exit(am_ctx *ctx, uint64_t *pos);
+AM_API int am_shard_set_exit(am_ctx *ctx, uint64_t pos);
 
 /* The same step without a host round trip in the middle (round 3): the exit table stays on the device.
  * am_shard_scan_async: as am_shard_scan, but everything is only ENQUEUED and the table goes to the device message
@@ -294,13 +316,13 @@ int am_shard_set_exit(am_ctx *ctx, uint64_t pos);
  *   or some rank's scan met more candidates than the capacity it was launched for (both rare, both read from the message
  *   headers: *redo is the same on every rank): no packets were delivered, repeat the step with am_shard_scan /
  *   am_shard_entry / am_shard_resolve. */
-int am_shard_scan_async(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
+AM_API int am_shard_scan_async(am_ctx *ctx, const float *iq, uint64_t abs_start, uint64_t abs_end, uint64_t total_n,
                         uint32_t flags, am_shard_exit *msg_dev, uint64_t msg_cap);
-int am_shard_resolve_async(am_ctx *ctx, const am_shard_exit *msgs_dev, uint32_t world, uint32_t rank, uint64_t msg_cap,
+AM_API int am_shard_resolve_async(am_ctx *ctx, const am_shard_exit *msgs_dev, uint32_t world, uint32_t rank, uint64_t msg_cap,
                            am_packet *out, uint64_t cap, uint64_t *n_out, int *redo);
 /* another stream of the context's device (NULL: the legacy default stream) waits, on the device, for what the context has
  * enqueued so far (the counterpart of am_wait_for_stream) */
-int am_signal_stream(am_ctx *ctx, void *hip_stream);
+AM_API int am_signal_stream(am_ctx *ctx, void *hip_stream);
 
 /* ---- resampling in front of the path (python/radio.py:49-53) ------------------------------------------------
  * modes_radio resamples anything slower than 4 Msps to 4 Msps with pfb.arb_resampler_ccf before rx_path.  GNU Radio's
@@ -312,13 +334,13 @@ int am_signal_stream(am_ctx *ctx, void *hip_stream);
  *   handle's device buffer (am_resampler_device_output, valid until the next call: hand it to am_process_iq with
  *   AM_F_DEVICE_IN).  The read position and the last 8 input samples carry over from call to call. */
 typedef struct am_resampler am_resampler;
-am_resampler *am_resampler_create(int device, double ratio, const double *taps, int *err);
-void am_resampler_destroy(am_resampler *h);
-int am_resampler_reset(am_resampler *h);
-int am_resampler_work(am_resampler *h, const float *iq, uint64_t n_complex, uint32_t flags, float *out, uint64_t cap,
+AM_API am_resampler *am_resampler_create(int device, double ratio, const double *taps, int *err);
+AM_API void am_resampler_destroy(am_resampler *h);
+AM_API int am_resampler_reset(am_resampler *h);
+AM_API int am_resampler_work(am_resampler *h, const float *iq, uint64_t n_complex, uint32_t flags, float *out, uint64_t cap,
                       uint64_t *n_out);
-const float *am_resampler_device_output(const am_resampler *h);
-const char *am_resampler_last_error(const am_resampler *h);
+AM_API const float *am_resampler_device_output(const am_resampler *h);
+AM_API const char *am_resampler_last_error(const am_resampler *h);
 
 /* ---- pinned staging for a host source (apps/modes_rx's file source, python/radio.py:221-234) --------------------
  * nslots pinned host buffers of capacity_complex samples each, with a device twin and a copy stream: the reader fills
@@ -327,37 +349,37 @@ const char *am_resampler_last_error(const am_resampler *h);
  * AM_F_DEVICE_IN) -- the transfer of chunk k+1 overlaps the scan of chunk k.  start and wait may be called from
  * different threads (one producer, one consumer); a slot is reused only after its consumer is done with it. */
 typedef struct am_uploader am_uploader;
-am_uploader *am_uploader_create(int device, uint64_t capacity_complex, int nslots, int *err);
-void am_uploader_destroy(am_uploader *u);
-float *am_uploader_host(am_uploader *u, int slot);
-int am_uploader_start(am_uploader *u, int slot, uint64_t n_complex);
-const float *am_uploader_wait(am_uploader *u, int slot);
+AM_API am_uploader *am_uploader_create(int device, uint64_t capacity_complex, int nslots, int *err);
+AM_API void am_uploader_destroy(am_uploader *u);
+AM_API float *am_uploader_host(am_uploader *u, int slot);
+AM_API int am_uploader_start(am_uploader *u, int slot, uint64_t n_complex);
+AM_API const float *am_uploader_wait(am_uploader *u, int slot);
 
 /* last error text of the context (or of am_create when ctx == NULL) */
-const char *am_last_error(const am_ctx *ctx);
+AM_API const char *am_last_error(const am_ctx *ctx);
 
 /* timing of the last am_process_iq / am_shard_scan call, measured with HIP events on the
  * context's own stream: device milliseconds for the whole call and for the dominant
  * (front-end + detection) kernel.  Used by bench.py for the roofline line.  Either pointer may be
  * NULL; asking for total_ms may wait a few microseconds for the call's last event (it is queued
  * behind the completion signal the call itself waits for), dominant_kernel_ms never waits. */
-int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
+AM_API int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
 
 /* Diagnostic: number of first-stage preamble candidates (positions passing preamble_impl.cc:172-179)
  * the last scan refined and chained.  Negative error code on a null context. */
-long long am_last_num_candidates(const am_ctx *ctx);
+AM_API long long am_last_num_candidates(const am_ctx *ctx);
 
 /* Diagnostic: which front-end kernel the last scan ran -- 3 = a streaming kernel (am_k_fe3 at 64 Msps, am_k_fe4 at 2, 4, 8,
  * 10, 16, 20, 32 and 40 Msps: persistent workgroups, LDS rings, sparse bb around candidates), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan
  * yet.  Results do not depend on it (test builds can keep the tile kernel; tests compare both). */
-int am_last_frontend(const am_ctx *ctx);
+AM_API int am_last_frontend(const am_ctx *ctx);
 
 /* Diagnostic (stage-level parity tests): the refined record of EVERY first-stage candidate of the last scan, in
  * position order -- absolute stream index of the position the first-stage test fired at (preamble_impl.cc:172-179), of
  * the position after the late-peak search (:182-192), the outcome of the quiet-zone test there (:198-209) and, for a
  * candidate, the reference level at that position (what :220 subtracts).  Any pointer may be NULL.  AM_ECAPACITY
  * (*n_out = needed) if cap is too small. */
-int am_fetch_candidates(am_ctx *ctx, uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg, uint64_t cap,
+AM_API int am_fetch_candidates(am_ctx *ctx, uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg, uint64_t cap,
                         uint64_t *n_out);
 
 #ifdef __cplusplus

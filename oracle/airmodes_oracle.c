@@ -289,7 +289,12 @@ static void geom_of(uint64_t rate_i, amo_geom *g)
     g->zb0 = (int)(5 * sps);                                     /* float product, truncated                       */
     g->zb1 = (int)floor(7.5 * sps);                              /* largest j with (double)j <= 7.5 * sps           */
     g->Bf = 240 * spcf;
-    g->B = (int)g->Bf;
+    /* :237 consume_each(i + 240 * d_samples_per_chip): int + float, rounded to float, truncated -- i counts from the start
+     * of the current general_work() window.  Where 240 * spcf is a whole number (every multiple of 2 MHz; 5, 6.25, 4.8, 3,
+     * 13 Msps ...) the skip is that number for every i.  Where it is not (2.1 Msps: 251.99998) the float sum rounds to
+     * i + 252 for every i >= 4 and to i + 251 below: the skip is taken at a representative window offset (i = 1024), i.e.
+     * what the reference does for all but the first few items of a window (canonical choice). */
+    g->B = (int)((float)1024 + g->Bf) - 1024;
     for (int j = 0; j < BURST_CHIPS; j++) g->idx[j] = (int)(j * spcf);
 }
 

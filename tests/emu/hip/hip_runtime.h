@@ -8,6 +8,7 @@
 // thread: __syncthreads() and the wave collectives (__ballot, __shfl*) yield until the
 // whole workgroup / 64-lane wave has arrived.  Device memory is host memory.
 #pragma once
+#define AM_HIP_EMULATION 1   /* am_is_emulated() reports it */
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>

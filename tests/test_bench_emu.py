@@ -59,3 +59,18 @@ def test_force_sharded_one_rank_line(emu_lib):
     """--force-sharded: one rank through the streaming time-shard receiver; the line carries the dominant kernel's time."""
     d = run_bench("--force-sharded", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline")
     assert d["n_gpus"] == 1 and d["parity"] is True and d["roofline"]["frac"] > 0
+
+
+def test_replicas_eight_receivers(emu_lib):
+    """BASELINE.json configs[4]: eight independent 20 Msps receivers, no collective on the data path; the line proves eight ranks."""
+    d = run_bench("--gpus", "8", "--replicas", "--seconds", "0.004", "--no-cpu-baseline")
+    assert d["n_gpus"] == 8 and d["parity"] is True and "8 independent receivers" in d["config"]["parallelism"]
+    assert d["ranks"]["ranks_seen"] == 8 and sorted(r["rank"] for r in d["ranks"]["per_rank"]) == list(range(8))
+    assert d["ranks"]["collectives"]["backend"] == "gloo" and d["ranks"]["collectives"]["world_size"] == 8
+
+
+def test_gpus_2_line_names_its_ranks_and_times_the_collectives(emu_lib):
+    d = run_bench("--gpus", "2", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline", "--no-parity")
+    assert d["ranks"]["ranks_seen"] == 2 and len(d["ranks"]["per_rank"]) == 2
+    h = d["host_dist_us_per_step"]
+    assert h["steps_counted"] >= 2 and h["exit_table_all_gather_into_tensor"] > 0 and h["tail_exchange_batch_isend_irecv"] > 0

@@ -26,7 +26,14 @@ def test_library_builds_loads_and_exports_all_symbols():
     for s in syms:
         assert hasattr(lib, s), "libairmodes_hip.so does not export %s" % s
     lib.am_abi_version.restype = ctypes.c_uint32
-    assert lib.am_abi_version() == 2
+    assert lib.am_abi_version() == 3
+    assert lib.am_is_emulated() == 0
+    # -fvisibility=hidden + AM_API: the shared object defines the header's entry points and NOTHING else (the reference
+    # hides what is not AIR_MODES_API: CMakeLists.txt:65, include/gr_air_modes/api.h:27-31)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", conftest.HIP_LIB], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-2] in "TWVDBRi")
+    exported = [e for e in exported if not e.startswith(("_init", "_fini", "__hip_", "_edata", "_end", "__bss_start"))]
+    assert exported == syms, (sorted(set(exported) - set(syms)), sorted(set(syms) - set(exported)))
     # host-only helpers are callable without a GPU
     lib.am_crc24.restype = ctypes.c_uint32
     b = bytes.fromhex("8D4840D6202CC371C32CE0")
@@ -156,3 +163,27 @@ def test_timing_accessors(emu_lib):
     total, dom = ctx.last_timing()
     assert total >= 0.0 and dom >= 0.0
     ctx.close()
+
+
+def test_format_messages_batch_equals_one_by_one():
+    """am_format_messages: a batch per call (lib/slicer_impl.cc:186-194: the precision quirk belongs to the stream's first message)."""
+    from air_modes import _capi
+    lib = _capi.Library(conftest.HIP_LIB)
+    rng = np.random.default_rng(5)
+    pk = np.zeros(300, _capi.PACKET_DTYPE)
+    pk["data"] = rng.integers(0, 256, (300, 14), dtype=np.uint8)
+    pk["nbytes"] = np.where(rng.random(300) < 0.5, 7, 14)
+    pk["crc"] = rng.integers(0, 1 << 24, 300)
+    pk["ref"] = rng.random(300).astype(np.float32) * np.float32(3.0)
+    pk["secs"] = rng.integers(0, 1 << 40, 300)
+    pk["frac"] = rng.random(300)
+    for first in (True, False):
+        one = [lib.format_message(pk[i], first and i == 0) for i in range(len(pk))]
+        assert lib.format_messages(pk, first) == one
+    assert lib.format_messages(pk[:0], True) == []
+    # capacity: nothing beyond cap is written, the bytes needed come back
+    buf = ctypes.create_string_buffer(64)
+    offs = np.zeros(4, np.uint64)
+    need = ctypes.c_uint64(0)
+    rc = lib.L.am_format_messages(pk.ctypes.data, 3, 1, ctypes.addressof(buf), 40, offs.ctypes.data, ctypes.byref(need))
+    assert rc == -5 and need.value == sum(len(t) + 1 for t in lib.format_messages(pk[:3], True)) and buf.raw[40:] == b"\0" * 24

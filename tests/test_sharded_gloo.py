@@ -45,7 +45,7 @@ def _worker(rank, world, port, ret, small_table=512, host_free=True):
 
 
 @pytest.mark.parametrize("world,small_table,host_free", [(2, 512, True), (3, 512, True), (4, 512, True), (2, 1, True),
-                                                         (2, 512, False), (2, 1, False)])
+                                                         (2, 512, False), (2, 1, False), (8, 512, True)])
 def test_time_sharded_matches_single_stream(emu_lib, oracle_mod, world, small_table, host_free):
     """host_free: the exit tables are exchanged and composed on the device side, one completion wait per step (three steps:
     none of them may fall back to the synchronous path).  small_table=1: the table does not fit the short message -- the
@@ -153,7 +153,8 @@ def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_r
 
 @pytest.mark.parametrize("world,small_table,host_free,rate,dcblock", [(2, 512, True, 20e6, False), (3, 512, True, 20e6, False),
                                                                       (2, 1, True, 20e6, False), (2, 512, False, 20e6, False),
-                                                                      (3, 512, True, 4e6, True)])
+                                                                      (3, 512, True, 4e6, True), (8, 512, True, 4e6, False),
+                                                                      (8, 1, True, 4e6, False)])
 def test_time_sharded_receiver_is_a_stream(emu_lib, oracle_mod, world, small_table, host_free, rate, dcblock):
     """VERDICT r3 missing #1: the scan position, the undecided tail and the sample count cross STEPS (lib/preamble_impl.cc:
     213,237,244).  Three consecutive steps over a 3 * world * n capture: the packets of all (step, rank) pairs in order ==
