@@ -97,6 +97,9 @@ struct am_ctx {
     bool keep_tags = false;       // AM_F_KEEP_TAGS of the call in progress: bursts + tags of its hits stay for am_fetch_tags
     uint64_t rec_base = 0;        // absolute index of array coordinate 0 of the resident records (am_fetch_candidates)
     bool poison = false;          // (test builds: AIRMODES_POISON=1) NaN-fill the sparse bb / reference-level arrays before every scan
+    bool rows_in_gather = true;      // 64 Msps: bb rows around candidates from IQ in am_k_gather_wg (test builds: AIRMODES_ROWS_FE=1 keeps the front end's)
+    bool rows_from_iq = false;       // ... in force for the scan in flight
+    am_rows_args rows = {};
     bool allow_stream = true;        // (test builds: AIRMODES_FE=2) keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
     // extraction recomputes from these samples (they must stay valid until the scan's hits are sliced)
@@ -461,7 +464,8 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             // streaming front end: candidates arrive as a bitmap; flat positions, then late-peak decisions, quiet zones,
             // records and the chain's successors in one launch (am_k_refine_late)
             HIPCHK(c, am_launch_gather_wg((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, c->fe_nwg, c->fe_wpw, c->fe_nwords, M,
-                                          c->fe_lag, c->fe_wbits, (uint32_t *)c->pos.p, (uint32_t *)c->blk_off.p, c->stream));
+                                          c->fe_lag, c->fe_wbits, (uint32_t *)c->pos.p, (uint32_t *)c->blk_off.p, c->stream,
+                                          c->rows_from_iq ? &c->rows : nullptr));
             ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
             HIPCHK(c, am_launch_refine_late(bb, avg, (uint32_t *)c->pos.p, M, c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p,
                                             (uint32_t *)c->tgt.p, (float *)c->inavg.p, (uint8_t *)c->valid.p,
@@ -555,7 +559,15 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
             HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
             HIPCHK(c, hipMemsetAsync(c->avg.p, 0xFF, out_n * sizeof(float), c->stream));
         }
-        HIPCHK(c, am_launch_fe4(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n, bb,
+        // 64 Msps (a bitmap word = one 32-sample chip, lag 288): the bb rows around candidates are formed from the samples by
+        // am_k_gather_wg, not written by the front end (54 MB of stores per 64 M samples that the dominant kernel does not make)
+        c->rows_from_iq = c->rows_in_gather && am_fe4_unit(c->spc) == 32 && am_fe4_lag(c->spc) == 288;
+        c->rows.iq = c->rows_from_iq ? src : nullptr;
+        c->rows.src_abs0 = (long long)src_abs0; c->rows.src_abs1 = (long long)src_abs1; c->rows.out_abs0 = (long long)out_abs0;
+        c->rows.out_n = (long long)out_n; c->rows.bb_sparse = bb; c->rows.use_pmf = c->use_pmf;
+        c->rows.s1 = (float)(1.0 / (double)c->spc);
+        HIPCHK(c, am_launch_fe4(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n,
+                                c->rows_from_iq ? nullptr : bb,
                                 (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
                                 (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream, c->fe_wgs_per_cu));
@@ -867,6 +879,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->force_generic = g && g[0] == '1';
             const char *fe = getenv("AIRMODES_FE");
             c->allow_stream = !(fe && fe[0] == '2');
+            const char *rf = getenv("AIRMODES_ROWS_FE");
+            c->rows_in_gather = !(rf && rf[0] == '1');
             const char *po = getenv("AIRMODES_POISON");
             c->poison = po && po[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");

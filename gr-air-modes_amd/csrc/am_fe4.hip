@@ -706,7 +706,7 @@ __device__ __forceinline__ void fe4_step(const am_fe4_args &a, const fe4_smem<SP
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (!(FE4_ABLATE & 32)) {
+    if (!(FE4_ABLATE & 32) && a.bb_sparse != nullptr) {                // (uniform; null: am_k_gather_wg forms the rows from the samples)
         // bb: the units from a candidate's on that hold the 17 chips from its chip on, copied from the ring
         unsigned long long need = cand;
 #pragma unroll

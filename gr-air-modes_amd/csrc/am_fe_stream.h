@@ -134,6 +134,19 @@ __device__ __forceinline__ float4 fes_gload16_at(unsigned long long base, unsign
 #endif
 }
 
+// the same with the default cache policy (samples that another kernel reads again soon: am_k_gather_wg's rows)
+__device__ __forceinline__ float4 fes_gload16_cached_at(unsigned long long base, unsigned off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const fes_f4 __attribute__((address_space(1))) *gp;
+    const fes_f4 t = *reinterpret_cast<gp>(base + (unsigned long long)off);
+    float4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    return r;
+#else
+    return *reinterpret_cast<const float4 *>(base + (unsigned long long)off);
+#endif
+}
+
 static inline long long fes_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
 static inline long long fes_ceil_div(long long x, long long d) { return -fes_floor_div(-x, d); }
 

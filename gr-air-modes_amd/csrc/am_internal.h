@@ -91,9 +91,20 @@ hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long
 /* flat candidate positions from the bitmap, one workgroup per front-end workgroup: workgroup g owns the words
  * [g * words_per_wg, (g + 1) * words_per_wg) (nwords in all) and starts its part of pos[] at the sum of wg_cnt[0 .. g)
  * -- no scan launch, no chain.  Entries at or beyond Mcap are dropped; *total_out = the number of candidates. */
+/* rows != null && rows->iq (64 Msps: am_k_fe3 no longer writes them): the same launch also forms, from the samples, the bb rows
+ * the refinement reads -- the 17 chips from every candidate's chip on, canonical order (am_rows_segment32). */
+struct am_rows_args {
+    const float *iq;                      /* null: no rows (the front end wrote them: am_k_fe4 rates)        */
+    long long src_abs0, src_abs1;         /* absolute range of samples present in iq                        */
+    long long out_abs0;                   /* absolute index of array coordinate 0                           */
+    long long out_n;                      /* array coordinates with data (nothing is stored at or beyond)   */
+    float *bb_sparse;
+    int use_pmf;
+    float s1;
+};
 hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uint32_t nwg, uint32_t words_per_wg,
                                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *pos,
-                               uint32_t *total_out, hipStream_t s);
+                               uint32_t *total_out, hipStream_t s, const am_rows_args *rows = nullptr);
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,

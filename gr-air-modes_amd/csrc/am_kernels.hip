@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "am_internal.h"
+#include "am_fe_stream.h"
 
 // keeps a loaded value where it is in the program (the compiler otherwise sinks loads to their first use, behind branches)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -483,10 +484,257 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 // A thread takes four consecutive words per round (one 16-byte load); the round's counts are scanned in the workgroup.
 // Entries at or beyond Mcap (a capacity launch that was too small: the scan is redone) are dropped; *total_out = the
 // number of candidates there are.
-__global__ void __launch_bounds__(256)
+// ---- bb rows around candidates, rebuilt from IQ (round 5; 64 Msps) ------------------------------------------------------------
+// Until round 4 am_k_fe3 wrote the pulse-matched power bb of the 17 chips from every candidate's chip on: 54 MB of stores per
+// 64 M-sample launch at the bench density, 15 us of a kernel that moves bytes at the rate the part can move them.
+// Those rows are formed HERE instead, by the workgroup that lists the segment's candidates anyway: it knows which chips the
+// refinement will read (a candidate in bitmap word w -> chips w - 9 .. w + 7 of the array: bit b of word w is position
+// 32 w + b - 288), loads exactly their samples (and the chip before each run: the filter's window reaches back one chip) and
+// repeats phase A of am_k_fe3 in the canonical order: in-chip suffix sums of the chip before right->left, prefix
+// sums of the own chip left->right, bb[n] = fl((suf + pre) s1); the chip's last sample: pre alone.  Same bits as the front
+// end's ring rows (stage-level device tests compare every candidate record with the arrays NaN-poisoned).
+// Machine mapping: every WAVE works on its own stripes of 32 chips, no workgroup barrier: 16 lanes load one chip's 256 bytes
+// (coalesced), |.|^2 goes to the wave's 33 LDS rows (stride 36 floats: 16-byte reads of consecutive rows hit all banks), lane t
+// forms chip t's row in registers from rows t and t + 1, writes it back in place, and the wave copies the flagged rows out eight
+// per store instruction (8 lanes x 16 bytes = one 128-byte line each).  A stripe without a flagged chip costs one LDS read.
+#define AM_ROWS_STRIPE 32                 /* chips per stripe = rows a wave forms at a time */
+#define AM_ROWS_XS 36                     /* floats per LDS row: 32 + 4 pad */
+#define AM_ROWS_BBW 17                    /* chips of bb the refinement reads from a candidate's chip on */
+#define AM_ROWS_MAXW 2048                 /* bitmap words per front-end workgroup this kernel can flag (am_k_fe3: 14 x 96) */
+
+// 32 bits of a bit array held in 64-bit words, from bit `off` on
+__device__ __forceinline__ uint32_t am_bits32(const unsigned long long *a, uint32_t off)
+{
+    const uint32_t j = off >> 6, sh = off & 63u;
+    unsigned long long v = a[j] >> sh;
+    if (sh > 32u) v |= a[j + 1u] << (64u - sh);
+    return (uint32_t)v;
+}
+
+// rows of the chips [w_begin - 9, w_end - 9) that some candidate in the words [w_begin - 16, w_end) asks for.  All threads of the
+// workgroup call it (two barriers in front of the flags, none after).  NZ / FL: (AM_ROWS_MAXW + 16) / 64 + 2 words each; XR: 33
+// rows per wave; TB: 3 x 40 bytes per wave.
+template <bool PMF>
+__device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const uint32_t *__restrict__ bits, uint32_t w_begin,
+                                                  uint32_t w_end, unsigned long long *NZ, unsigned long long *FL, float *XR_all,
+                                                  unsigned char *TB_all)
+{
+    constexpr int SPC = 32;
+    const int tid = threadIdx.x, nwv = blockDim.x / AM_WAVE;
+    int lane = tid & (AM_WAVE - 1);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / AM_WAVE);     // (wave-uniform, and known to be: scalar arithmetic, uniform branches)
+    const uint32_t nw = w_end - w_begin;                              // <= AM_ROWS_MAXW
+    const uint32_t nidx = nw + 16u;                                   // index i <-> word w_begin - 16 + i
+    const uint32_t n64 = (nidx + 63u) >> 6;
+    // which words hold a candidate (one bit per word; a wave's ballot is 64 of them)
+    for (uint32_t i0 = (uint32_t)wv * AM_WAVE; i0 < n64 * 64u; i0 += (uint32_t)nwv * AM_WAVE) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const long long w = (long long)w_begin - 16 + (long long)i;
+        const bool nz = i < nidx && w >= 0 && bits[w >= 0 ? w : 0] != 0u;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) NZ[i0 >> 6] = m;
+    }
+    __syncthreads();
+    // a word with a candidate flags its chip and the 16 after it: dilation by 16 bits across the 64-bit words
+    for (uint32_t j = (uint32_t)tid; j < n64 + 1u; j += blockDim.x) {
+        unsigned long long f = 0ull;
+        if (j < n64) {
+            const unsigned long long x = NZ[j];
+            unsigned long long d = x | (x << 1);
+            d |= d << 2; d |= d << 4; d |= d << 8;                    // shifts 0 .. 15
+            f = d | (x << 16);
+            const uint32_t hp = j ? (uint32_t)(NZ[j - 1u] >> 48) : 0u;      // the previous word's last 16 words reach into this one
+            if (hp) f |= (2ull << (31 - __clz((int)hp))) - 1ull;
+        }
+        FL[j] = f;
+    }
+    __syncthreads();
+    float *const XR = XR_all + wv * ((AM_ROWS_STRIPE + 1) * AM_ROWS_XS);
+    unsigned char *const TB = TB_all + wv * (3 * 40);                 // [0], [1]: rows whose |.|^2 a stripe needs (by parity); [2]: rows wanted
+    const bool wide = (reinterpret_cast<uintptr_t>(ra.iq) & 15u) == 0 && (((ra.out_abs0 - ra.src_abs0) & 1) == 0);   // (uniform)
+    const float2 *iq2 = reinterpret_cast<const float2 *>(ra.iq);
+    const uint32_t nstripes = (nw + AM_ROWS_STRIPE - 1u) / AM_ROWS_STRIPE;
+    constexpr int MAXR = (AM_ROWS_STRIPE + 1) * 16 / AM_WAVE + 1;     // rounds of 64 pieces that cover 33 rows: 9
+    // a wave's stripes that hold a wanted chip, one after the other; the loads of the next one are in flight while the
+    // current one is worked on (one memory round trip per stripe in the open was 54 us of this kernel at the bench density)
+    auto wanted = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
+        uint32_t fm = am_bits32(FL, 16u + st * AM_ROWS_STRIPE);       // bit t: chip t of the stripe is wanted
+        const uint32_t left = nw - st * AM_ROWS_STRIPE;               // chips of the segment from the stripe's first on
+        if (left < 32u) fm &= (1u << left) - 1u;
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)fm);     // (every lane read the same words)
+    };
+    auto next_stripe = [&](uint32_t st, uint32_t &fm) __attribute__((always_inline)) -> uint32_t {
+        fm = 0u;
+        for (; st < nstripes; st += (uint32_t)nwv) {
+            fm = wanted(st);
+            if (fm) break;
+        }
+        return st;
+    };
+    // rows whose |.|^2 a stripe needs: row r <-> chip chip0 - 1 + r; a wanted chip t needs its own row t + 1 and (filter on) row t
+    auto rows_needed = [&](uint32_t fm) __attribute__((always_inline)) -> unsigned long long {
+        return PMF ? ((unsigned long long)fm | ((unsigned long long)fm << 1)) : ((unsigned long long)fm << 1);
+    };
+    float4 v[MAXR];
+    // is every sample a stripe can ask for inside the source, at 16-byte aligned addresses?  (uniform; all but the stripes at the
+    // two ends of the stream and unaligned sources)
+    auto inside_of = [&](uint32_t st) __attribute__((always_inline)) -> bool {
+        const long long A0 = ra.out_abs0 + ((long long)w_begin + (long long)st * AM_ROWS_STRIPE - 9) * SPC;
+        return wide && A0 - SPC >= ra.src_abs0 && A0 + (long long)AM_ROWS_STRIPE * SPC <= ra.src_abs1;
+    };
+    // the loads of stripe st (wave-uniform st, fm; inside_of(st)) into v; tb: this stripe's list of needed rows.  Scalar base
+    // (the first sample of the chip before the stripe) + the lane's 32-bit byte offset: no 64-bit vector arithmetic
+    auto issue = [&](uint32_t st, uint32_t fm, unsigned char *tb) __attribute__((always_inline)) {
+        const long long A0 = ra.out_abs0 + ((long long)w_begin + (long long)st * AM_ROWS_STRIPE - 9) * SPC;
+        const unsigned long long mneed = rows_needed(fm);
+        const int np = __popcll(mneed) * 16;
+        if (lane <= AM_ROWS_STRIPE && ((mneed >> lane) & 1ull)) tb[__popcll(mneed & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+        __builtin_amdgcn_wave_barrier();
+        if (!inside_of(st)) return;                                   // (the stripe is staged one sample at a time when its turn comes)
+        unsigned long long gb = reinterpret_cast<unsigned long long>(iq2 + (A0 - SPC - ra.src_abs0));
+        gb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb >> 32)) << 32) |
+             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb);   // (wave-uniform: the base stays in scalar registers)
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int p = lane + AM_WAVE * r;
+            const int pc = p < np ? p : 0;                            // (a lane without a piece loads piece 0 again: no branch around the load)
+            const unsigned off = (unsigned)tb[pc >> 4] * (unsigned)(SPC * 8) + (unsigned)(pc & 15) * 16u;
+            v[r] = fes_gload16_cached_at(gb, off);
+        }
+    };
+    uint32_t fm = 0u;
+    uint32_t st = next_stripe((uint32_t)wv, fm);
+    if (st >= nstripes) return;                                       // (wave-uniform)
+    int par = 0;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) { v[r].x = 0.0f; v[r].y = 0.0f; v[r].z = 0.0f; v[r].w = 0.0f; }
+    issue(st, fm, TB);
+    for (;;) {                                                        // (wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(lane));                                // (nothing derived from the lane index is to live across iterations: registers)
+#endif
+        const long long chip0 = (long long)w_begin + (long long)st * AM_ROWS_STRIPE - 9;   // array chip of the stripe's first chip
+        const long long A0 = ra.out_abs0 + chip0 * SPC;
+        {
+            // |.|^2 of the needed rows into the wave's LDS rows
+            const unsigned char *tb = TB + par * 40;
+            const int np = __popcll(rows_needed(fm)) * 16;
+            if (inside_of(st)) {
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    const int p = lane + AM_WAVE * r;
+                    if (p < np) {
+                        const int row = (int)tb[p >> 4], k = p & 15;
+                        const float r0 = v[r].x * v[r].x, i0 = v[r].y * v[r].y, r1 = v[r].z * v[r].z, i1 = v[r].w * v[r].w;
+                        float2 mm;
+                        mm.x = r0 + i0;                               // a1: fl(fl(I*I) + fl(Q*Q))
+                        mm.y = r1 + i1;
+                        *reinterpret_cast<float2 *>(XR + row * AM_ROWS_XS + 2 * k) = mm;
+                    }
+                }
+            } else {
+                // stream edges / unaligned input: one sample at a time, zeros outside the stream (rare: kept small)
+#pragma unroll 1
+                for (int p = lane; p < np; p += AM_WAVE) {
+                    const int row = (int)tb[p >> 4], k = p & 15;
+                    const long long a = A0 + (long long)(row - 1) * SPC + 2 * k;      // absolute index of the piece's first sample
+                    float2 u0, u1;
+                    u0.x = 0.0f; u0.y = 0.0f; u1 = u0;
+                    if (a >= ra.src_abs0 && a < ra.src_abs1) u0 = iq2[a - ra.src_abs0];
+                    if (a + 1 >= ra.src_abs0 && a + 1 < ra.src_abs1) u1 = iq2[a + 1 - ra.src_abs0];
+                    const float r0 = u0.x * u0.x, i0 = u0.y * u0.y, r1 = u1.x * u1.x, i1 = u1.y * u1.y;
+                    float2 mm;
+                    mm.x = r0 + i0;
+                    mm.y = r1 + i1;
+                    *reinterpret_cast<float2 *>(XR + row * AM_ROWS_XS + 2 * k) = mm;
+                }
+            }
+        }
+        // the next stripe's loads go out now: they fly while this one's rows are formed and stored
+        uint32_t fm_next = 0u;
+        const uint32_t st_next = next_stripe(st + (uint32_t)nwv, fm_next);
+        if (st_next < nstripes) issue(st_next, fm_next, TB + (par ^ 1) * 40);
+        __builtin_amdgcn_wave_barrier();
+        // the row of chip t, canonical order, by TWO lanes: lane t forms the prefix sums of the own chip (row t + 1, left->right),
+        // lane t + 32 the suffix sums of the chip before (row t, right->left: it takes the row reversed, so both run the same
+        // chain), and lane t fetches what it needs across the wave: bb[i] = fl((suf[i + 1] + pre[i]) s1)
+        const int t = lane & (AM_ROWS_STRIPE - 1), half = lane >> 5;
+        const bool mine = ((fm >> t) & 1u) != 0u;
+        if (PMF) {
+            float c[SPC];
+            if (mine) {
+                const float4 *row = reinterpret_cast<const float4 *>(XR + (t + 1 - half) * AM_ROWS_XS);
+#pragma unroll
+                for (int k = 0; k < SPC / 4; ++k) {
+                    const float4 u = row[half ? SPC / 4 - 1 - k : k];
+                    c[4 * k] = half ? u.w : u.x; c[4 * k + 1] = half ? u.z : u.y; c[4 * k + 2] = half ? u.y : u.z; c[4 * k + 3] = half ? u.x : u.w;
+                }
+                float ap = 0.0f;
+#pragma unroll
+                for (int i = 0; i < SPC; ++i) { ap = ap + c[i]; c[i] = ap; }       // lane t: pre[i]; lane t + 32: suf[31 - i]
+            } else {
+#pragma unroll
+                for (int i = 0; i < SPC; ++i) c[i] = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();                          // (every lane has read its row)
+            // positions beyond the end of the stream read as zero (the preamble view pads with zeros)
+            const long long leftn = ra.src_abs1 - (A0 + (long long)t * SPC);
+            const int nin = leftn >= SPC ? SPC : (leftn <= 0 ? 0 : (int)leftn);
+            float4 *own = reinterpret_cast<float4 *>(XR + (t + 1) * AM_ROWS_XS);
+#pragma unroll
+            for (int k = 0; k < SPC / 4; ++k) {
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * k + j;
+                    float tt = c[i];                                  // the chip's last sample: the window is the chip
+                    if (i < SPC - 1) tt = __shfl(c[(i < SPC - 1) ? SPC - 2 - i : 0], lane ^ 32, AM_WAVE) + c[i];   // suf[i + 1] + pre[i]
+                    o4[j] = (i >= nin) ? 0.0f : tt * ra.s1;
+                }
+                if (mine && half == 0) { float4 o; o.x = o4[0]; o.y = o4[1]; o.z = o4[2]; o.w = o4[3]; own[k] = o; }
+            }
+        } else {
+            // no filter: bb is |.|^2 itself; only the end of the stream needs a hand
+            __builtin_amdgcn_wave_barrier();
+            const long long leftn = ra.src_abs1 - (A0 + (long long)t * SPC);
+            if (mine && half == 0 && leftn < SPC) {
+                const int nin = leftn <= 0 ? 0 : (int)leftn;
+                float *own = XR + (t + 1) * AM_ROWS_XS;
+                for (int i = nin; i < SPC; ++i) own[i] = 0.0f;
+            }
+        }
+        // the wanted rows leave eight per store instruction
+        unsigned char *const tf = TB + 2 * 40;
+        const int nf = __popc(fm);
+        if (mine && half == 0) tf[__popc(fm & ((1u << t) - 1u))] = (unsigned char)t;
+        __builtin_amdgcn_wave_barrier();
+        const int sub = lane >> 3, piece = lane & 7;
+        for (int r0 = 0; r0 < nf; r0 += 8) {                          // (uniform trip count)
+            const int r = r0 + sub;
+            if (r < nf) {
+                const int t = (int)tf[r];
+                const float4 u = *reinterpret_cast<const float4 *>(XR + (t + 1) * AM_ROWS_XS + 4 * piece);
+                const long long rel = (chip0 + t) * SPC + 4 * piece;  // array coordinate
+                if (rel >= 0 && rel + 4 <= ra.out_n) *reinterpret_cast<float4 *>(ra.bb_sparse + rel) = u;
+                else {
+                    if (rel >= 0 && rel < ra.out_n) ra.bb_sparse[rel] = u.x;
+                    if (rel + 1 >= 0 && rel + 1 < ra.out_n) ra.bb_sparse[rel + 1] = u.y;
+                    if (rel + 2 >= 0 && rel + 2 < ra.out_n) ra.bb_sparse[rel + 2] = u.z;
+                    if (rel + 3 >= 0 && rel + 3 < ra.out_n) ra.bb_sparse[rel + 3] = u.w;
+                }
+            }
+        }
+        if (st_next >= nstripes) break;
+        __builtin_amdgcn_wave_barrier();                              // (the rows and the list of wanted rows are rewritten)
+        st = st_next; fm = fm_next; par ^= 1;
+    }
+}
+
+template <int ROWS>       // 0: candidates only; 1 / 2: + the bb rows around them from IQ at 32 samples per chip (filter on / off)
+__global__ void __launch_bounds__(256, (ROWS ? 5 : 8))       // (with rows: five waves per SIMD, <= 102 VGPRs; left alone the compiler took 162)
 am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wg_cnt, uint32_t nwg, uint32_t words_per_wg,
                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *__restrict__ pos,
-               uint32_t *__restrict__ total_out)
+               uint32_t *__restrict__ total_out, am_rows_args ra)
 {
     __shared__ uint32_t ws[256 / AM_WAVE];
     __shared__ uint32_t red[256 / AM_WAVE];
@@ -564,16 +812,40 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
         }
     }
     if (g == nwg - 1u && threadIdx.x == 0) *total_out = run;
+    if constexpr (ROWS != 0) {
+        __shared__ unsigned long long NZ[(AM_ROWS_MAXW + 16) / 64 + 2];
+        __shared__ unsigned long long FL[(AM_ROWS_MAXW + 16) / 64 + 2];
+        __shared__ __attribute__((aligned(16))) float XR[(256 / AM_WAVE) * (AM_ROWS_STRIPE + 1) * AM_ROWS_XS];
+        __shared__ unsigned char TB[(256 / AM_WAVE) * 3 * 40];
+        for (uint32_t wa = w_begin; wa < w_end; wa += AM_ROWS_MAXW) {   // (one pass at am_k_fe3's 14 x 96 words per workgroup)
+            if (wa != w_begin) __syncthreads();                       // (the flags of the pass before are still being read)
+            am_rows_segment32<ROWS == 1>(ra, bits, wa, (wa + AM_ROWS_MAXW < w_end) ? wa + AM_ROWS_MAXW : w_end, NZ, FL, XR, TB);
+        }
+    }
 }
 
 hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uint32_t nwg, uint32_t words_per_wg,
                                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *pos,
-                               uint32_t *total_out, hipStream_t s)
+                               uint32_t *total_out, hipStream_t s, const am_rows_args *rows)
 {
     if (nwg == 0) return hipSuccess;
     if (wbits == 0 || wbits > 32 || words_per_wg == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(am_k_gather_wg, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag, wbits, pos,
-                       total_out);
+    am_rows_args ra;
+    memset(&ra, 0, sizeof(ra));
+    if (rows && rows->iq) {
+        // (the rows are formed for am_k_fe3's bitmap: a word = one 32-sample chip, lag 288)
+        if (wbits != 32 || lag != 288 || !rows->bb_sparse) return hipErrorInvalidValue;
+        ra = *rows;
+        if (ra.use_pmf)
+            hipLaunchKernelGGL(am_k_gather_wg<1>, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag,
+                               wbits, pos, total_out, ra);
+        else
+            hipLaunchKernelGGL(am_k_gather_wg<2>, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag,
+                               wbits, pos, total_out, ra);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(am_k_gather_wg<0>, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag, wbits, pos,
+                       total_out, ra);
     return hipGetLastError();
 }
 
@@ -2240,28 +2512,41 @@ __device__ __forceinline__ float am_soft_chip_iq(const float *__restrict__ iq, l
 // E[(s >> 5) * 36 + (s & 31)] = |.|^2 of sample B0 + s.  The source is read 16 bytes at a time: from the even sample at or
 // before B0 (one more piece, by thread 0, where B0 is odd).
 #define AM_XROW 36
+#ifndef AM_XTAIL_EARLY
+#define AM_XTAIL_EARLY 1                  /* tuning builds: 0 = a long packet's chips 128.. are loaded behind the long / short decision (round 4) */
+#endif
+// (loads and LDS stores apart: the kernel issues the loads of a burst's chips 128..239 together with those of chips 0..127 and
+// holds them in registers until the first five bits say whether the packet is a long one -- round 5: a long packet no longer pays a
+// second memory round trip behind the decision)
 template <int NS>
-__device__ __forceinline__ void am_stage_energies32(const float *__restrict__ iq, long long src_abs0, long long B0, float *E, int tid)
+struct am_energy_regs { float4 v[NS / 512]; float4 vx; };
+template <int NS>
+__device__ __forceinline__ void am_load_energies32(const float *__restrict__ iq, long long src_abs0, long long B0, int tid, am_energy_regs<NS> &R)
 {
     static_assert(NS % 512 == 0, "whole rounds of 256 threads x 2 samples");
     constexpr int ROUNDS = NS / 512;
     const int odd = (int)((B0 - src_abs0) & 1);
     const float4 *src = reinterpret_cast<const float4 *>(iq) + ((B0 - odd - src_abs0) >> 1);
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) R.v[r] = src[tid + 256 * r];
+    R.vx.x = R.vx.y = R.vx.z = R.vx.w = 0.0f;
+    if (odd && tid == 0) R.vx = src[NS / 2];                          // (the last sample's piece)
+}
+template <int NS>
+__device__ __forceinline__ void am_store_energies32(long long src_abs0, long long B0, float *E, int tid, const am_energy_regs<NS> &R)
+{
+    constexpr int ROUNDS = NS / 512;
+    const int odd = (int)((B0 - src_abs0) & 1);
     const int i0 = 2 * tid - odd, i1 = i0 + 1;                        // samples of the thread's piece in round 0 (i0 = -1: not wanted)
     float *const e0 = E + (i0 >> 5) * AM_XROW + (i0 & 31);            // (arithmetic shift: -1 -> row -1, column 31: right from round 1 on)
     float *const e1 = E + (i1 >> 5) * AM_XROW + (i1 & 31);
-    float4 v[ROUNDS], vx;
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) v[r] = src[tid + 256 * r];
-    vx.x = vx.y = vx.z = vx.w = 0.0f;
-    if (odd && tid == 0) vx = src[NS / 2];                            // (the last sample's piece)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const float a = v[r].x * v[r].x, b = v[r].y * v[r].y, c = v[r].z * v[r].z, d = v[r].w * v[r].w;
+        const float a = R.v[r].x * R.v[r].x, b = R.v[r].y * R.v[r].y, c = R.v[r].z * R.v[r].z, d = R.v[r].w * R.v[r].w;
         if (r > 0 || i0 >= 0) e0[r * 16 * AM_XROW] = a + b;           // a1: fl(fl(I*I) + fl(Q*Q))
         e1[r * 16 * AM_XROW] = c + d;
     }
-    if (odd && tid == 0) { const float a = vx.x * vx.x, b = vx.y * vx.y; E[((NS - 1) >> 5) * AM_XROW + 31] = a + b; }
+    if (odd && tid == 0) { const float a = R.vx.x * R.vx.x, b = R.vx.y * R.vx.y; E[((NS - 1) >> 5) * AM_XROW + 31] = a + b; }
 }
 // soft chip of the window in LDS row `row` (bb; the reference level comes off later): ii = offset of the burst's first sample
 // inside its canonical chip, the same for all of a burst's windows
@@ -2332,9 +2617,15 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         AM_XSTAMP(0);
         const bool staged = SPC == 32 && inside;                              // (uniform) coalesced loads through LDS
         const int ii = (int)(ae % SPC);
+        am_energy_regs<(SPC == 32 ? (AM_BURST - HEAD) * 32 : 512)> tailr;    // chips 128.. on their way (64 Msps)
         if constexpr (SPC == 32) {
             if (staged) {
-                am_stage_energies32<HEAD * 32>(iq, src_abs0, ae - (SPC - 1), stg, tid);
+                am_energy_regs<HEAD * 32> headr;
+                am_load_energies32<HEAD * 32>(iq, src_abs0, ae - (SPC - 1), tid, headr);
+#if AM_XTAIL_EARLY
+                am_load_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, tid, tailr);
+#endif
+                am_store_energies32<HEAD * 32>(src_abs0, ae - (SPC - 1), stg, tid, headr);
                 __syncthreads();
             }
         }
@@ -2350,7 +2641,10 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         const bool all = bursts_out != nullptr || am_burst_is_long(sb);       // (uniform)
         if constexpr (SPC == 32) {
             if (staged && all) {                                              // (the rows' readers are behind the barrier above)
-                am_stage_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, stg, tid);
+#if !AM_XTAIL_EARLY
+                am_load_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, tid, tailr);
+#endif
+                am_store_energies32<(AM_BURST - HEAD) * 32>(src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, stg, tid, tailr);
                 __syncthreads();
             }
         }

@@ -96,8 +96,31 @@ def ref():
         R.ref_preamble_slicer_tt.argtypes = R.ref_preamble_slicer.argtypes + [
             C.c_uint64, np.ctypeslib.ndpointer(np.uint64), np.ctypeslib.ndpointer(np.uint64),
             np.ctypeslib.ndpointer(np.float64)]
+        R.ref_slicer.argtypes = [_f32p, C.c_uint64, np.ctypeslib.ndpointer(np.uint64), np.ctypeslib.ndpointer(np.float64),
+                                 np.ctypeslib.ndpointer(np.uint8), C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint64)]
         _ref = R
     return _ref
+
+
+def ref_slice_bursts(bursts, tags):
+    """The reference's OWN slicer (lib/slicer_impl.cc:102-198, compiled by path into oracle/_ref) over caller-made bursts
+    [n, 240] tagged with (secs, frac) from `tags`.  Returns (message texts of the accepted bursts in order, accepted[n] bool)."""
+    b = np.ascontiguousarray(bursts, np.float32).reshape(-1)
+    n = len(tags)
+    assert b.size == n * 240
+    secs = np.ascontiguousarray(tags["secs"], np.uint64)
+    frac = np.ascontiguousarray(tags["frac"], np.float64)
+    acc = np.zeros(n, np.uint8)
+    mcap = n * 96 + 64
+    msgs = C.create_string_buffer(mcap)
+    mlen, nmsg = C.c_uint64(0), C.c_uint64(0)
+    rc = ref().ref_slicer(b, n, secs, frac, acc, msgs, mcap, C.byref(mlen), C.byref(nmsg))
+    if rc != 0:
+        raise RuntimeError("ref_slicer rc=%d" % rc)
+    text = msgs.raw[:mlen.value].decode().split("\n")[:-1]
+    assert len(text) == nmsg.value == int(acc.sum())
+    return text, acc.astype(bool)
 
 
 def as_iq_f32(iq):

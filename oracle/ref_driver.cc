@@ -128,6 +128,54 @@ int ref_preamble_slicer_tt(const float *in, const float *inavg, uint64_t n, floa
     return 0;
 }
 
+// The reference's slicer alone (lib/slicer_impl.cc:102-198) over nb bursts of 240 floats handed in by the caller, burst k
+// tagged "preamble_found" = (secs[k], frac[k]) at item 240 k.  msgs: '\n'-separated texts of the accepted ones, in order;
+// accepted[k] = 1 where burst k produced a message (matched up by the order of the tags: the slicer visits them in order
+// and posts at most one message per tag).  One work() call per `batch` bursts on a fresh window (the member ostringstream,
+// and with it the precision quirk of the first message, lives as long as the block).  Returns 0 on success.
+int ref_slicer(const float *bursts, uint64_t nb, const uint64_t *secs, const double *frac, uint8_t *accepted,
+               char *msgs, uint64_t msgs_cap, uint64_t *msgs_len, uint64_t *n_msgs)
+{
+    gr::msg_queue::sptr q = gr::msg_queue::make();
+    gr::air_modes::slicer::sptr sl = gr::air_modes::slicer::make(q);
+    const uint64_t batch = 4096;
+    uint64_t w = 0, total = 0;
+    std::vector<float> stream;
+    for (uint64_t b0 = 0; b0 < nb; b0 += batch) {
+        const uint64_t cnt = std::min<uint64_t>(batch, nb - b0);
+        stream.assign(bursts + b0 * 240, bursts + (b0 + cnt) * 240);
+        stream.resize(cnt * 240 + 2048, 0.0f);      // room for the slicer's look-ahead margin
+        for (uint64_t k = 0; k < cnt; k++) {
+            // one tag at a time: which bursts were accepted is then known exactly
+            sl->stub_in_tags.clear();
+            gr::tag_t g;
+            g.offset = k * 240;
+            g.key = pmt::string_to_symbol("preamble_found");
+            g.value = pmt::make_tuple(pmt::from_uint64(secs[b0 + k]), pmt::from_double(frac[b0 + k]));
+            sl->stub_in_tags.push_back(g);
+            sl->stub_nitems_read = 0;
+            gr_vector_const_void_star sins(1, stream.data());
+            gr_vector_void_star souts;
+            const size_t before = q->stub_msgs.size();
+            sl->work((int)(cnt * 240 + 960), sins, souts);
+            const size_t after = q->stub_msgs.size();
+            if (after > before + 1) return -4;
+            accepted[b0 + k] = after > before ? 1 : 0;
+        }
+        for (const std::string &m : q->stub_msgs) {
+            if (w + m.size() + 1 > msgs_cap) return -2;
+            memcpy(msgs + w, m.data(), m.size());
+            w += m.size();
+            msgs[w++] = '\n';
+        }
+        total += q->stub_msgs.size();
+        q->stub_msgs.clear();
+    }
+    *msgs_len = w;
+    *n_msgs = total;
+    return 0;
+}
+
 int ref_preamble_slicer(const float *in, const float *inavg, uint64_t n, float rate,
                         float thr_db, uint64_t pad_items, float *bursts, uint64_t *tag_secs,
                         double *tag_frac, uint64_t *tag_item, uint64_t cap_tags,

@@ -378,3 +378,113 @@ def check_front_ends_agree(lib, rate, iq, monkeypatch, thr=7.0, pmf=True, expect
     monkeypatch.delenv("AIRMODES_FE")
     assert fe2 == 2 and got2.tobytes() == want.tobytes(), "tile kernel differs from the oracle"
     return len(want)
+
+
+# ---- crafted bursts for the slicer / framer / CRC (lib/slicer_impl.cc:67-100, 128-182) ------------------------------
+EDGE_DFS = (0, 4, 5, 11, 16, 17, 18, 19, 20, 21, 24, 27, 31)
+
+
+def edge_bursts(n, seed):
+    """n bursts of 240 soft chips + tags, aimed at the reference slicer's odd rules: every downlink format incl. the ones it
+    takes for short although they are long on the air (DF18 / 19 / 24..31, :140) and DF16 long; chips exactly AT the 3 dB
+    limits `lo` / `hi` (strict comparisons, :74-75) and at half the lower limit (:92,:95: a double comparison), one float
+    next to them on either side; 0, 9 and 10 low-confidence bits on DF11 (:171), one on the other short formats (:170), 24
+    and more on long ones (the list saturates, :157); all-zero payloads (:162-166); non-finite and negative chips; valid
+    and damaged parity fields.  Reference levels over six decades (the message prints them: iostream %g formatting)."""
+    import synth
+    rng = np.random.default_rng(seed)
+    bursts = np.zeros((n, 240), np.float32)
+    tags = np.zeros(n, np.dtype([("sample", "<u8"), ("secs", "<u8"), ("frac", "<f8"), ("inavg", "<f4"), ("how_late", "<u4")]))
+    tags["secs"] = rng.integers(0, 1 << 33, n)
+    tags["frac"] = rng.random(n)
+    tags["sample"] = np.arange(n, dtype=np.uint64) * 4801
+    f32 = np.float32
+    for i in range(n):
+        kind = int(rng.integers(0, 12))
+        scale = f32(10.0 ** rng.uniform(-4, 2))
+        pre = (f32(1.0) + rng.uniform(-0.2, 0.2, 4).astype(f32)) * scale
+        b = bursts[i]
+        b[:16] = (rng.uniform(0.0, 0.1, 16).astype(f32) * scale)
+        b[[0, 2, 7, 9]] = pre
+        # the reference level exactly as slicer_impl.cc:128-131 forms it, and the limits of :71-72
+        ref = f32(np.float64(f32(f32(f32(pre[0] + pre[1]) + pre[2]) + pre[3])) / 4.0)
+        hi = f32(np.float64(ref) * 1.414)
+        lo = f32(np.float64(ref) * 0.707)
+        half = f32(np.float64(lo) * 0.5)
+        df = int(EDGE_DFS[int(rng.integers(0, len(EDGE_DFS)))])
+        frame = bytearray(synth.make_frame(rng, df if df in (16, 17, 20, 21) else (df if df < 24 else 0)))
+        if len(frame) == 7:
+            frame += bytes(rng.integers(0, 256, 7, dtype=np.uint8).tobytes())   # what follows a "short" frame on the air
+        frame[0] = ((df & 0x1F) << 3) | (frame[0] & 7)
+        if df not in (16, 17, 20, 21) and rng.random() < 0.7:
+            # a parity field the reference can check for the length IT assumes (56 bits)
+            par = synth._crc24(bytes(frame[:4]))
+            if df != 11 or rng.random() < 0.3:
+                par ^= int(rng.integers(0, 1 << 24)) if df != 11 else int(rng.integers(0, 2))
+            frame[4:7] = par.to_bytes(3, "big")
+        if kind == 0:
+            frame = bytearray(14)                                  # all zero: tossed whatever else holds (:162-166)
+        bits = np.unpackbits(np.frombuffer(bytes(frame), np.uint8))
+        strong = ref * (f32(1.0) + rng.uniform(-0.15, 0.15, 112).astype(f32))
+        weak = half * rng.uniform(0.0, 0.9, 112).astype(f32)
+        c0 = np.where(bits == 1, strong, weak).astype(f32)
+        c1 = np.where(bits == 1, weak, strong).astype(f32)
+        palette = np.array([lo, hi, np.nextafter(lo, f32(np.inf)), np.nextafter(lo, f32(-np.inf)), np.nextafter(hi, f32(np.inf)),
+                            np.nextafter(hi, f32(-np.inf)), half, np.nextafter(half, f32(np.inf)), np.nextafter(half, f32(-np.inf)),
+                            f32(0.0), f32(-0.0), -ref, ref, f32(2.0) * ref, f32(np.inf), f32(-np.inf), f32(np.nan),
+                            f32(1e-40), f32(3e38)], np.float32)
+        nbits_ref = 112 if df in (16, 17, 20, 21) else 56
+
+        def lowconf(j):                                            # both chips inside the limits: decided, not trusted (:84-87)
+            a, d = ref * f32(1.05), ref * f32(0.95)
+            c0[j], c1[j] = (a, d) if bits[j] else (d, a)
+        if kind in (1, 2, 3):                                      # a chosen number of low-confidence bits
+            want = {1: int(rng.integers(1, 3)), 2: int(rng.choice([8, 9, 10, 11])), 3: int(rng.integers(22, 40))}[kind]
+            for j in rng.choice(np.arange(5, nbits_ref), min(want, nbits_ref - 5), replace=False):
+                lowconf(int(j))
+        elif kind in (4, 5, 6):                                    # chips at / next to the limits, a few or many
+            m = {4: 2, 5: 12, 6: 60}[kind]
+            js = rng.integers(0, 112, m)
+            c0[js] = palette[rng.integers(0, len(palette), m)]
+            js = rng.integers(0, 112, m)
+            c1[js] = palette[rng.integers(0, len(palette), m)]
+        elif kind == 7:                                            # the header bits themselves on the limits
+            js = rng.integers(0, 5, 3)
+            c0[js] = palette[rng.integers(0, 9, 3)]
+            c1[js] = palette[rng.integers(0, 9, 3)]
+        elif kind == 8:                                            # noise-like: neither chip near the reference
+            c0 = (rng.uniform(0, 3, 112).astype(f32) * ref).astype(f32)
+            c1 = (rng.uniform(0, 3, 112).astype(f32) * ref).astype(f32)
+        b[16::2] = c0
+        b[17::2] = c1
+        if kind == 9:                                              # a non-finite or zero reference level
+            b[[0, 2, 7, 9][int(rng.integers(0, 4))]] = [f32(np.inf), f32(np.nan), f32(0.0), f32(-1.0) * scale][int(rng.integers(0, 4))]
+    return bursts, tags
+
+
+def check_slicer_edge_vectors(lib, n, seed, with_ref=False):
+    """pc.edge_bursts through the block-level slicer of the library (am_slicer_work -> am_k_slice / am_slice_wave) against the
+    oracle and, where oracle/_ref exists, the reference's own slicer_impl::work."""
+    bursts, tags = edge_bursts(n, seed)
+    ctx = _capi.Context(4e6, 7.0, True, lib=lib)
+    got = ctx.slicer_work(bursts, tags)
+    want = oracle.slice_bursts(bursts, tags)
+    assert got.tobytes() == want.tobytes(), "packets differ"       # (bytes: a NaN reference level must compare equal to itself)
+    texts = lib.format_messages(got, True)
+    assert texts == oracle.format_messages(want)
+    if with_ref and oracle.have_ref():
+        rtext, acc = oracle.ref_slice_bursts(bursts, tags)
+        assert texts == rtext and int(acc.sum()) == len(got)
+    return len(got)
+
+
+def check_framer_edge_formats(lib, rate, n, lam, seed, want_fe=None):
+    """DF16 / 18 / 19 / 24 on the air (synth.DF_MIX_EDGE) through the PRODUCTION path -- front end, refinement, chain,
+    am_k_extract_slice_iq + am_slice_wave -- at stage level: tags, bursts, packets against the oracle and the reference's C++."""
+    iq, truth = synth.synth_capture(rate, n, lam, seed, df_mix=synth.DF_MIX_EDGE, snr_db=(14.0, 35.0))
+    npk = check_production_stages(lib, rate, n, lam, seed, iq=iq, with_ref=True, want_fe=want_fe)
+    want = oracle.demod(iq, rate, 7.0, True)
+    dfs = set(int(d) for d in want["df"])
+    assert {16, 18, 19, 24} <= dfs, dfs
+    assert set(want["nbytes"][np.isin(want["df"], (18, 19, 24))]) == {7} and set(want["nbytes"][want["df"] == 16]) == {14}
+    return npk

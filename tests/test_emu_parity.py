@@ -337,3 +337,14 @@ def test_time_shards_as_a_stream_through_the_c_abi(emu_lib, rate, n, W, K, dc):
     where it stopped, across chunks and steps)."""
     iq, _ = synth.synth_capture(rate, n, 9000.0, seed=424)
     assert pc.check_stream_sharded(emu_lib, rate, iq, W, K, dcblock=dc) > 20
+
+
+def test_slicer_edge_vectors(emu_lib, oracle_mod):
+    """Crafted bursts (every downlink format, chips on the 3 dB limits, 9 / 10 / 24+ low-confidence bits, all-zero payloads,
+    non-finite chips) through am_slicer_work: oracle and the reference's own slicer (lib/slicer_impl.cc:67-100,140,157,162-182)."""
+    assert pc.check_slicer_edge_vectors(emu_lib, 12000, 20251, with_ref=True) > 2000
+
+
+@pytest.mark.parametrize("rate,n,lam", [(4e6, 600000, 3000.0), (64e6, 2500000, 12000.0)])
+def test_framer_edge_formats_through_the_production_path(emu_lib, oracle_mod, rate, n, lam):
+    assert pc.check_framer_edge_formats(emu_lib, rate, n, lam, 616) > 10
