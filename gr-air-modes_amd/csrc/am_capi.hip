@@ -416,6 +416,20 @@ int run_frontend(am_ctx *c, const float *src, uint64_t src_abs0, uint64_t src_ab
     return AM_OK;
 }
 
+// Which kernels a scan of this context runs: 3 = the streaming front ends (am_k_fe3 / am_k_fe4: bitmap + sparse rows), 1 = the
+// rate-generic kernels (dense bb / avg), 2 = the tile kernel am_k_fe2 (dense bb) -- in TEST builds only (-DAM_WITH_TILE_KERNEL:
+// tests/gpu_variants, tests/emu; round 5: the product library no longer carries it nor the split refinement behind it).
+// dense_wanted: the caller wants bb / avg as whole arrays (block-level am_frontend_work).
+static int scan_path(const am_ctx *c, bool dense_wanted)
+{
+    if (c->force_generic || c->frac) return 1;
+    if (!dense_wanted && c->allow_stream && am_fe4_supported(c->spc)) return 3;
+#if AM_WITH_TILE_KERNEL
+    if (am_fe2_tile(c->spc)) return 2;
+#endif
+    return 1;
+}
+
 // Scan of the per-segment candidate counts and read-back of the total; then either the
 // refinement kernel (generic path: candidates only) or the gather of the records the fused
 // kernel already produced.  Leaves the flat records (pos, e, tgt, inavg, valid) on the device.
@@ -472,7 +486,9 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
                                             (uint32_t *)c->jump.p, c->stream, Mp, (const float *)c->wgmax.p, c->fe_vspan,
                                             c->fe_nv));
             c->jump_ready = true;
-        } else if (mode >= 2) {
+        }
+#if AM_WITH_TILE_KERNEL
+        else if (mode >= 2) {
             // split refinement behind the tile kernel: positions -> energy per reachable position -> per-candidate test
             const uint32_t nb = (M + 2047u) / 2048u;
             const uint64_t ebound = std::min<uint64_t>((uint64_t)M * (uint64_t)(c->spc + 1), (uint64_t)M + 0xFFFFFFFFull);
@@ -497,7 +513,9 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
                                      c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p,
                                      (float *)c->inavg.p, (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, c->stream, Mp));
             c->jump_ready = true;
-        } else
+        }
+#endif
+        else
             HIPCHK(c, am_launch_refine(bb, avg, c->geom, c->thr_lin, (uint32_t *)c->cand_seg.p, seg_stride,
                                        (uint32_t *)c->blk_off.p, nseg, M, (uint32_t *)c->pos.p,
                                        (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, (float *)c->inavg.p,
@@ -533,10 +551,11 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     c->spec_now = false;
     c->Mdev = nullptr;
     c->bb_sparse = false;
-    const unsigned T2 = (c->force_generic || c->frac) ? 0u : am_fe2_tile(c->spc);   // (fractional samples per chip: the rate-generic kernels)
+    const int path = scan_path(c, avg != nullptr);           // (fractional samples per chip: the rate-generic kernels)
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    c->last_fe = T2 == 0 ? 1 : 2;
-    if (T2 == 0) {
+    c->last_fe = path == 1 ? 1 : 2;
+    if (path == 1) {
+        if (!avg) return fail(c, AM_EINVAL, "internal: the rate-generic kernels need the dense reference-level array");
         int rc = run_frontend(c, src, src_abs0, src_abs1, out_abs0, out_n, bb, avg);
         if (rc != AM_OK) return rc;
         HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -544,7 +563,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         return run_candidates(c, bb, avg, j0, j1, M_out);
     }
     c->scan_src = src; c->scan_src_abs0 = src_abs0; c->scan_src_abs1 = src_abs1;
-    if (!avg && c->allow_stream && am_fe4_supported(c->spc)) {
+    if (path == 3) {
         // streaming kernel: candidate bitmap + per-(step, wave) counts; bb and the reference level only around candidates
         const unsigned ns = am_fe4_steps((long long)out_n, c->spc);
         const unsigned wps = am_fe4_words(c->spc) * am_fe4_waves(c->spc);     // bitmap words per step
@@ -592,6 +611,8 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         return run_refine(c, bb, (const float *)c->avg.p, c->fe_nwg, 0, 3, M_out,
                           (uint32_t)std::min<uint64_t>(endj3, 0xFFFFFFFFull), cap3);
     }
+#if AM_WITH_TILE_KERNEL
+    const unsigned T2 = am_fe2_tile(c->spc);
     const unsigned ntiles = (unsigned)((out_n + T2 - 1) / T2);
     const size_t nslots = (size_t)ntiles * T2;
     ENSURE(c, c->cand_seg, nslots * sizeof(uint32_t));
@@ -621,6 +642,9 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
     }
     return run_refine(c, bb, avg_sparse ? avg_sparse : avg, nt, tl, 2, M_out,
                       (uint32_t)std::min<uint64_t>(endj, 0xFFFFFFFFull), spec_cap);
+#else
+    return fail(c, AM_EINVAL, "internal: no kernel for this scan");
+#endif
 }
 
 // Greedy chain, part 1 (independent of where the scan starts): successor array and per-block exits
@@ -1107,7 +1131,7 @@ static int process_iq_core(am_ctx *c, const float *iq, uint64_t n, uint32_t flag
         }
         if (fsrc_abs0 > need0) return fail(c, AM_EINVAL, "internal: stream history was not carried");
         const uint64_t pad = zero_pad(c->spc_hi);
-        const bool generic = c->force_generic || c->frac || am_fe2_tile(c->spc) == 0;
+        const bool generic = scan_path(c, false) == 1;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
         float *bb = (float *)c->bb.p, *avg = nullptr;
         ZERO_TAIL(c, 0, bb, out_n, pad);
@@ -1314,8 +1338,8 @@ int am_frontend_work(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, flo
     uint64_t s0 = 0;
     int rc = apply_dcblock(c, &src, &s0, n, 0);
     if (rc != AM_OK) return rc;
-    if (!c->force_generic && !c->frac && am_fe2_tile(c->spc)) {
-        uint32_t M = 0;      // fused kernel with an empty detection range: bb/avg only
+    if (scan_path(c, true) == 2) {
+        uint32_t M = 0;      // (test builds) the tile kernel with an empty detection range: bb/avg only
         rc = run_front_and_candidates(c, src, 0, n, 0, n, dbb, davg, 0, 0, &M);
     } else {
         rc = run_frontend(c, src, 0, n, 0, n, dbb, davg);
@@ -1525,7 +1549,7 @@ static int shard_scan_core(am_ctx *c, const float *iq, uint64_t abs_start, uint6
     c->spec_now = false;
     c->Mdev = nullptr;
     if (P1 > P0 && out_n) {
-        const bool generic = c->force_generic || c->frac || am_fe2_tile(c->spc) == 0;
+        const bool generic = scan_path(c, false) == 1;
         ENSURE(c, c->bb, (out_n + pad) * sizeof(float));
         float *bb = (float *)c->bb.p, *avg = nullptr;
         ZERO_TAIL(c, 0, bb, out_n, pad);

@@ -11,7 +11,8 @@
 //     back and waited for; |.|^2 goes straight into the ring slots of the step's chips.  No prefetch: while one
 //     workgroup waits for its loads the other five of the CU compute.  (LDS-DMA staging and register prefetch -- also the
 //     next step's loads under the current step's sparse outputs, which fit the registers -- were built and measured in
-//     rounds 2 and 4, DESIGN.md 5.1 / profiles/r4_valu: none is faster; those variants are gone from the source.)
+//     rounds 2, 4 and 5 (again once the bb rows had left the kernel), the default cache policy instead of nt in round 5:
+//     DESIGN.md 5.1 / profiles/r4_valu / profiles/r5_fe64: none is faster; those variants are gone from the source.)
 //   * thread = one chip (32 samples in registers).  The chip before it belongs to lane-1: its in-chip suffix sums come
 //     over inside the addition (v_add_f32_dpp wave_ror:1); lane 63 stands in for the chip before the wave's first.
 //   * THE KERNEL IS PRICED AGAINST HBM BUT WAS BOUND BY VALU ISSUE (a wave64 instruction holds the SIMD for four cycles;
@@ -63,11 +64,6 @@
 #define FE3_NT (AM_WAVE * FE3_NW)         /* lanes 0..47 of a wave = its block's chips; all threads stage the loads */
 #define FE3_T (FE3_S * FE3_SPC)           /* samples per step                                          */
 #define FE3_LAG 9                         /* phase B runs this many chips behind phase A               */
-#ifndef FE3_EARLY
-#define FE3_EARLY 0                       /* 1: the next step's loads are issued when phase B's registers are free, under the sparse
-                                             outputs (no spills; round 4, with the bb rows still written here: 0.1229-0.1308 against
-                                             0.1262-0.1285 ms on two boxes, a tie; measured again in round 5 without them: profiles/r5_fe64) */
-#endif
 #ifndef FE3_CR_EXTRA
 #define FE3_CR_EXTRA 0
 #endif
@@ -221,31 +217,6 @@ __device__ __forceinline__ void fe3_stage_step(const am_fe3_args &a, const fe3_s
     fe3_store_step<J0>(L, slot0, par, tid, v);
 }
 
-// The next step's loads, issued by the current step (FE3_EARLY).  Where they are not issued the registers are defined
-// all the same: a variable that keeps its old contents on one path is live across the whole loop body -- 48 VGPRs
-// through phase B, which has none to spare.
-__device__ __forceinline__ void fe3_next_loads(const am_fe3_args &a, long long A1, int tid, bool next_fast, fe3_raw &nx)
-{
-    if (!FE3_EARLY) return;
-    if (next_fast) {
-        int t2 = tid;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(t2));                                  // (the addresses are formed here, not hoisted)
-#endif
-        fe3_load_step<0>(a, A1, t2, nx);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            // ("some value", at no cost: zeros were hoisted in front of the branch, 48 moves on the path that loads)
-            asm volatile("" : "=v"(nx.v[j].x), "=v"(nx.v[j].y), "=v"(nx.v[j].z), "=v"(nx.v[j].w));
-#else
-            nx.v[j].x = 0.0f; nx.v[j].y = 0.0f; nx.v[j].z = 0.0f; nx.v[j].w = 0.0f;
-#endif
-        }
-    }
-}
-
 // One step (its |.|^2 is staged).
 //   step     global step index (may be -1: history before the first wanted block)
 //   test     false for a workgroup's first step (it only rebuilds the rings from the previous segment's tail)
@@ -253,7 +224,7 @@ __device__ __forceinline__ void fe3_next_loads(const am_fe3_args &a, long long A
 //   edge     (uniform) the step touches the end of the stream or positions that are not wanted
 __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L, const int step, const bool test,
                                          const int slot0, const int par, const bool edge, const int tid, float &mxrun,
-                                         bool &badrun, uint32_t &ncand, fe3_prof &PR, const bool next_fast, fe3_raw &nx)
+                                         bool &badrun, uint32_t &ncand, fe3_prof &PR)
 {
     constexpr int SPC = FE3_SPC;
     const int lane = tid & (AM_WAVE - 1);
@@ -356,10 +327,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     FE3_STAMP(1);
     fes_barrier();                                                    // B3: ring, totals and scans of this step complete
     FE3_STAMP(2);
-    if (!test) {                                                      // (uniform) ring rebuild only
-        fe3_next_loads(a, A0 + FE3_T, tid, next_fast, nx);
-        return;
-    }
+    if (!test) return;                                                // (uniform) ring rebuild only
 
     // ---- phase B on chip q = (this thread's phase-A chip) - 9: reference level (a4) + first-stage test (a6) --------
     // (ring offsets by add / compare / select from the phase-A chip's: slot * 36 is a multiply only once per step)
@@ -509,8 +477,6 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     ncand += (uint32_t)__popcll((unsigned long long)cm);
     const unsigned long long cand = __ballot(cm != 0u);               // bit l: chip 48 wave + l has a candidate
     FE3_STAMP(3);
-    // phase B's registers are free: the next step's raw samples start their way here and arrive under the sparse outputs
-    fe3_next_loads(a, A0 + FE3_T, tid, next_fast, nx);
     if (FE3_ABLATE & 1) return;
     // ---- sparse outputs ---------------------------------------------------------------------------------------------
     // reference level: the chip of a candidate and the one after it (a wave's lane 0 cannot see the chip before it:
@@ -655,8 +621,6 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     float mxrun = 0.0f;                                               // largest bb this thread has formed
     bool badrun = false;                                              // ... or one that is not finite
     uint32_t ncand = 0;                                               // candidates this thread's chips held
-    fe3_raw nx;                                                       // the next step's raw samples on their way (FE3_EARLY)
-    bool staged = false;
     for (int step = sb - 1; step < se; ++step) {                      // the step before the segment rebuilds the rings
         const bool test = step >= sb;
         const bool have = step >= a.raw_lo && step < a.raw_hi;        // the step's raw samples are all present and 16-byte aligned
@@ -669,8 +633,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
         // load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is chip
         // FE3_S - FE3_LAG of it, whose reference level reaches back 47 chips -- chips below FE3_WARM_J0 * 8 stay zero
-        if (FE3_EARLY && staged) fe3_store_step<0>(L, slot0, par, tid, nx);   // (loaded under the previous step's sparse outputs)
-        else if (have) {
+        if (have) {
             if (test) fe3_stage_step<false>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
             else fe3_stage_step<false, FE3_WARM_J0>(a, L, a.out_abs0 + (long long)step * FE3_T, slot0, par, tid);
         } else
@@ -678,10 +641,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         FE3_STAMP(5);
         fes_barrier();                                                // B1: |.|^2 of this step staged
         FE3_STAMP(0);
-        // the next step is a tested step of this segment whose samples are all present
-        const bool next_fast = FE3_EARLY && step + 1 < se && step + 1 >= a.raw_lo && step + 1 < a.raw_hi;
-        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR, next_fast, nx);
-        staged = next_fast;
+        fe3_step(a, L, step, test, slot0, par, edge, tid, mxrun, badrun, ncand, PR);
         slot0 = fe3_wrap_up(slot0 + FE3_S);
         par ^= 1;
         FE3_STAMP(6);

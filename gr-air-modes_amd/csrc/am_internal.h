@@ -8,6 +8,9 @@
 
 #include "airmodes_hip.h"
 
+#ifndef AM_WITH_TILE_KERNEL
+#define AM_WITH_TILE_KERNEL 0   /* 1 in TEST builds (tests/gpu_variants, tests/emu): the tile kernel am_k_fe2 and the split refinement behind it */
+#endif
 #define AM_CHIPS_AVG 48    /* reference level window in chips  (python/rx_path.py:54)      */
 #define AM_BURST 240       /* chips handed to the slicer       (lib/preamble_impl.cc:219)  */
 #define AM_WAVE 64
@@ -110,8 +113,6 @@ hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uin
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
                                 uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
                                 hipStream_t s, const uint32_t *Mp = nullptr);
-hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
-                                   hipStream_t s, const uint32_t *Mp = nullptr);
 hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
                             const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
                             double *energy, hipStream_t s, const uint32_t *Mp = nullptr);

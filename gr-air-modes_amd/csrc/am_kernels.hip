@@ -442,6 +442,7 @@ __device__ __forceinline__ uint32_t am_count(uint32_t cap, const uint32_t *__res
     return m < cap ? m : cap;
 }
 
+#if AM_WITH_TILE_KERNEL
 // One workgroup per tile segment: its slice of the flat arrays is [blk_off[b], blk_off[b+1]), so the
 // copy is coalesced and needs no search; only the first candidate of a segment looks back for its
 // predecessor (last candidate of the nearest earlier non-empty segment).
@@ -475,6 +476,7 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
     }
 }
 
+#endif  // AM_WITH_TILE_KERNEL
 // Flat candidate positions from the streaming front ends' bitmap (am_fe3.hip / am_fe4.hip), one workgroup per FRONT-END
 // workgroup (round 4).  Word w, bit b = array coordinate wbits * w + b - lag (wbits = 32 at 64 Msps, the unit length of
 // am_k_fe4 otherwise).  Front-end workgroup g tested the words [g * words_per_wg, (g + 1) * words_per_wg) and left their
@@ -486,56 +488,68 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 // number of candidates there are.
 // ---- bb rows around candidates, rebuilt from IQ (round 5; 64 Msps) ------------------------------------------------------------
 // Until round 4 am_k_fe3 wrote the pulse-matched power bb of the 17 chips from every candidate's chip on: 54 MB of stores per
-// 64 M-sample launch at the bench density, 15 us of a kernel that moves bytes at the rate the part can move them.
-// Those rows are formed HERE instead, by the workgroup that lists the segment's candidates anyway: it knows which chips the
+// 64 M-sample launch at the bench density, 12-15 us of a kernel that moves bytes at the rate the part can move them (DESIGN.md
+// 5.1).  Those rows are formed HERE instead, by the workgroup that lists the segment's candidates anyway: it knows which chips the
 // refinement will read (a candidate in bitmap word w -> chips w - 9 .. w + 7 of the array: bit b of word w is position
 // 32 w + b - 288), loads exactly their samples (and the chip before each run: the filter's window reaches back one chip) and
 // repeats phase A of am_k_fe3 in the canonical order: in-chip suffix sums of the chip before right->left, prefix
 // sums of the own chip left->right, bb[n] = fl((suf + pre) s1); the chip's last sample: pre alone.  Same bits as the front
 // end's ring rows (stage-level device tests compare every candidate record with the arrays NaN-poisoned).
-// Machine mapping: every WAVE works on its own stripes of 32 chips, no workgroup barrier: 16 lanes load one chip's 256 bytes
-// (coalesced), |.|^2 goes to the wave's 33 LDS rows (stride 36 floats: 16-byte reads of consecutive rows hit all banks), lane t
-// forms chip t's row in registers from rows t and t + 1, writes it back in place, and the wave copies the flagged rows out eight
-// per store instruction (8 lanes x 16 bytes = one 128-byte line each).  A stripe without a flagged chip costs one LDS read.
-#define AM_ROWS_STRIPE 32                 /* chips per stripe = rows a wave forms at a time */
+// Machine mapping: the wanted chips of the segment are taken 32 at a time, DENSELY (a wave's lanes hold 32 wanted chips wherever
+// they lie; the first version walked stripes of 32 consecutive chips of which 8 were wanted: 41 us of instruction issue at the
+// bench density).  Every wave works on its own batches, no workgroup barrier: 16 lanes load one chip's 256 bytes (coalesced), all of
+// a batch's loads in flight together; |.|^2 goes to the wave's LDS rows (stride 36 floats: 16-byte reads of consecutive rows hit
+// all banks); lane j forms the prefix sums of chip j's row, lane j + 32 the suffix sums of the chip before it (the row of lane
+// j - 1 where the wanted chips are neighbours -- they come in runs of 17 and more --, an extra row at the start of a run), lane j
+// fetches across the wave what it needs and writes the row back in place; the rows leave eight per store instruction
+// (8 lanes x 16 bytes = one 128-byte line each).
 #define AM_ROWS_XS 36                     /* floats per LDS row: 32 + 4 pad */
 #define AM_ROWS_BBW 17                    /* chips of bb the refinement reads from a candidate's chip on */
-#define AM_ROWS_MAXW 2048                 /* bitmap words per front-end workgroup this kernel can flag (am_k_fe3: 14 x 96) */
-
-// 32 bits of a bit array held in 64-bit words, from bit `off` on
-__device__ __forceinline__ uint32_t am_bits32(const unsigned long long *a, uint32_t off)
-{
-    const uint32_t j = off >> 6, sh = off & 63u;
-    unsigned long long v = a[j] >> sh;
-    if (sh > 32u) v |= a[j + 1u] << (64u - sh);
-    return (uint32_t)v;
-}
+#define AM_ROWS_MAXW 2048                 /* bitmap words per pass of a workgroup (am_k_fe3: 14 x 96 words per workgroup) */
+#define AM_ROWS_BATCH 32                  /* wanted chips a wave takes at a time */
+#define AM_ROWS_XSTART 8                  /* rows for the chip before a run's first (a batch holds at most 3 run starts: see below) */
+#define AM_ROWS_SLOTS (AM_ROWS_BATCH + AM_ROWS_XSTART)
+#define AM_ROWS_NFL ((AM_ROWS_MAXW + 16) / 64 + 2)
+#ifndef AM_ROWS_WPS
+#define AM_ROWS_WPS 5                     /* waves per SIMD the gather + rows kernel is compiled for (<= 102 VGPRs: a batch's 40 loads in flight, then a 32-register chain) */
+#endif
 
 // rows of the chips [w_begin - 9, w_end - 9) that some candidate in the words [w_begin - 16, w_end) asks for.  All threads of the
-// workgroup call it (two barriers in front of the flags, none after).  NZ / FL: (AM_ROWS_MAXW + 16) / 64 + 2 words each; XR: 33
-// rows per wave; TB: 3 x 40 bytes per wave.
+// workgroup call it (three barriers in front, none after).  NZ / FL: AM_ROWS_NFL words each; PFX: AM_ROWS_NFL + 1; XR: AM_ROWS_SLOTS
+// rows per wave; RC: AM_ROWS_SLOTS entries per wave.
 template <bool PMF>
 __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const uint32_t *__restrict__ bits, uint32_t w_begin,
-                                                  uint32_t w_end, unsigned long long *NZ, unsigned long long *FL, float *XR_all,
-                                                  unsigned char *TB_all)
+                                                  uint32_t w_end, unsigned long long *NZ, unsigned long long *FL, uint32_t *PFX,
+                                                  float *XR_all, uint16_t *RC_all)
 {
     constexpr int SPC = 32;
     const int tid = threadIdx.x, nwv = blockDim.x / AM_WAVE;
-    int lane = tid & (AM_WAVE - 1);
+    const int lane = tid & (AM_WAVE - 1);
     const int wv = __builtin_amdgcn_readfirstlane(tid / AM_WAVE);     // (wave-uniform, and known to be: scalar arithmetic, uniform branches)
     const uint32_t nw = w_end - w_begin;                              // <= AM_ROWS_MAXW
-    const uint32_t nidx = nw + 16u;                                   // index i <-> word w_begin - 16 + i
+    const uint32_t nidx = nw + 16u;                                   // index i <-> word w_begin - 16 + i <-> array chip w_begin - 25 + i
     const uint32_t n64 = (nidx + 63u) >> 6;
-    // which words hold a candidate (one bit per word; a wave's ballot is 64 of them)
-    for (uint32_t i0 = (uint32_t)wv * AM_WAVE; i0 < n64 * 64u; i0 += (uint32_t)nwv * AM_WAVE) {
-        const uint32_t i = i0 + (uint32_t)lane;
-        const long long w = (long long)w_begin - 16 + (long long)i;
-        const bool nz = i < nidx && w >= 0 && bits[w >= 0 ? w : 0] != 0u;
-        const unsigned long long m = __ballot(nz);
-        if (lane == 0) NZ[i0 >> 6] = m;
+    // which words hold a candidate (one bit per word; a wave's ballot is 64 of them).  The loads of all of a wave's chunks go
+    // out together (a load and its ballot per iteration were six serial memory round trips: ~12 us of this kernel)
+    {
+        constexpr int NCH = (AM_ROWS_NFL + 3) / 4;                    // chunks of 64 words per wave, four waves: 9
+        uint32_t x[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const uint32_t i = ((uint32_t)wv + (uint32_t)q * (uint32_t)nwv) * AM_WAVE + (uint32_t)lane;
+            const long long w = (long long)w_begin - 16 + (long long)i;
+            x[q] = (i < nidx && w >= 0) ? bits[w] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const uint32_t c = (uint32_t)wv + (uint32_t)q * (uint32_t)nwv;
+            const unsigned long long m = __ballot(x[q] != 0u);
+            if (lane == 0 && c < n64) NZ[c] = m;
+        }
     }
     __syncthreads();
-    // a word with a candidate flags its chip and the 16 after it: dilation by 16 bits across the 64-bit words
+    // a word with a candidate flags its chip and the 16 after it: dilation by 16 bits across the 64-bit words; kept: the chips
+    // of THIS segment (indices 16 .. nidx - 1: what lies before belongs to the workgroup before)
     for (uint32_t j = (uint32_t)tid; j < n64 + 1u; j += blockDim.x) {
         unsigned long long f = 0ull;
         if (j < n64) {
@@ -545,125 +559,129 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
             f = d | (x << 16);
             const uint32_t hp = j ? (uint32_t)(NZ[j - 1u] >> 48) : 0u;      // the previous word's last 16 words reach into this one
             if (hp) f |= (2ull << (31 - __clz((int)hp))) - 1ull;
+            if (j == 0) f &= ~0xFFFFull;
+            const uint32_t lim = nidx - 64u * j;                      // indices of this word below nidx
+            if (lim < 64u) f &= (1ull << lim) - 1ull;
         }
         FL[j] = f;
     }
     __syncthreads();
-    float *const XR = XR_all + wv * ((AM_ROWS_STRIPE + 1) * AM_ROWS_XS);
-    unsigned char *const TB = TB_all + wv * (3 * 40);                 // [0], [1]: rows whose |.|^2 a stripe needs (by parity); [2]: rows wanted
+    if ((uint32_t)tid <= n64) {                                       // (<= 34 words: every entry adds up the words before it, reads in flight together)
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < (uint32_t)tid; ++k) acc += (uint32_t)__popcll(FL[k]);
+        PFX[tid] = acc;
+    }
+    __syncthreads();
+    const uint32_t nf = PFX[n64];                                     // wanted chips of the segment
+    float *const XR = XR_all + wv * (AM_ROWS_SLOTS * AM_ROWS_XS);
+    uint16_t *const RC = RC_all + wv * AM_ROWS_SLOTS;                 // index i of the chip in row slot s
     const bool wide = (reinterpret_cast<uintptr_t>(ra.iq) & 15u) == 0 && (((ra.out_abs0 - ra.src_abs0) & 1) == 0);   // (uniform)
     const float2 *iq2 = reinterpret_cast<const float2 *>(ra.iq);
-    const uint32_t nstripes = (nw + AM_ROWS_STRIPE - 1u) / AM_ROWS_STRIPE;
-    constexpr int MAXR = (AM_ROWS_STRIPE + 1) * 16 / AM_WAVE + 1;     // rounds of 64 pieces that cover 33 rows: 9
-    // a wave's stripes that hold a wanted chip, one after the other; the loads of the next one are in flight while the
-    // current one is worked on (one memory round trip per stripe in the open was 54 us of this kernel at the bench density)
-    auto wanted = [&](uint32_t st) __attribute__((always_inline)) -> uint32_t {
-        uint32_t fm = am_bits32(FL, 16u + st * AM_ROWS_STRIPE);       // bit t: chip t of the stripe is wanted
-        const uint32_t left = nw - st * AM_ROWS_STRIPE;               // chips of the segment from the stripe's first on
-        if (left < 32u) fm &= (1u << left) - 1u;
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)fm);     // (every lane read the same words)
-    };
-    auto next_stripe = [&](uint32_t st, uint32_t &fm) __attribute__((always_inline)) -> uint32_t {
-        fm = 0u;
-        for (; st < nstripes; st += (uint32_t)nwv) {
-            fm = wanted(st);
-            if (fm) break;
-        }
-        return st;
-    };
-    // rows whose |.|^2 a stripe needs: row r <-> chip chip0 - 1 + r; a wanted chip t needs its own row t + 1 and (filter on) row t
-    auto rows_needed = [&](uint32_t fm) __attribute__((always_inline)) -> unsigned long long {
-        return PMF ? ((unsigned long long)fm | ((unsigned long long)fm << 1)) : ((unsigned long long)fm << 1);
-    };
-    float4 v[MAXR];
-    // is every sample a stripe can ask for inside the source, at 16-byte aligned addresses?  (uniform; all but the stripes at the
-    // two ends of the stream and unaligned sources)
-    auto inside_of = [&](uint32_t st) __attribute__((always_inline)) -> bool {
-        const long long A0 = ra.out_abs0 + ((long long)w_begin + (long long)st * AM_ROWS_STRIPE - 9) * SPC;
-        return wide && A0 - SPC >= ra.src_abs0 && A0 + (long long)AM_ROWS_STRIPE * SPC <= ra.src_abs1;
-    };
-    // the loads of stripe st (wave-uniform st, fm; inside_of(st)) into v; tb: this stripe's list of needed rows.  Scalar base
-    // (the first sample of the chip before the stripe) + the lane's 32-bit byte offset: no 64-bit vector arithmetic
-    auto issue = [&](uint32_t st, uint32_t fm, unsigned char *tb) __attribute__((always_inline)) {
-        const long long A0 = ra.out_abs0 + ((long long)w_begin + (long long)st * AM_ROWS_STRIPE - 9) * SPC;
-        const unsigned long long mneed = rows_needed(fm);
-        const int np = __popcll(mneed) * 16;
-        if (lane <= AM_ROWS_STRIPE && ((mneed >> lane) & 1ull)) tb[__popcll(mneed & ((1ull << lane) - 1ull))] = (unsigned char)lane;
-        __builtin_amdgcn_wave_barrier();
-        if (!inside_of(st)) return;                                   // (the stripe is staged one sample at a time when its turn comes)
-        unsigned long long gb = reinterpret_cast<unsigned long long>(iq2 + (A0 - SPC - ra.src_abs0));
-        gb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb >> 32)) << 32) |
-             (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb);   // (wave-uniform: the base stays in scalar registers)
-#pragma unroll
-        for (int r = 0; r < MAXR; ++r) {
-            const int p = lane + AM_WAVE * r;
-            const int pc = p < np ? p : 0;                            // (a lane without a piece loads piece 0 again: no branch around the load)
-            const unsigned off = (unsigned)tb[pc >> 4] * (unsigned)(SPC * 8) + (unsigned)(pc & 15) * 16u;
-            v[r] = fes_gload16_cached_at(gb, off);
-        }
-    };
-    uint32_t fm = 0u;
-    uint32_t st = next_stripe((uint32_t)wv, fm);
-    if (st >= nstripes) return;                                       // (wave-uniform)
-    int par = 0;
-#pragma unroll
-    for (int r = 0; r < MAXR; ++r) { v[r].x = 0.0f; v[r].y = 0.0f; v[r].z = 0.0f; v[r].w = 0.0f; }
-    issue(st, fm, TB);
-    for (;;) {                                                        // (wave-uniform)
+    // index 15 = the chip before the segment's first: the lowest one a row can ask for
+    const long long Abase = ra.out_abs0 + ((long long)w_begin - 10) * SPC;
+    const bool inside = wide && Abase >= ra.src_abs0 && Abase + (long long)(nw + 1u) * SPC <= ra.src_abs1;   // (uniform) every sample present, 16-byte aligned
+    unsigned long long gb = reinterpret_cast<unsigned long long>(iq2 + (inside ? Abase - ra.src_abs0 : 0));
+    gb = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gb >> 32)) << 32) |
+         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gb);   // (wave-uniform: the base stays in scalar registers)
+    constexpr int MAXR = AM_ROWS_SLOTS * 16 / AM_WAVE;                // rounds of 64 pieces that cover all row slots: 10
+    int lane_ = lane;
+    for (uint32_t b0 = (uint32_t)wv * AM_ROWS_BATCH; b0 < nf; b0 += (uint32_t)nwv * AM_ROWS_BATCH) {          // (wave-uniform)
 #if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(lane));                                // (nothing derived from the lane index is to live across iterations: registers)
-#endif
-        const long long chip0 = (long long)w_begin + (long long)st * AM_ROWS_STRIPE - 9;   // array chip of the stripe's first chip
-        const long long A0 = ra.out_abs0 + chip0 * SPC;
+        asm volatile("" : "+v"(lane_));                               // (nothing derived from the lane index is to live across batches: hoisted,
+#endif                                                                //  those addresses cost 40 registers and as many spills)
+        const int lane = lane_;
+        const int j = lane & (AM_ROWS_BATCH - 1), half = lane >> 5;
+        const int cnt = (nf - b0 < AM_ROWS_BATCH) ? (int)(nf - b0) : AM_ROWS_BATCH;
+        const bool live = j < cnt;
+        // the (b0 + j)-th wanted chip: the word by bisection of the prefix counts, the bit by bisection of the word
+        uint32_t ci;
         {
-            // |.|^2 of the needed rows into the wave's LDS rows
-            const unsigned char *tb = TB + par * 40;
-            const int np = __popcll(rows_needed(fm)) * 16;
-            if (inside_of(st)) {
+            const uint32_t r = b0 + (uint32_t)(live ? j : 0);
+            uint32_t lo = 0, hi = n64;                                // last word with PFX <= r
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (PFX[mid] <= r) lo = mid; else hi = mid;
+            }
+            uint32_t rr = r - PFX[lo];
+            unsigned long long y = FL[lo];
+            uint32_t pos = 0;
 #pragma unroll
-                for (int r = 0; r < MAXR; ++r) {
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                const unsigned long long lowpart = y & ((1ull << sh) - 1ull);
+                const uint32_t c = (uint32_t)__popcll(lowpart);
+                if (rr >= c) { rr -= c; y >>= sh; pos += (uint32_t)sh; } else y = lowpart;
+            }
+            ci = 64u * lo + pos;                                      // >= 16
+        }
+        // runs: the chip before chip j is lane j - 1's own chip unless a run starts at j.  Wanted chips come in runs of 17 and
+        // more (every candidate word flags 17 consecutive chips; only a segment's first run can be cut shorter), so 32 consecutive
+        // ones hold at most three run starts: the batch's first, the end of a cut first run, and one more 17 further on.
+        const uint32_t cprev = (uint32_t)__shfl((int)ci, (lane + AM_WAVE - 1) & (AM_WAVE - 1), AM_WAVE);
+        const bool start = live && (j == 0 || cprev + 1u != ci);
+        const uint32_t smask = (uint32_t)__ballot(start);            // (lanes 0..31; 32..63 hold the same chips)
+        int srank = __popc(smask & ((1u << j) - 1u));
+        srank = srank < AM_ROWS_XSTART ? srank : AM_ROWS_XSTART - 1;  // (never: see above)
+        const int nstart = PMF ? __popc(smask) : 0;
+        const int nrow = cnt + (nstart < AM_ROWS_XSTART ? nstart : AM_ROWS_XSTART);
+        __builtin_amdgcn_wave_barrier();                              // (RC / XR: the batch before is done with them)
+        if (half == 0 && live) {
+            RC[j] = (uint16_t)ci;
+            if (PMF && start) RC[cnt + srank] = (uint16_t)(ci - 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // |.|^2 of the rows: all loads of the batch in flight together
+        const int np = nrow * 16;
+        if (inside) {
+            float4 v[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                if (AM_WAVE * r < np) {                               // (uniform)
+                    const int p = lane + AM_WAVE * r;
+                    const int pc = p < np ? p : 0;                    // (a lane without a piece loads piece 0 again)
+                    const unsigned off = ((unsigned)RC[pc >> 4] - 15u) * (unsigned)(SPC * 8) + (unsigned)(pc & 15) * 16u;
+                    v[r] = fes_gload16_cached_at(gb, off);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                if (AM_WAVE * r < np) {                               // (uniform)
                     const int p = lane + AM_WAVE * r;
                     if (p < np) {
-                        const int row = (int)tb[p >> 4], k = p & 15;
                         const float r0 = v[r].x * v[r].x, i0 = v[r].y * v[r].y, r1 = v[r].z * v[r].z, i1 = v[r].w * v[r].w;
                         float2 mm;
                         mm.x = r0 + i0;                               // a1: fl(fl(I*I) + fl(Q*Q))
                         mm.y = r1 + i1;
-                        *reinterpret_cast<float2 *>(XR + row * AM_ROWS_XS + 2 * k) = mm;
+                        *reinterpret_cast<float2 *>(XR + (p >> 4) * AM_ROWS_XS + 2 * (p & 15)) = mm;
                     }
                 }
-            } else {
-                // stream edges / unaligned input: one sample at a time, zeros outside the stream (rare: kept small)
+            }
+        } else {
+            // stream edges / unaligned input: one sample at a time, zeros outside the stream (rare: kept small)
 #pragma unroll 1
-                for (int p = lane; p < np; p += AM_WAVE) {
-                    const int row = (int)tb[p >> 4], k = p & 15;
-                    const long long a = A0 + (long long)(row - 1) * SPC + 2 * k;      // absolute index of the piece's first sample
-                    float2 u0, u1;
-                    u0.x = 0.0f; u0.y = 0.0f; u1 = u0;
-                    if (a >= ra.src_abs0 && a < ra.src_abs1) u0 = iq2[a - ra.src_abs0];
-                    if (a + 1 >= ra.src_abs0 && a + 1 < ra.src_abs1) u1 = iq2[a + 1 - ra.src_abs0];
-                    const float r0 = u0.x * u0.x, i0 = u0.y * u0.y, r1 = u1.x * u1.x, i1 = u1.y * u1.y;
-                    float2 mm;
-                    mm.x = r0 + i0;
-                    mm.y = r1 + i1;
-                    *reinterpret_cast<float2 *>(XR + row * AM_ROWS_XS + 2 * k) = mm;
-                }
+            for (int p = lane; p < np; p += AM_WAVE) {
+                const long long a = Abase + ((long long)RC[p >> 4] - 15) * SPC + 2 * (p & 15);   // absolute index of the piece's first sample
+                float2 u0, u1;
+                u0.x = 0.0f; u0.y = 0.0f; u1 = u0;
+                if (a >= ra.src_abs0 && a < ra.src_abs1) u0 = iq2[a - ra.src_abs0];
+                if (a + 1 >= ra.src_abs0 && a + 1 < ra.src_abs1) u1 = iq2[a + 1 - ra.src_abs0];
+                const float r0 = u0.x * u0.x, i0 = u0.y * u0.y, r1 = u1.x * u1.x, i1 = u1.y * u1.y;
+                float2 mm;
+                mm.x = r0 + i0;
+                mm.y = r1 + i1;
+                *reinterpret_cast<float2 *>(XR + (p >> 4) * AM_ROWS_XS + 2 * (p & 15)) = mm;
             }
         }
-        // the next stripe's loads go out now: they fly while this one's rows are formed and stored
-        uint32_t fm_next = 0u;
-        const uint32_t st_next = next_stripe(st + (uint32_t)nwv, fm_next);
-        if (st_next < nstripes) issue(st_next, fm_next, TB + (par ^ 1) * 40);
         __builtin_amdgcn_wave_barrier();
-        // the row of chip t, canonical order, by TWO lanes: lane t forms the prefix sums of the own chip (row t + 1, left->right),
-        // lane t + 32 the suffix sums of the chip before (row t, right->left: it takes the row reversed, so both run the same
-        // chain), and lane t fetches what it needs across the wave: bb[i] = fl((suf[i + 1] + pre[i]) s1)
-        const int t = lane & (AM_ROWS_STRIPE - 1), half = lane >> 5;
-        const bool mine = ((fm >> t) & 1u) != 0u;
+        // positions beyond the end of the stream read as zero (the preamble view pads with zeros)
+        const long long leftn = ra.src_abs1 - (Abase + ((long long)ci - 15) * SPC);
+        const int nin = leftn >= SPC ? SPC : (leftn <= 0 ? 0 : (int)leftn);
         if (PMF) {
+            // lane j: prefix sums of the own chip (row j), left->right; lane j + 32: suffix sums of the chip before (the row
+            // reversed, so both run the same chain); bb[i] = fl((suf[i + 1] + pre[i]) s1)
             float c[SPC];
-            if (mine) {
-                const float4 *row = reinterpret_cast<const float4 *>(XR + (t + 1 - half) * AM_ROWS_XS);
+            if (live) {
+                const int slot = half ? (start ? cnt + srank : j - 1) : j;
+                const float4 *row = reinterpret_cast<const float4 *>(XR + slot * AM_ROWS_XS);
 #pragma unroll
                 for (int k = 0; k < SPC / 4; ++k) {
                     const float4 u = row[half ? SPC / 4 - 1 - k : k];
@@ -671,50 +689,41 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
                 }
                 float ap = 0.0f;
 #pragma unroll
-                for (int i = 0; i < SPC; ++i) { ap = ap + c[i]; c[i] = ap; }       // lane t: pre[i]; lane t + 32: suf[31 - i]
+                for (int i = 0; i < SPC; ++i) { ap = ap + c[i]; c[i] = ap; }       // lane j: pre[i]; lane j + 32: suf[31 - i]
             } else {
 #pragma unroll
                 for (int i = 0; i < SPC; ++i) c[i] = 0.0f;
             }
             __builtin_amdgcn_wave_barrier();                          // (every lane has read its row)
-            // positions beyond the end of the stream read as zero (the preamble view pads with zeros)
-            const long long leftn = ra.src_abs1 - (A0 + (long long)t * SPC);
-            const int nin = leftn >= SPC ? SPC : (leftn <= 0 ? 0 : (int)leftn);
-            float4 *own = reinterpret_cast<float4 *>(XR + (t + 1) * AM_ROWS_XS);
+            float4 *own = reinterpret_cast<float4 *>(XR + j * AM_ROWS_XS);
 #pragma unroll
             for (int k = 0; k < SPC / 4; ++k) {
                 float o4[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * k + j;
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 4 * k + q;
                     float tt = c[i];                                  // the chip's last sample: the window is the chip
                     if (i < SPC - 1) tt = __shfl(c[(i < SPC - 1) ? SPC - 2 - i : 0], lane ^ 32, AM_WAVE) + c[i];   // suf[i + 1] + pre[i]
-                    o4[j] = (i >= nin) ? 0.0f : tt * ra.s1;
+                    o4[q] = (i >= nin) ? 0.0f : tt * ra.s1;
                 }
-                if (mine && half == 0) { float4 o; o.x = o4[0]; o.y = o4[1]; o.z = o4[2]; o.w = o4[3]; own[k] = o; }
+                if (live && half == 0) { float4 o; o.x = o4[0]; o.y = o4[1]; o.z = o4[2]; o.w = o4[3]; own[k] = o; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);                    // (four positions at a time: hoisted, the 31 exchanges cost 31 registers more)
+#endif
             }
-        } else {
+        } else if (live && half == 0 && nin < SPC) {
             // no filter: bb is |.|^2 itself; only the end of the stream needs a hand
-            __builtin_amdgcn_wave_barrier();
-            const long long leftn = ra.src_abs1 - (A0 + (long long)t * SPC);
-            if (mine && half == 0 && leftn < SPC) {
-                const int nin = leftn <= 0 ? 0 : (int)leftn;
-                float *own = XR + (t + 1) * AM_ROWS_XS;
-                for (int i = nin; i < SPC; ++i) own[i] = 0.0f;
-            }
+            float *own = XR + j * AM_ROWS_XS;
+            for (int i = nin; i < SPC; ++i) own[i] = 0.0f;
         }
-        // the wanted rows leave eight per store instruction
-        unsigned char *const tf = TB + 2 * 40;
-        const int nf = __popc(fm);
-        if (mine && half == 0) tf[__popc(fm & ((1u << t) - 1u))] = (unsigned char)t;
         __builtin_amdgcn_wave_barrier();
+        // the rows leave eight per store instruction
         const int sub = lane >> 3, piece = lane & 7;
-        for (int r0 = 0; r0 < nf; r0 += 8) {                          // (uniform trip count)
+        for (int r0 = 0; r0 < cnt; r0 += 8) {                         // (uniform trip count)
             const int r = r0 + sub;
-            if (r < nf) {
-                const int t = (int)tf[r];
-                const float4 u = *reinterpret_cast<const float4 *>(XR + (t + 1) * AM_ROWS_XS + 4 * piece);
-                const long long rel = (chip0 + t) * SPC + 4 * piece;  // array coordinate
+            if (r < cnt) {
+                const float4 u = *reinterpret_cast<const float4 *>(XR + r * AM_ROWS_XS + 4 * piece);
+                const long long rel = ((long long)w_begin - 25 + (long long)RC[r]) * SPC + 4 * piece;   // array coordinate
                 if (rel >= 0 && rel + 4 <= ra.out_n) *reinterpret_cast<float4 *>(ra.bb_sparse + rel) = u;
                 else {
                     if (rel >= 0 && rel < ra.out_n) ra.bb_sparse[rel] = u.x;
@@ -724,14 +733,11 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
                 }
             }
         }
-        if (st_next >= nstripes) break;
-        __builtin_amdgcn_wave_barrier();                              // (the rows and the list of wanted rows are rewritten)
-        st = st_next; fm = fm_next; par ^= 1;
     }
 }
 
 template <int ROWS>       // 0: candidates only; 1 / 2: + the bb rows around them from IQ at 32 samples per chip (filter on / off)
-__global__ void __launch_bounds__(256, (ROWS ? 5 : 8))       // (with rows: five waves per SIMD, <= 102 VGPRs; left alone the compiler took 162)
+__global__ void __launch_bounds__(256, (ROWS ? AM_ROWS_WPS : 8))       // (with rows: five waves per SIMD, <= 102 VGPRs; left alone the compiler took 162)
 am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ wg_cnt, uint32_t nwg, uint32_t words_per_wg,
                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *__restrict__ pos,
                uint32_t *__restrict__ total_out, am_rows_args ra)
@@ -813,13 +819,14 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
     }
     if (g == nwg - 1u && threadIdx.x == 0) *total_out = run;
     if constexpr (ROWS != 0) {
-        __shared__ unsigned long long NZ[(AM_ROWS_MAXW + 16) / 64 + 2];
-        __shared__ unsigned long long FL[(AM_ROWS_MAXW + 16) / 64 + 2];
-        __shared__ __attribute__((aligned(16))) float XR[(256 / AM_WAVE) * (AM_ROWS_STRIPE + 1) * AM_ROWS_XS];
-        __shared__ unsigned char TB[(256 / AM_WAVE) * 3 * 40];
+        __shared__ unsigned long long NZ[AM_ROWS_NFL];
+        __shared__ unsigned long long FL[AM_ROWS_NFL];
+        __shared__ uint32_t PFX[AM_ROWS_NFL + 1];
+        __shared__ __attribute__((aligned(16))) float XR[(256 / AM_WAVE) * AM_ROWS_SLOTS * AM_ROWS_XS];
+        __shared__ uint16_t RC[(256 / AM_WAVE) * AM_ROWS_SLOTS];
         for (uint32_t wa = w_begin; wa < w_end; wa += AM_ROWS_MAXW) {   // (one pass at am_k_fe3's 14 x 96 words per workgroup)
             if (wa != w_begin) __syncthreads();                       // (the flags of the pass before are still being read)
-            am_rows_segment32<ROWS == 1>(ra, bits, wa, (wa + AM_ROWS_MAXW < w_end) ? wa + AM_ROWS_MAXW : w_end, NZ, FL, XR, TB);
+            am_rows_segment32<ROWS == 1>(ra, bits, wa, (wa + AM_ROWS_MAXW < w_end) ? wa + AM_ROWS_MAXW : w_end, NZ, FL, PFX, XR, RC);
         }
     }
 }
@@ -913,6 +920,7 @@ __device__ __forceinline__ uint32_t am_chain_place(uint32_t *ticket, uint32_t ba
     return *tick;
 }
 
+#if AM_WITH_TILE_KERNEL
 // exclusive scan of n counts in one launch: 2048 elements per workgroup, the offsets of the workgroups before it
 // through am_chain_prefix; *total_out = the sum of all counts
 __global__ void __launch_bounds__(256)
@@ -948,32 +956,6 @@ am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, u
 #pragma unroll
     for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = off; off += v[k]; }
     if (blk == gridDim.x - 1 && threadIdx.x == 0) *total_out = before + total;
-}
-
-// block-local exclusive scan (2048 elements per workgroup) + block totals
-__global__ void __launch_bounds__(256)
-am_k_exscan_blocks(const uint32_t *__restrict__ in, uint32_t *__restrict__ out_local, uint32_t *__restrict__ blk_tot,
-                   uint32_t ncap, const uint32_t *__restrict__ Mp)
-{
-    const uint32_t n = am_count(ncap, Mp);
-    __shared__ uint32_t ws[256 / AM_WAVE];
-    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
-    const uint32_t base = blockIdx.x * AM_SCAN_BLK + threadIdx.x * 8;
-    uint32_t v[8], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
-    uint32_t incl = sum;
-    for (int d = 1; d < AM_WAVE; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
-        if (lane >= d) incl += up;
-    }
-    if (lane == AM_WAVE - 1) ws[wv] = incl;
-    __syncthreads();
-    uint32_t off = incl - sum, total = 0;
-    for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) off += ws[k]; total += ws[k]; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { if (base + k < n) out_local[base + k] = off; off += v[k]; }
-    if (threadIdx.x == 0) blk_tot[blockIdx.x] = total;
 }
 
 __device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_local,
@@ -1069,6 +1051,7 @@ am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, cons
     }
 }
 
+#endif  // AM_WITH_TILE_KERNEL
 __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ pos, uint32_t lo,
                                                    uint32_t hi, uint32_t key)
 {
@@ -1083,6 +1066,7 @@ __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ 
     return l;
 }
 
+#if AM_WITH_TILE_KERNEL
 __global__ void __launch_bounds__(256)
 am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
           const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ off_local,
@@ -1147,6 +1131,7 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
     }
 }
 
+#endif  // AM_WITH_TILE_KERNEL
 // The refinement behind the streaming front ends in ONE launch (round 4): late-peak decisions and the per-candidate test
 // of am_k_energy (late mode) + am_k_cand, per group of AM_RCB consecutive candidates.  The decisions never leave LDS, and
 // with them went the global compact layout: no distance-to-the-predecessor array, no scan of it (two launches fewer, and
@@ -1311,6 +1296,7 @@ hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const
     return hipGetLastError();
 }
 
+#if AM_WITH_TILE_KERNEL
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
                                 uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
                                 hipStream_t s, const uint32_t *Mp)
@@ -1318,14 +1304,6 @@ hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, co
     if (M == 0 || nseg == 0) return hipSuccess;
     hipLaunchKernelGGL(am_k_gather_pos, dim3(nseg), dim3(128), 0, s, seg_pos, seg_stride, blk_off, nseg, M, spc, pos,
                        dcount, Mp);
-    return hipGetLastError();
-}
-hipError_t am_launch_exscan_blocks(const uint32_t *in, uint32_t *out_local, uint32_t *blk_tot, uint32_t n,
-                                   hipStream_t s, const uint32_t *Mp)
-{
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_exscan_blocks, dim3((n + AM_SCAN_BLK - 1) / AM_SCAN_BLK), dim3(256), 0, s, in,
-                       out_local, blk_tot, n, Mp);
     return hipGetLastError();
 }
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
@@ -1360,6 +1338,7 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
                        blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp);
     return hipGetLastError();
 }
+#endif  // AM_WITH_TILE_KERNEL
 
 // ------------------------------------------------------------------------------------------
 // Greedy chain.  The reference scan visits candidates in position order; after visiting c it
@@ -2512,41 +2491,32 @@ __device__ __forceinline__ float am_soft_chip_iq(const float *__restrict__ iq, l
 // E[(s >> 5) * 36 + (s & 31)] = |.|^2 of sample B0 + s.  The source is read 16 bytes at a time: from the even sample at or
 // before B0 (one more piece, by thread 0, where B0 is odd).
 #define AM_XROW 36
-#ifndef AM_XTAIL_EARLY
-#define AM_XTAIL_EARLY 1                  /* tuning builds: 0 = a long packet's chips 128.. are loaded behind the long / short decision (round 4) */
-#endif
-// (loads and LDS stores apart: the kernel issues the loads of a burst's chips 128..239 together with those of chips 0..127 and
-// holds them in registers until the first five bits say whether the packet is a long one -- round 5: a long packet no longer pays a
-// second memory round trip behind the decision)
+// (Round 5: the loads of a burst's chips 128..239 issued together with those of chips 0..127 and held in registers until the first
+// five bits say whether the packet is a long one -- no second memory round trip behind the decision -- measured 43.8 against 40.0 us
+// at the bench density, 20.9 against 18.7 at 2 000 bursts/s: 28 more registers and 47 % more bytes for every short packet cost more
+// than the round trip; profiles/r5_fe64.  Not kept.)
 template <int NS>
-struct am_energy_regs { float4 v[NS / 512]; float4 vx; };
-template <int NS>
-__device__ __forceinline__ void am_load_energies32(const float *__restrict__ iq, long long src_abs0, long long B0, int tid, am_energy_regs<NS> &R)
+__device__ __forceinline__ void am_stage_energies32(const float *__restrict__ iq, long long src_abs0, long long B0, float *E, int tid)
 {
     static_assert(NS % 512 == 0, "whole rounds of 256 threads x 2 samples");
     constexpr int ROUNDS = NS / 512;
     const int odd = (int)((B0 - src_abs0) & 1);
     const float4 *src = reinterpret_cast<const float4 *>(iq) + ((B0 - odd - src_abs0) >> 1);
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) R.v[r] = src[tid + 256 * r];
-    R.vx.x = R.vx.y = R.vx.z = R.vx.w = 0.0f;
-    if (odd && tid == 0) R.vx = src[NS / 2];                          // (the last sample's piece)
-}
-template <int NS>
-__device__ __forceinline__ void am_store_energies32(long long src_abs0, long long B0, float *E, int tid, const am_energy_regs<NS> &R)
-{
-    constexpr int ROUNDS = NS / 512;
-    const int odd = (int)((B0 - src_abs0) & 1);
     const int i0 = 2 * tid - odd, i1 = i0 + 1;                        // samples of the thread's piece in round 0 (i0 = -1: not wanted)
     float *const e0 = E + (i0 >> 5) * AM_XROW + (i0 & 31);            // (arithmetic shift: -1 -> row -1, column 31: right from round 1 on)
     float *const e1 = E + (i1 >> 5) * AM_XROW + (i1 & 31);
+    float4 v[ROUNDS], vx;
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) v[r] = src[tid + 256 * r];
+    vx.x = vx.y = vx.z = vx.w = 0.0f;
+    if (odd && tid == 0) vx = src[NS / 2];                            // (the last sample's piece)
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const float a = R.v[r].x * R.v[r].x, b = R.v[r].y * R.v[r].y, c = R.v[r].z * R.v[r].z, d = R.v[r].w * R.v[r].w;
+        const float a = v[r].x * v[r].x, b = v[r].y * v[r].y, c = v[r].z * v[r].z, d = v[r].w * v[r].w;
         if (r > 0 || i0 >= 0) e0[r * 16 * AM_XROW] = a + b;           // a1: fl(fl(I*I) + fl(Q*Q))
         e1[r * 16 * AM_XROW] = c + d;
     }
-    if (odd && tid == 0) { const float a = R.vx.x * R.vx.x, b = R.vx.y * R.vx.y; E[((NS - 1) >> 5) * AM_XROW + 31] = a + b; }
+    if (odd && tid == 0) { const float a = vx.x * vx.x, b = vx.y * vx.y; E[((NS - 1) >> 5) * AM_XROW + 31] = a + b; }
 }
 // soft chip of the window in LDS row `row` (bb; the reference level comes off later): ii = offset of the burst's first sample
 // inside its canonical chip, the same for all of a burst's windows
@@ -2617,15 +2587,9 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         AM_XSTAMP(0);
         const bool staged = SPC == 32 && inside;                              // (uniform) coalesced loads through LDS
         const int ii = (int)(ae % SPC);
-        am_energy_regs<(SPC == 32 ? (AM_BURST - HEAD) * 32 : 512)> tailr;    // chips 128.. on their way (64 Msps)
         if constexpr (SPC == 32) {
             if (staged) {
-                am_energy_regs<HEAD * 32> headr;
-                am_load_energies32<HEAD * 32>(iq, src_abs0, ae - (SPC - 1), tid, headr);
-#if AM_XTAIL_EARLY
-                am_load_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, tid, tailr);
-#endif
-                am_store_energies32<HEAD * 32>(src_abs0, ae - (SPC - 1), stg, tid, headr);
+                am_stage_energies32<HEAD * 32>(iq, src_abs0, ae - (SPC - 1), stg, tid);
                 __syncthreads();
             }
         }
@@ -2641,10 +2605,7 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         const bool all = bursts_out != nullptr || am_burst_is_long(sb);       // (uniform)
         if constexpr (SPC == 32) {
             if (staged && all) {                                              // (the rows' readers are behind the barrier above)
-#if !AM_XTAIL_EARLY
-                am_load_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, tid, tailr);
-#endif
-                am_store_energies32<(AM_BURST - HEAD) * 32>(src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, stg, tid, tailr);
+                am_stage_energies32<(AM_BURST - HEAD) * 32>(iq, src_abs0, ae - (SPC - 1) + (long long)HEAD * SPC, stg, tid);
                 __syncthreads();
             }
         }

@@ -58,9 +58,12 @@ def test_fractional_samples_per_chip(lib, rate, n, lam):
     assert pc.check_sharded(lib, rate, iq, 3) > 20
 
 
-def test_tiled_fused_kernel_still_matches(lib, monkeypatch):
+def test_tiled_fused_kernel_still_matches(klib, lib, monkeypatch):
+    """The tile kernel am_k_fe2 (dense bb / reference level for the block-level API) lives in the TEST builds only since round 5
+    (-DAM_WITH_TILE_KERNEL); the product library serves am_frontend_work from the rate-generic kernel: both, stage by stage."""
     for rate, n in ((16e6, 2000000), (20e6, 2000000), (64e6, 6000000)):
-        assert pc.check_stages(lib, rate, n, 6000.0, 51) > 3
+        assert pc.check_stages(klib, rate, n, 6000.0, 51) > 3
+    assert pc.check_stages(lib, 64e6, 3000000, 6000.0, 52) > 3
 
 
 def test_generic_kernels_still_match(klib, monkeypatch):

@@ -14,7 +14,7 @@ set -e
 cd "$(dirname "$0")/../gr-air-modes_amd/csrc"
 mkdir -p ../../build/var
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -mllvm -amdgpu-sched-strategy=iterative-ilp -shared -I. -I../../include"
-SRC="am_kernels.hip am_fe2.hip am_fe3.hip am_fe4.hip am_dcblock.hip am_resample.hip am_capi.hip"
+SRC="am_kernels.hip am_fe3.hip am_fe4.hip am_dcblock.hip am_resample.hip am_capi.hip"
 if [ -n "$NAME" ]; then
   /opt/rocm/bin/hipcc $FLAGS $DEFS -o ../../build/var/lib_$NAME.so $SRC
 else
