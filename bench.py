@@ -220,6 +220,8 @@ def main():
             extra["pipelined"] = {"batches_in_flight": PIPE_DEPTH, "host_threads": 1, "batches": PIPE_BATCHES,
                                   "value": n * PIPE_BATCHES / dt3,
                                   "unit": "samples/s", "ms_per_step": dt3 / PIPE_BATCHES * 1e3,
+                                  # the whole path priced like the kernel: algorithmic bytes per batch / time per batch / HBM peak
+                                  "path_frac_of_hbm_peak": 8.0 * n * PIPE_BATCHES / dt3 / 1e9 / HBM_PEAK_GBS,
                                   "same_packet_counts": counts3 == [per_batch[k % nb] for k in range(PIPE_BATCHES)],
                                   "same_packets_last_batch": bool(np.array_equal(last3, want_last))}
             pipe.close()
@@ -437,7 +439,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel_ms": fe_avg_ms,
                          "kernel_ms_per_rank": {"min": min(fe_ranks), "max": max(fe_ranks)},
-                         "algorithmic_bytes_per_launch": 8 * n},
+                         "algorithmic_bytes_per_launch": 8 * n,
+                         # the whole path (all launches of a step, the host's turn-around included) priced the same way:
+                         # algorithmic bytes per step / driver-timed step / HBM peak -- NOT the kernel's fraction
+                         "path_frac_of_hbm_peak": 8.0 * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
         coll = None
         if world > 1:

@@ -192,10 +192,12 @@ struct am_entry_src {
 
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
-                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
+                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint4 *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch, uint32_t *ticket, uint32_t *ticket_base,
                                  uint32_t *scalars, int want_resume,
-                                 hipStream_t s, const uint32_t *Mp = nullptr, const am_entry_src *entry_src = nullptr);
+                                 hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src, const float *inavg);
+/* (emit_idx: one 16-byte record per hit -- candidate index, first-stage position, refined position, reference level -- so that
+ * the extraction kernels fetch a hit with one load) */
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */
 hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, uint32_t M, uint32_t n,
                                       uint32_t lead_end, uint32_t *scratch, uint64_t base_abs, am_shard_exit *table,
@@ -223,7 +225,7 @@ struct am_time_tag {
 /* chip_idx: device table of the 240 soft chips' sample offsets int(j * samples per chip) (null: j * spc); hist0: history
  * items of the preamble block (the tag's item count = stream index + hist0) */
 hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const int *chip_idx, int hist0,
-                                   const uint32_t *emit_idx,
+                                   const uint4 *emit_idx,
                                    const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
                                    uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
                                    uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,
@@ -231,7 +233,7 @@ hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc,
                                    const uint32_t *Mp = nullptr);
 /* the same when bb exists only around the candidates: the burst is recomputed from IQ (iq[0] = absolute sample src_abs0) */
 hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
-                                      const float *inavg, int spc, const uint32_t *emit_idx, const uint32_t *n_ptr,
+                                      const float *inavg, int spc, const uint4 *emit_idx, const uint32_t *n_ptr,
                                       uint32_t n_max, const uint32_t *pos, const uint32_t *e, uint64_t base_abs,
                                       uint64_t rate, const am_time_tag *tt, uint32_t ntt, float *bursts_out,
                                       am_tag *tags_out, const uint32_t *crc_pow, am_packet *packets,

@@ -506,12 +506,14 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 #define AM_ROWS_XS 36                     /* floats per LDS row: 32 + 4 pad */
 #define AM_ROWS_BBW 17                    /* chips of bb the refinement reads from a candidate's chip on */
 #define AM_ROWS_MAXW 2048                 /* bitmap words per pass of a workgroup (am_k_fe3: 14 x 96 words per workgroup) */
-#define AM_ROWS_BATCH 32                  /* wanted chips a wave takes at a time */
+#ifndef AM_ROWS_BATCH
+#define AM_ROWS_BATCH 32                  /* wanted chips a wave takes at a time (<= 32: lane j and lane j + 32 share a chip) */
+#endif
 #define AM_ROWS_XSTART 8                  /* rows for the chip before a run's first (a batch holds at most 3 run starts: see below) */
 #define AM_ROWS_SLOTS (AM_ROWS_BATCH + AM_ROWS_XSTART)
 #define AM_ROWS_NFL ((AM_ROWS_MAXW + 16) / 64 + 2)
 #ifndef AM_ROWS_WPS
-#define AM_ROWS_WPS 5                     /* waves per SIMD the gather + rows kernel is compiled for (<= 102 VGPRs: a batch's 40 loads in flight, then a 32-register chain) */
+#define AM_ROWS_WPS 6                     /* waves per SIMD the gather + rows kernel is compiled for: all of am_k_fe3's 1 489 segments resident at once (67 VGPRs, 24 KB of LDS) */
 #endif
 
 // rows of the chips [w_begin - 9, w_end - 9) that some candidate in the words [w_begin - 16, w_end) asks for.  All threads of the
@@ -590,7 +592,7 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
         asm volatile("" : "+v"(lane_));                               // (nothing derived from the lane index is to live across batches: hoisted,
 #endif                                                                //  those addresses cost 40 registers and as many spills)
         const int lane = lane_;
-        const int j = lane & (AM_ROWS_BATCH - 1), half = lane >> 5;
+        const int j = lane & 31, half = lane >> 5;
         const int cnt = (nf - b0 < AM_ROWS_BATCH) ? (int)(nf - b0) : AM_ROWS_BATCH;
         const bool live = j < cnt;
         // the (b0 + j)-th wanted chip: the word by bisection of the prefix counts, the bit by bisection of the word
@@ -633,26 +635,24 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
         const int np = nrow * 16;
         if (inside) {
             float4 v[MAXR];
+            // (straight-line: a lane without a piece loads piece 0 again -- with a branch per round the register allocator
+            // spilled the first loads right behind their issue, one memory round trip each)
 #pragma unroll
             for (int r = 0; r < MAXR; ++r) {
-                if (AM_WAVE * r < np) {                               // (uniform)
-                    const int p = lane + AM_WAVE * r;
-                    const int pc = p < np ? p : 0;                    // (a lane without a piece loads piece 0 again)
-                    const unsigned off = ((unsigned)RC[pc >> 4] - 15u) * (unsigned)(SPC * 8) + (unsigned)(pc & 15) * 16u;
-                    v[r] = fes_gload16_cached_at(gb, off);
-                }
+                const int p = lane + AM_WAVE * r;
+                const int pc = p < np ? p : 0;
+                const unsigned off = ((unsigned)RC[pc >> 4] - 15u) * (unsigned)(SPC * 8) + (unsigned)(pc & 15) * 16u;
+                v[r] = fes_gload16_cached_at(gb, off);
             }
 #pragma unroll
             for (int r = 0; r < MAXR; ++r) {
-                if (AM_WAVE * r < np) {                               // (uniform)
-                    const int p = lane + AM_WAVE * r;
-                    if (p < np) {
-                        const float r0 = v[r].x * v[r].x, i0 = v[r].y * v[r].y, r1 = v[r].z * v[r].z, i1 = v[r].w * v[r].w;
-                        float2 mm;
-                        mm.x = r0 + i0;                               // a1: fl(fl(I*I) + fl(Q*Q))
-                        mm.y = r1 + i1;
-                        *reinterpret_cast<float2 *>(XR + (p >> 4) * AM_ROWS_XS + 2 * (p & 15)) = mm;
-                    }
+                const int p = lane + AM_WAVE * r;
+                if (p < np) {
+                    const float r0 = v[r].x * v[r].x, i0 = v[r].y * v[r].y, r1 = v[r].z * v[r].z, i1 = v[r].w * v[r].w;
+                    float2 mm;
+                    mm.x = r0 + i0;                                   // a1: fl(fl(I*I) + fl(Q*Q))
+                    mm.y = r1 + i1;
+                    *reinterpret_cast<float2 *>(XR + (p >> 4) * AM_ROWS_XS + 2 * (p & 15)) = mm;
                 }
             }
         } else {
@@ -1808,10 +1808,13 @@ am_k_cblk_exit_table(const uint32_t *__restrict__ pos, const uint32_t *__restric
 struct am_emit_args {
     const uint8_t *valid;
     const uint32_t *pos, *e, *tgt;
+    const float *inavg;             // reference level of every candidate (goes into the hit records)
     uint32_t emit_max;              // room rule (:212): a valid hit too close to the end of the stream is not
                                     // emitted (and nothing after it can be)
     uint32_t own_lo, own_hi;        // first-stage positions this GPU's time chunk owns (everything on one GPU)
-    uint32_t *emit_idx;             // out: the candidates to extract, in position order
+    uint4 *emit_idx;                // out: the candidates to extract, in position order: {candidate index, first-stage position,
+                                    // refined position, reference level (bits)} -- everything the extraction kernels need of a hit
+                                    // in ONE load (round 5: index -> e / inavg / pos was a dependent memory round trip per hit)
     uint32_t *n_out;                // out: how many
     unsigned long long *slots;      // chained scan of the per-block hit counts (am_chain_prefix)
     uint32_t epoch;
@@ -1843,6 +1846,10 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
     const uint32_t ent = (base < M) ? entry[blk] : AM_CB_NONE;
     const int lane = threadIdx.x & (AM_WAVE - 1), w = threadIdx.x / AM_WAVE;
     uint32_t embits = 0, tmax = 0;                            // bit k: node threadIdx.x + k * AM_CB_THREADS is a hit
+    uint32_t hp[AM_CB_PER], he[AM_CB_PER];                    // position / refined position / reference level of the thread's nodes
+    float hav[AM_CB_PER];                                     // (what a hit's record carries; loaded with the flags below)
+#pragma unroll
+    for (int k = 0; k < AM_CB_PER; ++k) { hp[k] = 0u; he[k] = 0u; hav[k] = 0.0f; }
     if (ent != AM_CB_NONE) {                                  // (uniform; otherwise the scan jumps over this block or nothing is here)
         const uint32_t end = (base + AM_CB < M) ? base + AM_CB : M;
         const uint32_t n = end - base;
@@ -1929,12 +1936,14 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
             va[k] = ea.valid[g];
             ee[k] = ea.e[g];
             tg[k] = ea.tgt[g];
+            hav[k] = ea.inavg[g];
         }
 #pragma unroll
         for (int k = 0; k < AM_CB_PER; ++k) {
             const bool em = vis[k] && va[k] != 0 && ee[k] <= ea.emit_max && p[k] >= ea.own_lo && p[k] < ea.own_hi;
             if (vis[k] && ea.want_resume) tmax = tg[k] > tmax ? tg[k] : tmax;
             if (em) embits |= 1u << k;
+            hp[k] = p[k]; he[k] = ee[k];
         }
     }
     AM_MSTAMP();                                              // 4 (or 1): hits known
@@ -1968,12 +1977,18 @@ am_k_cblk_mark(const uint32_t *__restrict__ jump0, const uint32_t *__restrict__ 
         return;
     }
     uint32_t off = before;
+#pragma unroll
     for (int k = 0; k < AM_CB_PER; ++k) {
         const bool em = ((embits >> k) & 1u) != 0u;
         const unsigned long long m = __ballot(em);
         uint32_t o = off;
         for (int q = 0; q < w; ++q) o += wc[k][q];
-        if (em) ea.emit_idx[o + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + threadIdx.x + (uint32_t)k * AM_CB_THREADS;
+        if (em) {
+            const uint32_t g = base + threadIdx.x + (uint32_t)k * AM_CB_THREADS;
+            uint4 rec;
+            rec.x = g; rec.y = hp[k]; rec.z = he[k]; rec.w = __float_as_uint(hav[k]);
+            ea.emit_idx[o + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = rec;
+        }
         for (int q = 0; q < AM_CB_THREADS / AM_WAVE; ++q) off += wc[k][q];
     }
     if (blk == gridDim.x - 1 && threadIdx.x == 0) *ea.n_out = before + tot;
@@ -2067,9 +2082,10 @@ hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uin
 // emit_idx[0 .. *n_out) = the hits in position order, scalars[0] = resume position
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
                                  uint32_t *scratch, const uint8_t *valid, const uint32_t *e, const uint32_t *tgt,
-                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint32_t *emit_idx, uint32_t *n_out,
+                                 uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint4 *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch, uint32_t *ticket, uint32_t *ticket_base,
-                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src)
+                                 uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src,
+                                 const float *inavg)
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -2084,7 +2100,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp, es);
     am_emit_args ea;
-    ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.emit_max = emit_max; ea.own_lo = own_lo;
+    ea.valid = valid; ea.pos = pos; ea.e = e; ea.tgt = tgt; ea.inavg = inavg; ea.emit_max = emit_max; ea.own_lo = own_lo;
     ea.own_hi = own_hi; ea.emit_idx = emit_idx; ea.n_out = n_out; ea.slots = slots; ea.epoch = epoch; ea.scalars = scalars;
     ea.want_resume = want_resume;
     ea.ticket = ticket; ea.ticket_base = *ticket_base;
@@ -2317,7 +2333,7 @@ am_k_slice(const float *__restrict__ bursts, const am_tag *__restrict__ tags, co
 __global__ void __launch_bounds__(256)
 am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg, int spc,
                    const int *__restrict__ chip_idx, int hist0,
-                   const uint32_t *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr,
+                   const uint4 *__restrict__ emit_idx, const uint32_t *__restrict__ n_ptr,
                    const uint32_t *__restrict__ pos, const uint32_t *__restrict__ eo, uint64_t base_abs,
                    long long e_off, uint64_t rate, const am_time_tag *__restrict__ tt, uint32_t ntt,
                    float *__restrict__ bursts_out, am_tag *__restrict__ tags_out,
@@ -2335,10 +2351,11 @@ am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg
         host_out[5] = scalars[9];                             // a chained scan of this step gave up (am_chain_prefix)
     }
     if (i >= *n_ptr) return;                              // wave-uniform; device-side hit count
-    const uint32_t g = emit_idx[i];
-    const uint32_t e = eo[g];
+    const uint4 rec = emit_idx[i];                          // {candidate, first-stage position, refined position, reference level}
+    const uint32_t g = rec.x;
+    const uint32_t e = rec.z;
     const size_t ei = (size_t)((long long)e + e_off);      // index of e in this GPU's bb/avg
-    const float av = inavg[g];                              // reference level at the shifted start
+    const float av = __uint_as_float(rec.w);                // reference level at the shifted start
     for (int c = lane; c < AM_BURST; c += AM_WAVE) {
         const float v = bb[ei + (size_t)(chip_idx ? chip_idx[c] : c * spc)] - av;    // preamble_impl.cc:219-221: in[i + int(j * spc)]
         sb[wv][c] = v;
@@ -2353,7 +2370,7 @@ am_k_extract_slice(const float *__restrict__ bb, const float *__restrict__ inavg
 }
 
 hipError_t am_launch_extract_slice(const float *bb, const float *inavg, int spc, const int *chip_idx, int hist0,
-                                   const uint32_t *emit_idx,
+                                   const uint4 *emit_idx,
                                    const uint32_t *n_ptr, uint32_t n_max, const uint32_t *pos, const uint32_t *e,
                                    uint64_t base_abs, long long e_off, uint64_t rate, const am_time_tag *tt,
                                    uint32_t ntt, float *bursts_out, am_tag *tags_out, const uint32_t *crc_pow,
@@ -2537,10 +2554,13 @@ __device__ __forceinline__ float am_soft_chip_row32(const float *E, int row, int
     return (ii == SPC - 1) ? pre * s1 : (suf + pre) * s1;
 }
 
+#ifndef AM_XS_WPS
+#define AM_XS_WPS 8                       /* waves per SIMD the extraction kernel is compiled for (64 VGPRs, no spills: eight workgroups per CU, 2 048 hits in flight) */
+#endif
 template <int SPC>
-__global__ void __launch_bounds__(256, 5)
+__global__ void __launch_bounds__(256, AM_XS_WPS)
 am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
-                      const float *__restrict__ inavg, const uint32_t *__restrict__ emit_idx,
+                      const float *__restrict__ inavg, const uint4 *__restrict__ emit_idx,
                       const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ pos,
                       const uint32_t *__restrict__ eo, uint64_t base_abs, uint64_t rate,
                       const am_time_tag *__restrict__ tt, uint32_t ntt, float *__restrict__ bursts_out,
@@ -2575,9 +2595,9 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     // (Taking a hit's candidate index, refined position, reference level and first-stage position one hit AHEAD, so that
     // those two dependent round trips ride along with the current hit's sample loads, changed nothing: 54.8 against 54.7 us.)
     for (uint32_t i = blockIdx.x; i < nhit; i += gridDim.x) {                 // (uniform)
-        const uint32_t g = emit_idx[i];
-        const uint32_t e = eo[g];
-        const float av = inavg[g];
+        const uint4 rec = emit_idx[i];                                        // one load per hit (am_k_cblk_mark filed everything)
+        const uint32_t e = rec.z;
+        const float av = __uint_as_float(rec.w);
         const long long ae = (long long)base_abs + (long long)e;             // absolute index of the burst's first sample
         // (uniform) every lane's loads inside the source: all but the hits at the two ends of the stream
         const bool inside = pmf && wide && ae - SPC >= src_abs0 && ae + (long long)(AM_BURST - 1) * SPC + 2 < src_abs1;
@@ -2623,7 +2643,7 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
         if (tid < AM_WAVE) {
             am_tag t = am_make_tag(base_abs + e + (uint64_t)(2 * SPC - 1), rate, tt, ntt);
             t.inavg = av;
-            t.how_late = e - pos[g];
+            t.how_late = e - rec.y;
             if (tags_out && tid == 0) tags_out[i] = t;
             am_slice_wave(sb, t, i, lane, crc_pow, packets);
         }
@@ -2642,7 +2662,7 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
 }
 
 hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long long src_abs1, int use_pmf, float s1,
-                                      const float *inavg, int spc, const uint32_t *emit_idx, const uint32_t *n_ptr,
+                                      const float *inavg, int spc, const uint4 *emit_idx, const uint32_t *n_ptr,
                                       uint32_t n_max, const uint32_t *pos, const uint32_t *e, uint64_t base_abs,
                                       uint64_t rate, const am_time_tag *tt, uint32_t ntt, float *bursts_out,
                                       am_tag *tags_out, const uint32_t *crc_pow, am_packet *packets,
