@@ -519,10 +519,45 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 // rows of the chips [w_begin - 9, w_end - 9) that some candidate in the words [w_begin - 16, w_end) asks for.  All threads of the
 // workgroup call it (three barriers in front, none after).  NZ / FL: AM_ROWS_NFL words each; PFX: AM_ROWS_NFL + 1; XR: AM_ROWS_SLOTS
 // rows per wave; RC: AM_ROWS_SLOTS entries per wave.
+// the words [w_begin - 16, w_end) as the flags want them: word index i = (wave + 4 q) * 64 + lane of a 256-thread workgroup
+#define AM_ROWS_NCH ((AM_ROWS_NFL + 3) / 4)                  /* chunks of 64 words per wave, four waves: 9 */
+struct am_rows_words { uint32_t w[AM_ROWS_NCH]; };
+// (two halves: the loads -- unconditional, from clamped indices, all in flight together -- and, where the caller has something else
+// to wait for first, the masking.  Written as `valid ? bits[w] : 0` each load sat behind its own branch and was waited for on the
+// spot -- the compiler keeps only "word != 0" --: nine serial memory round trips)
+__device__ __forceinline__ void am_rows_issue_words(const uint32_t *__restrict__ bits, uint32_t w_begin, uint32_t w_end, am_rows_words &x)
+{
+    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE, nwv = blockDim.x / AM_WAVE;
+#pragma unroll
+    for (int q = 0; q < AM_ROWS_NCH; ++q) {
+        const uint32_t i = ((uint32_t)wv + (uint32_t)q * (uint32_t)nwv) * AM_WAVE + (uint32_t)lane;
+        const long long w = (long long)w_begin - 16 + (long long)i;
+        const long long wc = w < 0 ? 0 : (w >= (long long)w_end ? (long long)w_end - 1 : w);
+        x.w[q] = bits[wc];
+    }
+}
+__device__ __forceinline__ void am_rows_finish_words(uint32_t w_begin, uint32_t w_end, am_rows_words &x)
+{
+    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE, nwv = blockDim.x / AM_WAVE;
+    const uint32_t nidx = w_end - w_begin + 16u;
+#pragma unroll
+    for (int q = 0; q < AM_ROWS_NCH; ++q) {
+        AM_PIN_U32(x.w[q]);
+        const uint32_t i = ((uint32_t)wv + (uint32_t)q * (uint32_t)nwv) * AM_WAVE + (uint32_t)lane;
+        const long long w = (long long)w_begin - 16 + (long long)i;
+        if (!(i < nidx && w >= 0)) x.w[q] = 0u;
+    }
+}
+__device__ __forceinline__ void am_rows_load_words(const uint32_t *__restrict__ bits, uint32_t w_begin, uint32_t w_end, am_rows_words &x)
+{
+    am_rows_issue_words(bits, w_begin, w_end, x);
+    am_rows_finish_words(w_begin, w_end, x);
+}
+
 template <bool PMF>
 __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const uint32_t *__restrict__ bits, uint32_t w_begin,
                                                   uint32_t w_end, unsigned long long *NZ, unsigned long long *FL, uint32_t *PFX,
-                                                  float *XR_all, uint16_t *RC_all)
+                                                  float *XR_all, uint16_t *RC_all, const am_rows_words &early, bool use_early)
 {
     constexpr int SPC = 32;
     const int tid = threadIdx.x, nwv = blockDim.x / AM_WAVE;
@@ -532,20 +567,15 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
     const uint32_t nidx = nw + 16u;                                   // index i <-> word w_begin - 16 + i <-> array chip w_begin - 25 + i
     const uint32_t n64 = (nidx + 63u) >> 6;
     // which words hold a candidate (one bit per word; a wave's ballot is 64 of them).  The loads of all of a wave's chunks go
-    // out together (a load and its ballot per iteration were six serial memory round trips: ~12 us of this kernel)
+    // out together (a load and its ballot per iteration were six serial memory round trips: ~12 us of this kernel) -- for the
+    // workgroup's first pass at the very start of the kernel, under the listing of the candidates (`early`)
     {
-        constexpr int NCH = (AM_ROWS_NFL + 3) / 4;                    // chunks of 64 words per wave, four waves: 9
-        uint32_t x[NCH];
+        am_rows_words x = early;
+        if (!use_early) am_rows_load_words(bits, w_begin, w_end, x);   // (uniform; a workgroup's later passes: test builds only)
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) {
-            const uint32_t i = ((uint32_t)wv + (uint32_t)q * (uint32_t)nwv) * AM_WAVE + (uint32_t)lane;
-            const long long w = (long long)w_begin - 16 + (long long)i;
-            x[q] = (i < nidx && w >= 0) ? bits[w] : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < NCH; ++q) {
+        for (int q = 0; q < AM_ROWS_NCH; ++q) {
             const uint32_t c = (uint32_t)wv + (uint32_t)q * (uint32_t)nwv;
-            const unsigned long long m = __ballot(x[q] != 0u);
+            const unsigned long long m = __ballot(x.w[q] != 0u);
             if (lane == 0 && c < n64) NZ[c] = m;
         }
     }
@@ -748,23 +778,37 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
     const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
     const uint32_t w_begin = g * words_per_wg;
     const uint32_t w_end = (w_begin + words_per_wg < nwords) ? w_begin + words_per_wg : nwords;
-    const bool vec = (reinterpret_cast<uintptr_t>(bits + w_begin) & 15u) == 0;   // (uniform)
-    auto load4 = [&](uint32_t w0, uint32_t *x) __attribute__((always_inline)) {
-        x[0] = x[1] = x[2] = x[3] = 0u;
-        if (vec && w0 + 4u <= w_end) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(bits + w0);
-            x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-        } else {
+    // (uniform) 16-byte loads: the segment starts on a 16-byte boundary and is a whole number of four-word groups (always, for the
+    // streaming front ends' bitmaps: 96 or 128 words per step)
+    const bool vec = (reinterpret_cast<uintptr_t>(bits + w_begin) & 15u) == 0 && ((w_end - w_begin) & 3u) == 0u;
+    // The load and, apart from it, what depends on it.  The 16-byte load is UNCONDITIONAL (a lane without a group loads the
+    // segment's first one again; a segment that does not qualify loads from the 16-byte boundary below it and throws the result
+    // away): round 5 found that written as `if (vec && inside) load16; else guarded loads` each of the two rounds below was waited
+    // for on the spot (the join of the two paths does not know which loads are in flight) -- the "one memory round trip in front of
+    // the arithmetic" of round 4 was three in the machine code.
+    auto issue4 = [&](uint32_t w0) __attribute__((always_inline)) -> uint4 {
+        const uint32_t wc = (w0 + 4u <= w_end) ? w0 : w_begin;
+        return *reinterpret_cast<const uint4 *>(reinterpret_cast<uintptr_t>(bits + wc) & ~(uintptr_t)15);
+    };
+    auto finish4 = [&](uint32_t w0, uint4 t, uint32_t *x) __attribute__((always_inline)) {
+        AM_PIN_U32(t.x); AM_PIN_U32(t.y); AM_PIN_U32(t.z); AM_PIN_U32(t.w);
+        const bool in = w0 + 4u <= w_end;
+        x[0] = in ? t.x : 0u; x[1] = in ? t.y : 0u; x[2] = in ? t.z : 0u; x[3] = in ? t.w : 0u;
+        if (!vec) {                                           // (uniform; never for the streaming front ends' bitmaps)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (w0 + (uint32_t)k < w_end) x[k] = bits[w0 + (uint32_t)k];
+            for (int k = 0; k < 4; ++k) x[k] = (w0 + (uint32_t)k < w_end) ? bits[w0 + (uint32_t)k] : 0u;
         }
     };
     // the first two rounds' words (all of them at 64 Msps) go out together with the counts of the workgroups before this one:
     // one memory round trip in front of the arithmetic, not three
     uint32_t xa[4], xb[4];
-    load4(w_begin + 4u * threadIdx.x, xa);
-    load4(w_begin + 4u * (threadIdx.x + blockDim.x), xb);
+    const uint4 ta = issue4(w_begin + 4u * threadIdx.x);
+    const uint4 tb = issue4(w_begin + 4u * (threadIdx.x + blockDim.x));
+    // (with rows: the words once more, laid out as the rows' chip flags want them -- the same cache lines, one more round of loads
+    // under this one instead of a memory round trip of its own behind the listing)
+    am_rows_words early;
+    if constexpr (ROWS != 0)
+        am_rows_issue_words(bits, w_begin, (w_begin + AM_ROWS_MAXW < w_end) ? w_begin + AM_ROWS_MAXW : w_end, early);
     // where this workgroup's candidates start: the counts of the workgroups before it, eight per thread and round trip (a plain
     // `acc += wg_cnt[k]` loop waits for every load before it issues the next: six serial round trips at 64 Msps)
     uint32_t acc = 0;
@@ -783,6 +827,10 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
     }
     for (int o = AM_WAVE / 2; o >= 1; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, AM_WAVE);
     if (lane == 0) red[wv] = acc;
+    finish4(w_begin + 4u * threadIdx.x, ta, xa);              // (arrived with the counts)
+    finish4(w_begin + 4u * (threadIdx.x + blockDim.x), tb, xb);
+    if constexpr (ROWS != 0)
+        am_rows_finish_words(w_begin, (w_begin + AM_ROWS_MAXW < w_end) ? w_begin + AM_ROWS_MAXW : w_end, early);
     __syncthreads();
     uint32_t run = 0;
     for (int k = 0; k < 256 / AM_WAVE; ++k) run += red[k];
@@ -792,7 +840,7 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
         uint32_t x[4];
         if (round == 0) { x[0] = xa[0]; x[1] = xa[1]; x[2] = xa[2]; x[3] = xa[3]; }
         else if (round == 1) { x[0] = xb[0]; x[1] = xb[1]; x[2] = xb[2]; x[3] = xb[3]; }
-        else load4(w0, x);
+        else finish4(w0, issue4(w0), x);
         const uint32_t c = (uint32_t)(__popc(x[0]) + __popc(x[1]) + __popc(x[2]) + __popc(x[3]));
         uint32_t incl = c;
         for (int d = 1; d < AM_WAVE; d <<= 1) {
@@ -824,9 +872,17 @@ am_k_gather_wg(const uint32_t *__restrict__ bits, const uint32_t *__restrict__ w
         __shared__ uint32_t PFX[AM_ROWS_NFL + 1];
         __shared__ __attribute__((aligned(16))) float XR[(256 / AM_WAVE) * AM_ROWS_SLOTS * AM_ROWS_XS];
         __shared__ uint16_t RC[(256 / AM_WAVE) * AM_ROWS_SLOTS];
-        for (uint32_t wa = w_begin; wa < w_end; wa += AM_ROWS_MAXW) {   // (one pass at am_k_fe3's 14 x 96 words per workgroup)
-            if (wa != w_begin) __syncthreads();                       // (the flags of the pass before are still being read)
-            am_rows_segment32<ROWS == 1>(ra, bits, wa, (wa + AM_ROWS_MAXW < w_end) ? wa + AM_ROWS_MAXW : w_end, NZ, FL, PFX, XR, RC);
+        // (one pass at am_k_fe3's 14 x 96 words per workgroup: its words were loaded at the start of the kernel; more only in the
+        // test builds that run 64 Msps through am_k_fe4<32, 1, 3>)
+        am_rows_segment32<ROWS == 1>(ra, bits, w_begin, (w_begin + AM_ROWS_MAXW < w_end) ? w_begin + AM_ROWS_MAXW : w_end, NZ, FL, PFX,
+                                     XR, RC, early, true);
+        for (uint32_t wa = w_begin + AM_ROWS_MAXW; wa < w_end; wa += AM_ROWS_MAXW) {
+            __syncthreads();                                          // (the flags of the pass before are still being read)
+            am_rows_words none;
+#pragma unroll
+            for (int q = 0; q < AM_ROWS_NCH; ++q) none.w[q] = 0u;
+            am_rows_segment32<ROWS == 1>(ra, bits, wa, (wa + AM_ROWS_MAXW < w_end) ? wa + AM_ROWS_MAXW : w_end, NZ, FL, PFX, XR, RC,
+                                         none, false);
         }
     }
 }
@@ -1171,9 +1227,11 @@ am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_spa
     const bool live = i < nc;
     const uint32_t g = c0 + (live ? i : 0u);
     const uint32_t j = pos[g];
+    uint32_t pvw = pos[g ? g - 1u : 0u];                      // (unconditional, in flight with pos[g]: behind `if (live && i)` it was a round trip of its own)
+    AM_PIN_U32(pvw);
     uint32_t lo = j, d = 0;
     if (live) {
-        if (i) { const uint32_t pv = pos[g - 1u] + (uint32_t)spc; lo = pv > j ? pv : j; }
+        if (i) { const uint32_t pv = pvw + (uint32_t)spc; lo = pv > j ? pv : j; }
         d = j + (uint32_t)spc - lo;                           // >= 1: positions ascend strictly
     }
     {
