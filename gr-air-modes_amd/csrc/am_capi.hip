@@ -579,7 +579,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
             HIPCHK(c, hipMemsetAsync(c->avg.p, 0xFF, out_n * sizeof(float), c->stream));
         }
         // 64 Msps (a bitmap word = one 32-sample chip, lag 288): the bb rows around candidates are formed from the samples by
-        // am_k_gather_wg, not written by the front end (54 MB of stores per 64 M samples that the dominant kernel does not make)
+        // am_k_gather_wg, not written by the front end (~42 MB of stores per 64 M samples that the dominant kernel does not make)
         c->rows_from_iq = c->rows_in_gather && am_fe4_unit(c->spc) == 32 && am_fe4_lag(c->spc) == 288;
         c->rows.iq = c->rows_from_iq ? src : nullptr;
         c->rows.src_abs0 = (long long)src_abs0; c->rows.src_abs1 = (long long)src_abs1; c->rows.out_abs0 = (long long)out_abs0;

@@ -546,7 +546,7 @@ __device__ __forceinline__ void fe3_step(const am_fe3_args &a, const fe3_smem &L
     // its first one: wave 0 thereby serves the first 16 chips of wave 1 where its own candidates reach; what wave 1's
     // candidates need beyond the step is handed to the next step's wave 0 (CARRY).
     // (round 5: at 64 Msps the launcher passes no bb array -- the rows are formed from the samples by the kernel that lists the
-    // candidates, am_k_gather_wg<1>, am_kernels.hip: 54 MB of stores per launch less here.  The block stays for callers that
+    // candidates, am_k_gather_wg<1>, am_kernels.hip: ~42 MB of stores per launch less here.  The block stays for callers that
     // still hand one in.)
     if (!(FE3_ABLATE & 32) && a.bb_sparse != nullptr) {                // (uniform)
         unsigned long long need = cand;                               // dilate by 16 chips to the right

@@ -487,7 +487,7 @@ am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const
 // Entries at or beyond Mcap (a capacity launch that was too small: the scan is redone) are dropped; *total_out = the
 // number of candidates there are.
 // ---- bb rows around candidates, rebuilt from IQ (round 5; 64 Msps) ------------------------------------------------------------
-// Until round 4 am_k_fe3 wrote the pulse-matched power bb of the 17 chips from every candidate's chip on: 54 MB of stores per
+// Until round 4 am_k_fe3 wrote the pulse-matched power bb of the 17 chips from every candidate's chip on: ~42 MB of stores per
 // 64 M-sample launch at the bench density, 12-15 us of a kernel that moves bytes at the rate the part can move them (DESIGN.md
 // 5.1).  Those rows are formed HERE instead, by the workgroup that lists the segment's candidates anyway: it knows which chips the
 // refinement will read (a candidate in bitmap word w -> chips w - 9 .. w + 7 of the array: bit b of word w is position

@@ -15,3 +15,9 @@ for f in ['bench','bench_20msps','bench_2msps','bench_force_sharded']:
     d=json.load(open('gpurun_out/final/%s.json'%f)); r=d['roofline']
     print(f, 'GS/s %.1f ms/step %.4f kernel_ms %.4f frac %.3f traffic %s parity %s'%(d['value']/1e9,d['ms_per_step'],r['kernel_ms'],r['frac'],r['traffic'],d.get('parity')))
 PY
+# a long leg (2 000 steps = 0.6 s of device work) so that a sampler of GPU activity sees the device busy
+timeout 200 python bench.py --steps 2000 --warmup 20 --no-cpu-baseline --no-extra --no-parity > $OUT/bench_2000_steps.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/final/bench_2000_steps.json')); print('2000 steps: GS/s %.1f ms/step %.4f kernel_ms %.4f frac %.3f'%(d['value']/1e9,d['ms_per_step'],d['roofline']['kernel_ms'],d['roofline']['frac']))
+PY
