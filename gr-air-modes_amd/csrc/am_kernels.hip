@@ -588,6 +588,7 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
             const unsigned long long x = NZ[j];
             unsigned long long d = x | (x << 1);
             d |= d << 2; d |= d << 4; d |= d << 8;                    // shifts 0 .. 15
+            static_assert(AM_ROWS_BBW == 17, "a candidate's chip and the 16 after it");
             f = d | (x << 16);
             const uint32_t hp = j ? (uint32_t)(NZ[j - 1u] >> 48) : 0u;      // the previous word's last 16 words reach into this one
             if (hp) f |= (2ull << (31 - __clz((int)hp))) - 1ull;
