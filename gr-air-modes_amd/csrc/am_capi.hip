@@ -99,6 +99,8 @@ struct am_ctx {
     bool poison = false;          // (test builds: AIRMODES_POISON=1) NaN-fill the sparse bb / reference-level arrays before every scan
     bool rows_in_gather = true;      // 64 Msps: bb rows around candidates from IQ in am_k_gather_wg (test builds: AIRMODES_ROWS_FE=1 keeps the front end's)
     bool rows_from_iq = false;       // ... in force for the scan in flight
+    bool rows_max = true;            // ... with a maximum per row for am_k_refine_late (test builds: AIRMODES_ROWS_MAX=0 keeps round 5's first form)
+    DevBuf bbmax;
     am_rows_args rows = {};
     bool allow_stream = true;        // (test builds: AIRMODES_FE=2) keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
     // the scan whose records are resident: bb exists only around candidates (streaming front end), so burst
@@ -484,7 +486,7 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
             HIPCHK(c, am_launch_refine_late(bb, avg, (uint32_t *)c->pos.p, M, c->spc, c->thr_lin, end_j, (uint32_t *)c->e.p,
                                             (uint32_t *)c->tgt.p, (float *)c->inavg.p, (uint8_t *)c->valid.p,
                                             (uint32_t *)c->jump.p, c->stream, Mp, (const float *)c->wgmax.p, c->fe_vspan,
-                                            c->fe_nv));
+                                            c->fe_nv, c->rows_from_iq ? c->rows.bb_max : nullptr));
             c->jump_ready = true;
         }
 #if AM_WITH_TILE_KERNEL
@@ -584,6 +586,13 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         c->rows.iq = c->rows_from_iq ? src : nullptr;
         c->rows.src_abs0 = (long long)src_abs0; c->rows.src_abs1 = (long long)src_abs1; c->rows.out_abs0 = (long long)out_abs0;
         c->rows.out_n = (long long)out_n; c->rows.bb_sparse = bb; c->rows.use_pmf = c->use_pmf;
+        c->rows.bb_max = nullptr;
+        if (c->rows_from_iq && c->rows_max) {
+            // one float per array chip: the largest bb of every row formed (am_k_refine_late: whole chips of a quiet zone)
+            ENSURE(c, c->bbmax, ((size_t)(out_n / 32) + 64) * sizeof(float));
+            c->rows.bb_max = (float *)c->bbmax.p;
+            if (c->poison) HIPCHK(c, hipMemsetAsync(c->bbmax.p, 0xFF, ((size_t)(out_n / 32) + 64) * sizeof(float), c->stream));
+        }
         c->rows.s1 = (float)(1.0 / (double)c->spc);
         HIPCHK(c, am_launch_fe4(c->spc, src, (long long)src_abs0, (long long)src_abs1, (long long)out_abs0, (long long)out_n,
                                 c->rows_from_iq ? nullptr : bb,
@@ -905,6 +914,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->allow_stream = !(fe && fe[0] == '2');
             const char *rf = getenv("AIRMODES_ROWS_FE");
             c->rows_in_gather = !(rf && rf[0] == '1');
+            const char *rm = getenv("AIRMODES_ROWS_MAX");
+            c->rows_max = !(rm && rm[0] == '0');
             const char *po = getenv("AIRMODES_POISON");
             c->poison = po && po[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");
@@ -951,7 +962,7 @@ void am_destroy(am_ctx *c)
                 c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
 #endif
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
+    DevBuf *all[] = {&c->bbmax, &c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->bits, &c->seg_base, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->jump, &c->emit_idx,
                      &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,

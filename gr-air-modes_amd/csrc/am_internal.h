@@ -102,6 +102,8 @@ struct am_rows_args {
     long long out_abs0;                   /* absolute index of array coordinate 0                           */
     long long out_n;                      /* array coordinates with data (nothing is stored at or beyond)   */
     float *bb_sparse;
+    float *bb_max;                        /* [array chip] the largest bb of every row formed (what am_k_refine_late takes for a chip that
+                                             lies inside a quiet zone as a whole) */
     int use_pmf;
     float s1;
 };
@@ -125,7 +127,9 @@ hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32
 hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const uint32_t *pos, uint32_t M, int spc,
                                  float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
                                  uint32_t *jump0, hipStream_t s, const uint32_t *Mp, const float *vmax, uint32_t vspan,
-                                 uint32_t nv);
+                                 uint32_t nv, const float *bb_max = nullptr);
+/* (bb_max, 32 samples per chip only: bb_max[c] = the largest bb of array chip c for every chip whose row exists -- am_k_gather_wg<1>
+ * writes it with the rows; a quiet zone's whole chips are then judged by six numbers instead of 192 samples) */
 /* exclusive scan of n counts in ONE launch (2048 per workgroup, chained through slots[]: am_chain_prefix);
  * slots: one 64-bit word per workgroup, zero at allocation; epoch: a value no earlier launch on these slots used */
 hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,

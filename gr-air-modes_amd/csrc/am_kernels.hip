@@ -727,6 +727,7 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
             }
             __builtin_amdgcn_wave_barrier();                          // (every lane has read its row)
             float4 *own = reinterpret_cast<float4 *>(XR + j * AM_ROWS_XS);
+            float rmx = 0.0f;                                         // the row's largest value (fmaxf: a NaN is no sample above anything)
 #pragma unroll
             for (int k = 0; k < SPC / 4; ++k) {
                 float o4[4];
@@ -736,16 +737,24 @@ __device__ __forceinline__ void am_rows_segment32(const am_rows_args &ra, const 
                     float tt = c[i];                                  // the chip's last sample: the window is the chip
                     if (i < SPC - 1) tt = __shfl(c[(i < SPC - 1) ? SPC - 2 - i : 0], lane ^ 32, AM_WAVE) + c[i];   // suf[i + 1] + pre[i]
                     o4[q] = (i >= nin) ? 0.0f : tt * ra.s1;
+                    rmx = fmaxf(rmx, o4[q]);
                 }
                 if (live && half == 0) { float4 o; o.x = o4[0]; o.y = o4[1]; o.z = o4[2]; o.w = o4[3]; own[k] = o; }
 #if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_sched_barrier(0);                    // (four positions at a time: hoisted, the 31 exchanges cost 31 registers more)
 #endif
             }
-        } else if (live && half == 0 && nin < SPC) {
+            // the row's maximum beside the row: am_k_refine_late judges a chip that lies inside a quiet zone as a whole by it
+            const long long chipa = (long long)w_begin - 25 + (long long)ci;          // array chip
+            if (live && half == 0 && ra.bb_max && chipa >= 0 && chipa * SPC < ra.out_n) ra.bb_max[chipa] = rmx;
+        } else if (live && half == 0) {
             // no filter: bb is |.|^2 itself; only the end of the stream needs a hand
             float *own = XR + j * AM_ROWS_XS;
             for (int i = nin; i < SPC; ++i) own[i] = 0.0f;
+            float rmx = 0.0f;
+            for (int i = 0; i < SPC; ++i) rmx = fmaxf(rmx, own[i]);
+            const long long chipa = (long long)w_begin - 25 + (long long)ci;
+            if (ra.bb_max && chipa >= 0 && chipa * SPC < ra.out_n) ra.bb_max[chipa] = rmx;
         }
         __builtin_amdgcn_wave_barrier();
         // the rows leave eight per store instruction
@@ -1208,12 +1217,45 @@ am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, co
 //     (:198-209), the record, and the greedy chain's successor.
 #define AM_RCB 256                  /* candidates per workgroup */
 #define AM_RPL 2                    /* positions per lane and round */
-__global__ void __launch_bounds__(256)
+// any sample of the two 32-sample chips at ra_ / rb_ (16-byte aligned rows) above thr, among the samples i >= o (from_o) or i <= o.
+// Half a row of each at a time (eight 16-byte loads in flight: 32 registers -- whole rows cost the kernel its eighth wave per SIMD),
+// and only the halves that hold wanted samples
+__device__ __forceinline__ bool am_rows_partly_above(const float *__restrict__ ra_, const float *__restrict__ rb_, int o, bool from_o,
+                                                     float thr)
+{
+    bool hit = false;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // samples 16 h .. 16 h + 15: wanted ones among them?  (from_o: i >= o -> the upper half always, the lower one if o < 16;
+        // else i <= o -> the lower half always, the upper one if o >= 16)
+        const bool some = from_o ? (h == 1 || o < 16) : (h == 0 || o >= 16);
+        if (some && !hit) {
+            float4 ta[4], tb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ta[k] = reinterpret_cast<const float4 *>(ra_)[4 * h + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tb[k] = reinterpret_cast<const float4 *>(rb_)[4 * h + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a4[4] = {ta[k].x, ta[k].y, ta[k].z, ta[k].w}, b4[4] = {tb[k].x, tb[k].y, tb[k].z, tb[k].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * h + 4 * k + q;
+                    const bool in = from_o ? (i >= o) : (i <= o);
+                    hit = hit || (in && (a4[q] > thr || b4[q] > thr));
+                }
+            }
+        }
+    }
+    return hit;
+}
+
+__global__ void __launch_bounds__(256, 8)                    // (64 VGPRs: all of a bench scan's ~1 950 workgroups resident at once)
 am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
                  uint32_t Mcap, int spc, float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo,
                  uint32_t *__restrict__ tgt, float *__restrict__ inavg, uint8_t *__restrict__ valid,
                  uint32_t *__restrict__ jump0, const uint32_t *__restrict__ Mp, const float *__restrict__ vmax,
-                 uint32_t vspan, uint32_t nv)
+                 uint32_t vspan, uint32_t nv, const float *__restrict__ bb_max)
 {
     const uint32_t M = am_count(Mcap, Mp);
     __shared__ uint32_t coff[AM_RCB + 1];   // compact index of the first position candidate i owns (+ end)
@@ -1325,13 +1367,38 @@ am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_spa
     // quiet zones (preamble_impl.cc:198-209)
     const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
     const float av = (e >= end_j) ? 0.0f : avg_sparse[e];    // beyond the end of the stream: 0
+    // (the maxima of the quiet zones' whole chips ride along with the four pulses: they depend on e alone)
+    float mz[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (bb_max) {
+        const uint32_t c = e >> 5;
+        const uint32_t cz[6] = {c + 4u, c + 5u, c + 11u, c + 12u, c + 13u, c + 14u};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mz[k] = ((unsigned long long)cz[k] * 32ull < (unsigned long long)end_j) ? bb_max[cz[k]] : 0.0f;
+    }
     float ps = p0 + p1;
     ps = ps + p2;
     ps = ps + p3;
     const float avgpeak = (float)((double)ps / 4.0);
     const float sthr = av + (avgpeak - av) / thr_lin;
-    const bool ok = live && !am_any_above2(bb + e + 3 * spc, 3 * spc + 1,             // offsets 3spc .. 6spc
-                                           bb + e + 10 * spc, 5 * spc + 1, sthr);     // offsets 10spc .. 15spc
+    bool ok;
+    if (bb_max) {
+        // (uniform) 32 samples per chip, rows and their maxima from am_k_gather_wg<1> (round 5).  With e at offset o of chip c the
+        // zones [e + 96, e + 192] and [e + 320, e + 480] are: chip c + 3 from o on, chips c + 4, c + 5 whole, chip c + 6 up to o;
+        // chip c + 10 from o on, chips c + 11 .. c + 14 whole, chip c + 15 up to o.  A whole chip holds a sample above the limit
+        // exactly when its maximum is above it (fmaxf skips a NaN as `NaN > x` is false): six numbers in one round trip decide
+        // most candidates; the four partial chips follow as whole aligned rows, two at a time, masked by the sample index.
+        // Chips beyond the data read as zeros, like the array's padding.
+        const uint32_t c = e >> 5;
+        const int o = (int)(e & 31u);
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hit = hit || (mz[k] > sthr);
+        if (!hit) hit = am_rows_partly_above(bb + (size_t)(c + 3u) * 32u, bb + (size_t)(c + 10u) * 32u, o, true, sthr);
+        if (!hit) hit = am_rows_partly_above(bb + (size_t)(c + 6u) * 32u, bb + (size_t)(c + 15u) * 32u, o, false, sthr);
+        ok = live && !hit;
+    } else
+        ok = live && !am_any_above2(bb + e + 3 * spc, 3 * spc + 1,                    // offsets 3spc .. 6spc
+                                    bb + e + 10 * spc, 5 * spc + 1, sthr);            // offsets 10spc .. 15spc
     if (!live) return;
     eo[g] = e;
     inavg[g] = av;
@@ -1346,12 +1413,13 @@ am_k_refine_late(const float *__restrict__ bb, const float *__restrict__ avg_spa
 hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const uint32_t *pos, uint32_t M, int spc,
                                  float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid,
                                  uint32_t *jump0, hipStream_t s, const uint32_t *Mp, const float *vmax, uint32_t vspan,
-                                 uint32_t nv)
+                                 uint32_t nv, const float *bb_max)
 {
     if (M == 0) return hipSuccess;
     if (spc > 32 || spc < 1 || !vmax || vspan == 0 || nv == 0 || !jump0) return hipErrorInvalidValue;   // (the rounding bound is stated for 4 spc <= 128 terms)
+    if (bb_max && (spc != 32 || (reinterpret_cast<uintptr_t>(bb) & 15u) != 0)) return hipErrorInvalidValue;   // (rows of 32 samples, 16-byte aligned)
     hipLaunchKernelGGL(am_k_refine_late, dim3((M + AM_RCB - 1) / AM_RCB), dim3(AM_RCB), 0, s, bb, avg_sparse, pos, M, spc, thr_lin,
-                       end_j, e, tgt, inavg, valid, jump0, Mp, vmax, vspan, nv);
+                       end_j, e, tgt, inavg, valid, jump0, Mp, vmax, vspan, nv, bb_max);
     return hipGetLastError();
 }
 

@@ -1,0 +1,21 @@
+# Round 5, call 11: a maximum per bb row beside the rows (am_k_gather_wg<1>), six numbers instead of 192 samples for the whole chips of
+# a candidate's quiet zones in am_k_refine_late (default) against the rows alone (test build, AIRMODES_ROWS_MAX=0) and round 4's
+# arrangement (AIRMODES_ROWS_FE=1); device tests first
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG:-r5_11}
+rm -rf $OUT; mkdir -p $OUT
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > $OUT/tests_gpu.txt
+K=$PWD/tests/gpu_variants/libairmodes_hip_knobs.so
+line() { python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1: ms/step %.4f  GS/s %.1f  fe_ms %.4f frac %.3f pk %d'%(d['ms_per_step'],d['value']/1e9,d['roofline']['kernel_ms'],d['roofline']['frac'],d['packets_per_step']))"; }
+run() { env AIRMODES_HIP_LIB=$K $2 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-extra $ARGS 2>/dev/null | line "$1" >> $OUT/ab.txt; }
+for ARGS in "" "--lambda 2000"; do
+  echo "== bench args: $ARGS" >> $OUT/ab.txt
+  for rep in 1 2 3; do
+    run "rows+max " AIRMODES_X=0
+    run "rows only" AIRMODES_ROWS_MAX=0
+    run "rowsfe   " AIRMODES_ROWS_FE=1
+  done
+done
+STEPS=10 timeout 300 bash tools/gpu_kstats.sh > $OUT/kstats.txt 2>&1
+BENCH_ARGS="--lambda 2000" STEPS=10 timeout 300 bash tools/gpu_kstats.sh > $OUT/kstats_lambda2000.txt 2>&1
+cat $OUT/tests_gpu.txt $OUT/ab.txt; head -9 $OUT/kstats.txt; head -9 $OUT/kstats_lambda2000.txt
