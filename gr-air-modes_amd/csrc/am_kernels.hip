@@ -442,41 +442,6 @@ __device__ __forceinline__ uint32_t am_count(uint32_t cap, const uint32_t *__res
     return m < cap ? m : cap;
 }
 
-#if AM_WITH_TILE_KERNEL
-// One workgroup per tile segment: its slice of the flat arrays is [blk_off[b], blk_off[b+1]), so the
-// copy is coalesced and needs no search; only the first candidate of a segment looks back for its
-// predecessor (last candidate of the nearest earlier non-empty segment).
-__global__ void __launch_bounds__(128)
-am_k_gather_pos(const uint32_t *__restrict__ seg_pos, uint32_t seg_stride, const uint32_t *__restrict__ blk_off,
-                uint32_t nseg, uint32_t Mcap, int spc, uint32_t *__restrict__ pos, uint32_t *__restrict__ dcount,
-                const uint32_t *__restrict__ Mp)
-{
-    const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t b = blockIdx.x;
-    const uint32_t off = blk_off[b], cnt = blk_off[b + 1u] - off;
-    if (cnt == 0 || off >= M) return;                        // uniform
-    const uint32_t *src = seg_pos + (size_t)b * seg_stride;
-    uint32_t before = 0;                                     // position of the candidate before this segment's first
-    if (off > 0) {
-        uint32_t pb = b - 1u;
-        while (blk_off[pb + 1u] == blk_off[pb]) --pb;        // some earlier segment is non-empty because off > 0
-        before = seg_pos[(size_t)pb * seg_stride + (blk_off[pb + 1u] - blk_off[pb] - 1u)];
-    }
-    for (uint32_t k = threadIdx.x; k < cnt; k += blockDim.x) {
-        const uint32_t g = off + k;
-        if (g >= M) break;
-        const uint32_t p = src[k];
-        uint32_t d = (uint32_t)spc + 1u;
-        if (g > 0) {
-            const uint32_t gap = p - (k ? src[k - 1u] : before);
-            d = gap < d ? gap : d;
-        }
-        pos[g] = p;
-        dcount[g] = d;
-    }
-}
-
-#endif  // AM_WITH_TILE_KERNEL
 // Flat candidate positions from the streaming front ends' bitmap (am_fe3.hip / am_fe4.hip), one workgroup per FRONT-END
 // workgroup (round 4).  Word w, bit b = array coordinate wbits * w + b - lag (wbits = 32 at 64 Msps, the unit length of
 // am_k_fe4 otherwise).  Front-end workgroup g tested the words [g * words_per_wg, (g + 1) * words_per_wg) and left their
@@ -986,138 +951,6 @@ __device__ __forceinline__ uint32_t am_chain_place(uint32_t *ticket, uint32_t ba
     return *tick;
 }
 
-#if AM_WITH_TILE_KERNEL
-// exclusive scan of n counts in one launch: 2048 elements per workgroup, the offsets of the workgroups before it
-// through am_chain_prefix; *total_out = the sum of all counts
-__global__ void __launch_bounds__(256)
-am_k_exscan_chain(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t ncap,
-                  const uint32_t *__restrict__ Mp, unsigned long long *slots, uint32_t epoch,
-                  uint32_t *__restrict__ total_out, uint32_t *__restrict__ err, uint32_t *ticket, uint32_t ticket_base)
-{
-    const uint32_t n = am_count(ncap, Mp);
-    __shared__ uint32_t ws[256 / AM_WAVE];
-    __shared__ uint32_t red[256 / AM_WAVE];
-    __shared__ uint32_t tick;
-    const int lane = threadIdx.x & (AM_WAVE - 1), wv = threadIdx.x / AM_WAVE;
-    const uint32_t blk = am_chain_place(ticket, ticket_base, &tick);
-    const uint32_t base = blk * AM_SCAN_BLK + threadIdx.x * 8;
-    uint32_t v[8], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; sum += v[k]; }
-    uint32_t incl = sum;
-    for (int d = 1; d < AM_WAVE; d <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, AM_WAVE);
-        if (lane >= d) incl += up;
-    }
-    if (lane == AM_WAVE - 1) ws[wv] = incl;
-    __syncthreads();
-    uint32_t off = incl - sum, total = 0;
-    for (int k = 0; k < 256 / AM_WAVE; ++k) { if (k < wv) off += ws[k]; total += ws[k]; }
-    const uint32_t before = am_chain_prefix(slots, blk, epoch, total, red);
-    if (before == AM_CHAIN_FAIL) {                            // (uniform) a place was never published: no stores, the error word, an empty result
-        if (threadIdx.x == 0) { *err = 1u; if (blk == gridDim.x - 1) *total_out = 0u; }
-        return;
-    }
-    off += before;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = off; off += v[k]; }
-    if (blk == gridDim.x - 1 && threadIdx.x == 0) *total_out = before + total;
-}
-
-__device__ __forceinline__ uint32_t am_off_at(const uint32_t *__restrict__ off_local,
-                                              const uint32_t *__restrict__ blk_base, uint32_t c)
-{
-    return off_local[c] + (blk_base ? blk_base[c / AM_SCAN_BLK] : 0u);   // (null: the offsets are global already)
-}
-
-// E(q) for every compact index.  One workgroup owns AM_ECB consecutive candidates, whose compact
-// indices form one contiguous range [off(c0), off(c0 + AM_ECB)): their offsets, positions and counts
-// sit in LDS, so a lane finds the candidate of its index with an LDS binary search (no dependent
-// global loads).  Consecutive compact indices are consecutive positions except where two candidates
-// lie more than spc + 1 apart, so the 256 positions of a pass read one short stretch of bb
-// (256 + 10*spc samples, each sample up to 4*spc times): it is staged in LDS once and every lane
-// runs its own sequential double sum (pulse 0, 2, 7, 9; ascending within a pulse:
-// preamble_impl.cc:91-98) from there.
-#ifndef AM_ECB
-#define AM_ECB 64                   /* candidates per workgroup (about one 256-lane pass of positions) */
-#endif
-#define AM_ESTAGE 2048              /* floats of bb a pass may stage (8 KB) */
-
-__global__ void __launch_bounds__(256)
-am_k_energy(const float *__restrict__ bb, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ dcount,
-            const uint32_t *__restrict__ off_local, const uint32_t *__restrict__ blk_base, uint32_t Mcap, int spc,
-            double *__restrict__ energy, const uint32_t *__restrict__ Mp)
-{
-    const uint32_t M = am_count(Mcap, Mp);
-    __shared__ uint32_t coff[AM_ECB + 1];   // compact offset of each candidate of this group (+ end)
-    __shared__ uint32_t cq[AM_ECB];         // position of the candidate's first compact index
-    __shared__ uint32_t qr[2];
-    __shared__ float W[AM_ESTAGE];
-    const uint32_t c0 = blockIdx.x * AM_ECB;
-    if (c0 >= M) return;
-    const uint32_t nc = (M - c0 < AM_ECB) ? M - c0 : AM_ECB;
-    {
-        const uint32_t i = threadIdx.x;
-        if (i < nc) {
-            const uint32_t c = c0 + i;
-            const uint32_t o = am_off_at(off_local, blk_base, c);
-            const uint32_t d = dcount[c];
-            coff[i] = o;
-            cq[i] = pos[c] + (uint32_t)spc + 1u - d;
-            if (i == nc - 1) coff[nc] = o + d;
-        }
-    }
-    __syncthreads();
-    const uint32_t kbeg = coff[0], kend = coff[nc];
-    for (uint32_t k0 = kbeg; k0 < kend; k0 += blockDim.x) {
-        const uint32_t k = k0 + threadIdx.x;
-        const uint32_t klast = (k0 + blockDim.x - 1 < kend) ? k0 + blockDim.x - 1 : kend - 1;
-        uint32_t q = 0;
-        if (k < kend) {
-            uint32_t lo = 0, hi = nc;                        // last candidate with coff <= k
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (coff[mid] <= k) lo = mid; else hi = mid;
-            }
-            q = cq[lo] + (k - coff[lo]);
-            if (k == k0) qr[0] = q;                          // k -> q is strictly increasing
-            if (k == klast) qr[1] = q;
-        }
-        __syncthreads();
-        const uint32_t w0 = qr[0] & ~3u;                     // 16-byte aligned start of the window
-        const uint32_t wn = qr[1] + 10u * (uint32_t)spc - w0;   // samples q .. q + 10*spc - 1 of every lane
-        if (wn <= AM_ESTAGE) {
-            for (uint32_t i = 4u * threadIdx.x; i < wn; i += 4u * blockDim.x) {
-                const float4 t = *reinterpret_cast<const float4 *>(bb + w0 + i);   // (arrays are padded)
-                *reinterpret_cast<float4 *>(&W[i]) = t;
-            }
-            __syncthreads();
-            if (k < kend) {
-                const float *p = W + (q - w0);
-                double e = 0.0;
-                const int offs[4] = {0, 2 * spc, 7 * spc, 9 * spc};
-                for (int pu = 0; pu < 4; ++pu) {
-                    const float *pp = p + offs[pu];
-                    int i = 0;
-                    for (; i + 8 <= spc; i += 8) {
-                        float t[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) t[u] = pp[i + u];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) e += (double)t[u];
-                    }
-                    for (; i < spc; ++i) e += (double)pp[i];
-                }
-                energy[k] = e;
-            }
-        } else if (k < kend) {
-            energy[k] = am_preamble_energy(bb + q, spc);     // sparse candidates: straight from memory
-        }
-        __syncthreads();
-    }
-}
-
-#endif  // AM_WITH_TILE_KERNEL
 __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ pos, uint32_t lo,
                                                    uint32_t hi, uint32_t key)
 {
@@ -1133,71 +966,8 @@ __device__ __forceinline__ uint32_t am_lower_bound(const uint32_t *__restrict__ 
 }
 
 #if AM_WITH_TILE_KERNEL
-__global__ void __launch_bounds__(256)
-am_k_cand(const float *__restrict__ bb, const float *__restrict__ avg_sparse, const uint32_t *__restrict__ pos,
-          const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ off_local,
-          const uint32_t *__restrict__ blk_base, const double *__restrict__ energy, uint32_t Mcap, int spc,
-          float thr_lin, uint32_t end_j, uint32_t *__restrict__ eo, uint32_t *__restrict__ tgt,
-          float *__restrict__ inavg, uint8_t *__restrict__ valid, uint32_t *__restrict__ jump0,
-          const uint32_t *__restrict__ Mp)
-{
-    const uint32_t M = am_count(Mcap, Mp);
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = g < M;                                 // (no early return: the wave cooperates below)
-    const uint32_t gi = live ? g : 0u;
-    if (M == 0) return;
-    const uint32_t j = pos[gi];
-    // late-peak search (preamble_impl.cc:184-192) over the precomputed energies
-    const uint32_t e_first = am_off_at(off_local, blk_base, gi) + dcount[gi] - 1u - (uint32_t)spc;   // compact index of position j
-    // (8 energies per round trip: a lane that slides all spc steps would otherwise hold its whole wave
-    // for spc dependent loads)
-    int how_late = 0;
-    bool rising = true;
-    {
-        const double *E = energy + e_first;
-        for (int k0 = 0; k0 < spc && rising; k0 += 8) {
-            double ev[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) ev[k] = E[(k0 + k <= spc) ? k0 + k : spc];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (rising && k0 + k < spc) {
-                    if (ev[k + 1] > ev[k]) how_late++; else rising = false;
-                }
-            }
-        }
-    }
-    const uint32_t e = j + (uint32_t)how_late;
-    // quiet zones (preamble_impl.cc:198-209)
-    const float p0 = bb[e], p1 = bb[e + 2 * spc], p2 = bb[e + 7 * spc], p3 = bb[e + 9 * spc];
-    const float av = (e >= end_j) ? 0.0f : avg_sparse[e];   // beyond the end of the stream: 0
-    float ps = p0 + p1;
-    ps = ps + p2;
-    ps = ps + p3;
-    const float avgpeak = (float)((double)ps / 4.0);
-    const float sthr = av + (avgpeak - av) / thr_lin;
-    // (a wave-cooperative check of the survivors was tried: at the bench density too many candidates
-    // survive the first samples of both zones, 86 us instead of 32)
-    const bool ok = live && !am_any_above2(bb + e + 3 * spc, 3 * spc + 1,             // offsets 3spc .. 6spc
-                                           bb + e + 10 * spc, 5 * spc + 1, sthr);     // offsets 10spc .. 15spc
-    if (!live) return;
-    eo[g] = e;
-    inavg[g] = av;
-    valid[g] = ok ? 1 : 0;
-    const uint32_t tg = ok ? (e + (uint32_t)(AM_BURST * spc)) : (e + 1u);   // :237 / :209
-    tgt[g] = tg;
-    if (jump0) {
-        // the greedy chain's successor (first candidate at or after the resume position; all positions are known by
-        // now), here instead of in a launch of its own (am_k_chain_succ: 7 us at the bench density).
-        // (Round 3: the scan of the bitmap's segment counts used as an index into pos[] -- two round trips, the offset and
-        // eight positions side by side, instead of a dozen dependent ones -- changed nothing: 28.0 against 28.4 us; the
-        // kernel is bound by the cache traffic of the quiet-zone reads, 1 KB per surviving candidate.)
-        jump0[g] = am_lower_bound(pos, g + 1u, M, tg);
-        if (g == M - 1u) jump0[M] = M;
-    }
-}
-
-#endif  // AM_WITH_TILE_KERNEL
+#include "am_split_refine.inc"      // (test builds only: the split refinement behind the tile kernel)
+#endif
 // The refinement behind the streaming front ends in ONE launch (round 4): late-peak decisions and the per-candidate test
 // of am_k_energy (late mode) + am_k_cand, per group of AM_RCB consecutive candidates.  The decisions never leave LDS, and
 // with them went the global compact layout: no distance-to-the-predecessor array, no scan of it (two launches fewer, and
@@ -1423,49 +1193,6 @@ hipError_t am_launch_refine_late(const float *bb, const float *avg_sparse, const
     return hipGetLastError();
 }
 
-#if AM_WITH_TILE_KERNEL
-hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,
-                                uint32_t nseg, uint32_t M, int spc, uint32_t *pos, uint32_t *dcount,
-                                hipStream_t s, const uint32_t *Mp)
-{
-    if (M == 0 || nseg == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_gather_pos, dim3(nseg), dim3(128), 0, s, seg_pos, seg_stride, blk_off, nseg, M, spc, pos,
-                       dcount, Mp);
-    return hipGetLastError();
-}
-hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n, unsigned long long *slots, uint32_t epoch,
-                                  uint32_t *total_out, uint32_t *err, uint32_t *ticket, uint32_t *ticket_base, hipStream_t s,
-                                  const uint32_t *Mp)
-{
-    if (n == 0) return hipSuccess;
-    const uint32_t grid = (n + AM_SCAN_BLK - 1) / AM_SCAN_BLK;
-    hipLaunchKernelGGL(am_k_exscan_chain, dim3(grid), dim3(256), 0, s, in, out, n, Mp, slots, epoch, total_out, err, ticket,
-                       *ticket_base);
-    const hipError_t rc = hipGetLastError();
-    if (rc == hipSuccess) *ticket_base += grid;              // (every workgroup of a launch that happened draws one: the host's
-    return rc;                                               //  count must not run ahead of the device's when a launch fails)
-}
-hipError_t am_launch_energy(const float *bb, const uint32_t *pos, const uint32_t *dcount,
-                            const uint32_t *off_local, const uint32_t *blk_base, uint32_t M, int spc,
-                            double *energy, hipStream_t s, const uint32_t *Mp)
-{
-    if (M == 0) return hipSuccess;
-    const unsigned grid = (unsigned)(((uint64_t)M + AM_ECB - 1) / AM_ECB);
-    hipLaunchKernelGGL(am_k_energy, dim3(grid), dim3(256), 0, s, bb, pos, dcount, off_local, blk_base, M, spc,
-                       energy, Mp);
-    return hipGetLastError();
-}
-hipError_t am_launch_cand(const float *bb, const float *avg_sparse, const uint32_t *pos, const uint32_t *dcount,
-                          const uint32_t *off_local, const uint32_t *blk_base, const double *energy, uint32_t M,
-                          int spc, float thr_lin, uint32_t end_j, uint32_t *e, uint32_t *tgt, float *inavg,
-                          uint8_t *valid, uint32_t *jump0, hipStream_t s, const uint32_t *Mp)
-{
-    if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(am_k_cand, dim3((M + 255) / 256), dim3(256), 0, s, bb, avg_sparse, pos, dcount, off_local,
-                       blk_base, energy, M, spc, thr_lin, end_j, e, tgt, inavg, valid, jump0, Mp);
-    return hipGetLastError();
-}
-#endif  // AM_WITH_TILE_KERNEL
 
 // ------------------------------------------------------------------------------------------
 // Greedy chain.  The reference scan visits candidates in position order; after visiting c it
