@@ -94,6 +94,7 @@ class Library(object):
         L.am_last_num_tags.argtypes = [vp]
         L.am_frontend_work.argtypes = [vp, vp, u64, u32, vp, vp]
         L.am_preamble_work.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
+        L.am_preamble_stream.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
         L.am_slicer_work.argtypes = [vp, vp, vp, u64, u32, vp, u64, pu64]
         L.am_crc24.restype = u32
         L.am_crc24.argtypes = [vp, ci]
@@ -406,6 +407,22 @@ class Context(object):
         got = C.c_uint64(0)
         self._chk(self.lib.L.am_preamble_work(self._h, a.ctypes.data, b.ctypes.data, n, 0, bursts.ctypes.data,
                                               tags.ctypes.data, cap, C.byref(got)))
+        return bursts[:got.value], tags[:got.value]
+
+    def preamble_stream(self, in_, inavg, flush=False):
+        """The next items of the preamble block's two input streams (am_preamble_stream): this call's hits."""
+        a = np.ascontiguousarray(in_, np.float32)
+        b = np.ascontiguousarray(inavg, np.float32)
+        assert a.size == b.size
+        n = a.size
+        spc = max(int(self.get_rate() / 2e6), 1)
+        cap = n // (240 * spc) + 4
+        bursts = np.zeros((cap, 240), np.float32)
+        tags = np.zeros(cap, TAG_DTYPE)
+        got = C.c_uint64(0)
+        self._chk(self.lib.L.am_preamble_stream(self._h, a.ctypes.data if n else None, b.ctypes.data if n else None, n,
+                                                AM_F_FLUSH if flush else 0, bursts.ctypes.data, tags.ctypes.data, cap,
+                                                C.byref(got)))
         return bursts[:got.value], tags[:got.value]
 
     def slicer_work(self, bursts, tags):

@@ -42,6 +42,19 @@ class preamble(object):
             self._ctx.set_rx_time(*tag)
         return self._ctx.preamble_work(in0, in1)
 
+    def general_work(self, in0, in1, rx_time=(), flush=False):
+        """The block under a scheduler (lib/preamble_impl.cc:139: general_work, called again and again on the next
+        items): the next items of both input streams in, this call's hits out; the calls together give what one
+        work() over the concatenation gives.  Decisions wait for 244 chips of look-ahead (:150,212); the undecided
+        tail is carried inside the block.  rx_time offsets are stream-absolute; flush=True: these are the stream's
+        last items, the next call starts a new stream.  reset() drops the carried state."""
+        for tag in rx_time:
+            self._ctx.set_rx_time(*tag)
+        return self._ctx.preamble_stream(in0, in1, flush=flush)
+
+    def reset(self):
+        self._ctx.reset()
+
 
 class slicer(object):
     """air_modes.slicer(queue): PPM bit slicer + framer + CRC; posts one text message per

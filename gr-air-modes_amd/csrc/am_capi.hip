@@ -117,6 +117,10 @@ struct am_ctx {
     DevBuf tt_dev;
 
     // stream state (absolute sample indices)
+    // the block-level preamble as a STREAM (am_preamble_stream): items so far, first undecided position, where the greedy scan
+    // resumes, and the tail of both inputs that the next call's decisions still read
+    uint64_t pb_total = 0, pb_next = 0, pb_cur = 0, pb_carry_abs0 = 0, pb_carry_n = 0;
+    DevBuf pb_bb, pb_avg;
     uint64_t total_in = 0;    // samples received so far
     uint64_t next_pos = 0;    // first position whose preamble test is still undecided
     uint64_t chain_cur = 0;   // position at which the greedy scan resumes
@@ -327,6 +331,7 @@ int configure_rate(am_ctx *c, double rate)
 
 void reset_stream(am_ctx *c)
 {
+    c->pb_total = c->pb_next = c->pb_cur = c->pb_carry_abs0 = c->pb_carry_n = 0;
     c->total_in = 0;
     c->next_pos = 0;
     c->chain_cur = 0;
@@ -962,7 +967,7 @@ void am_destroy(am_ctx *c)
                 c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
 #endif
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->bbmax, &c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
+    DevBuf *all[] = {&c->pb_bb, &c->pb_avg, &c->bbmax, &c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
                      &c->energy, &c->bits, &c->seg_base, &c->blk_cnt, &c->blk_off,
                      &c->pos, &c->e, &c->tgt, &c->valid, &c->jump, &c->emit_idx,
                      &c->lb_dc, &c->lb_mark, &c->cblk_cnt, &c->cblk_off, &c->scalars, &c->bursts, &c->tags, &c->packets, &c->crc_pow,
@@ -1395,6 +1400,104 @@ int am_preamble_work(am_ctx *c, const float *in, const float *inavg, uint64_t n,
         if (rc != AM_OK) return rc;
     }
     const uint64_t nt = c->h_tags.size();
+    if (n_out) *n_out = nt;
+    if (nt > cap) return fail(c, AM_ECAPACITY, "burst/tag arrays too small");
+    if (nt) {
+        if (!bursts || !tags) return fail(c, AM_EINVAL, "null output");
+        memcpy(bursts, c->h_bursts.data(), nt * AM_BURST * sizeof(float));
+        memcpy(tags, c->h_tags.data(), nt * sizeof(am_tag));
+    }
+    return AM_OK;
+}
+
+// The preamble block as the streaming gr::block it is in the reference (include/gr_air_modes/preamble.h:36-46,
+// lib/preamble_impl.cc:139-246): call after call on consecutive pieces of the two input streams, the result is what ONE work()
+// call over their concatenation gives -- positions are decided when (240 + 4) samples-per-chip items of look-ahead
+// exist, the undecided tail of both inputs is carried to the next call, the greedy scan resumes where it stopped
+// (consume_each, :213,237,244), item counts and time stamps keep counting; AM_F_FLUSH ends the stream under the end-of-buffer rule
+// (:150,212) and starts a new one at item 0.  am_reset() drops the state; am_set_rx_time offsets are stream-absolute.
+int am_preamble_stream(am_ctx *c, const float *in, const float *inavg, uint64_t n, uint32_t flags,
+                       float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out)
+{
+    if (!c) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    if (n && (!in || !inavg)) return fail(c, AM_EINVAL, "null input");
+    if (c->pb_carry_n + n > ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "piece larger than 2^31 items");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool flush = (flags & AM_F_FLUSH) != 0;
+    const hipMemcpyKind kind = (flags & AM_F_DEVICE_IN) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const uint64_t pad = zero_pad(c->spc_hi);
+    // one contiguous device view of the items [A0, S1): carried tail + new ones; array coordinate 0 = item A0
+    const uint64_t A0 = c->pb_carry_n ? c->pb_carry_abs0 : c->pb_total;
+    const uint64_t S1 = c->pb_total + n, nn = S1 - A0;
+    c->h_packets.clear();
+    c->h_tags.clear();
+    c->h_bursts.clear();
+    if (nn) {
+        ENSURE(c, c->bb, (nn + pad) * sizeof(float));
+        ENSURE(c, c->avg, (nn + pad) * sizeof(float));
+        float *bb = (float *)c->bb.p, *avg = (float *)c->avg.p;
+        if (c->pb_carry_n) {
+            HIPCHK(c, hipMemcpyAsync(bb, c->pb_bb.p, c->pb_carry_n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(avg, c->pb_avg.p, c->pb_carry_n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (n) {
+            HIPCHK(c, hipMemcpyAsync(bb + c->pb_carry_n, in, n * sizeof(float), kind, c->stream));
+            HIPCHK(c, hipMemcpyAsync(avg + c->pb_carry_n, inavg, n * sizeof(float), kind, c->stream));
+        }
+        ZERO_TAIL(c, 0, bb, nn, pad);
+        ZERO_TAIL(c, 1, avg, nn, pad);
+        // positions that can be decided now (as am_process_iq: a hit decided now must also be one if the stream ended here)
+        const uint64_t P0 = c->pb_next;
+        uint64_t P1 = P0, emit_max_abs = ~(uint64_t)0;
+        if (flush) {
+            uint64_t em;
+            if (flush_limits(c, S1, &em)) {
+                emit_max_abs = em;
+                if (em + 1 > P0) P1 = em + 1;
+            }
+        } else {
+            const uint64_t hold = (uint64_t)(AM_BURST + 4) * (uint64_t)c->spc_hi;
+            if (S1 > hold && S1 - hold > P0) P1 = S1 - hold;
+        }
+        if (P1 > P0) {
+            uint32_t M = 0, fin = 0;
+            int rc = run_candidates(c, bb, avg, (uint32_t)(P0 - A0), (uint32_t)(P1 - A0), &M);
+            if (rc != AM_OK) return rc;
+            const uint32_t cur0 = c->pb_cur > A0 ? (uint32_t)std::min<uint64_t>(c->pb_cur - A0, 0xFFFFFFF0u) : 0u;
+            const uint32_t emax = emit_max_abs == ~(uint64_t)0 ? 0xFFFFFFFFu : (uint32_t)(emit_max_abs - A0);
+            fin = cur0;
+            rc = run_chain_and_slice(c, bb, avg, M, cur0, emax, A0, true, &fin,
+                                     (uint32_t)((P1 - P0) / ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2));
+            if (rc != AM_OK) return rc;
+            if (A0 + fin > c->pb_cur) c->pb_cur = A0 + fin;
+            c->pb_next = P1;
+        }
+        if (!flush) {
+            // what the next call's decisions still read: everything from the first undecided position on
+            const uint64_t C0 = c->pb_next > A0 ? c->pb_next : A0;
+            const uint64_t keep = S1 - C0;
+            if (keep) {
+                ENSURE(c, c->pb_bb, keep * sizeof(float));
+                ENSURE(c, c->pb_avg, keep * sizeof(float));
+                HIPCHK(c, hipMemcpyAsync(c->pb_bb.p, bb + (C0 - A0), keep * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->pb_avg.p, avg + (C0 - A0), keep * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            }
+            c->pb_carry_abs0 = C0;
+            c->pb_carry_n = keep;
+            c->pb_total = S1;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // (the caller may reuse its buffers)
+    }
+    const uint64_t nt = c->h_tags.size();
+    if (flush) {
+        // (the hits were copied to the host vectors above; the stream starts over at item 0)
+        std::vector<am_tag> keep_t = c->h_tags;
+        std::vector<float> keep_b = c->h_bursts;
+        reset_stream(c);
+        c->h_tags.swap(keep_t);
+        c->h_bursts.swap(keep_b);
+    }
     if (n_out) *n_out = nt;
     if (nt > cap) return fail(c, AM_ECAPACITY, "burst/tag arrays too small");
     if (nt) {

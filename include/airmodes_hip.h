@@ -218,6 +218,15 @@ AM_API int am_frontend_work(am_ctx *ctx, const float *iq, uint64_t n_complex, ui
 AM_API int am_preamble_work(am_ctx *ctx, const float *in, const float *inavg, uint64_t n,
                      uint32_t flags, float *bursts, am_tag *tags, uint64_t cap,
                      uint64_t *n_out);
+/* The preamble block as a STREAM: what gr::air_modes::preamble is under the scheduler (include/gr_air_modes/preamble.h:36-46;
+ * general_work is called again and again on the next items, lib/preamble_impl.cc:139-246).  Consecutive calls on consecutive pieces
+ * of the two input streams give, together, what ONE am_preamble_work over the concatenation gives: decisions wait for (240 + 4)
+ * samples-per-chip items of look-ahead, the undecided tail of both inputs is carried inside the context, the greedy scan resumes
+ * where it stopped (consume_each, :213,237,244), item counts and time stamps keep counting.  AM_F_FLUSH: these are the stream's last
+ * items (end-of-buffer rule :150,212); the next call starts a new stream at item 0.  am_reset() drops the carried state.
+ * bursts / tags: this call's hits, cap entries; AM_ECAPACITY with *n_out = the number needed if they do not fit. */
+AM_API int am_preamble_stream(am_ctx *ctx, const float *in, const float *inavg, uint64_t n, uint32_t flags,
+                              float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out);
 AM_API int am_slicer_work(am_ctx *ctx, const float *bursts, const am_tag *tags, uint64_t nbursts,
                    uint32_t flags, am_packet *out, uint64_t cap, uint64_t *n_out);
 

@@ -224,6 +224,66 @@ def rx_time_golden_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, "rxtime_*.npz")))
 
 
+def check_preamble_stream(lib, rate, n, lam, seed, thr=7.0, pmf=True, trials=4):
+    """The preamble block as a stream (am_preamble_stream, preamble.general_work): consecutive calls on random pieces
+    of the block's two input streams -- pieces shorter than a burst, empty ones, cuts inside preambles -- give the
+    bursts and tags of ONE work() over the whole streams (= the oracle's scan), "rx_time" tags included; a flush
+    ends the stream and the next one starts at item 0; reset() drops a half-fed stream."""
+    import air_modes
+    spc = max(int(rate / 2e6), 1)
+    iq, _ = synth.synth_capture(rate, n, lam, seed)
+    whole = float(rate) == 2e6 * spc                 # (the oracle's scan is pinned at whole samples per chip)
+    if whole:
+        obb, oavg = oracle.frontend(iq, spc, pmf)
+    else:
+        fe = _capi.Context(rate, thr, pmf, lib=lib)
+        obb, oavg = fe.frontend_work(iq)
+        fe.close()
+    rx = [(0, 1600000000, 0.125), (n // 3 + 5, 1600000007, 0.9999995), (2 * n // 3, 1700000000, 0.75)]
+    blk = air_modes.preamble(rate, thr, lib=lib)
+    wb, wt = blk.work(obb, oavg, rx_time=rx)
+    if whole:
+        ob, ot = oracle.preamble_scan(obb, oavg, spc, thr, rate, rx_time=rx)
+        assert np.array_equal(wt, ot) and np.array_equal(u32(wb), u32(ob))
+    assert len(wt) > 3
+    rng = np.random.default_rng(seed)
+    hold = 244 * spc
+    for t in range(trials):
+        blk.reset()
+        k = int(rng.integers(2, 12))
+        cuts = sorted(int(c) for c in rng.integers(0, n + 1, k))
+        if t == 0 and len(wt):                       # cuts inside a hit's preamble and inside its look-ahead
+            s0 = int(wt["sample"][len(wt) // 2])
+            cuts = sorted(cuts + [max(s0 - 3, 0), s0 + 2 * spc, min(s0 + hold - 1, n), min(s0 + hold, n), min(s0 + hold + 1, n)])
+        if t == 1:
+            cuts = sorted(cuts + [cuts[0], cuts[0] + min(7, n - cuts[0])])      # an empty piece and a 7-item one
+        edges = [0] + cuts + [n]
+        gb, gt = [], []
+        for a, b in zip(edges[:-1], edges[1:]):
+            tg = [x for x in rx if a <= x[0] < b] if b > a else []
+            if a == b == 0:
+                tg = []
+            b_, t_ = blk.general_work(obb[a:b], oavg[a:b], rx_time=tg, flush=False)
+            gb.append(b_); gt.append(t_)
+        b_, t_ = blk.general_work(obb[:0], oavg[:0], flush=True)
+        gb.append(b_); gt.append(t_)
+        early = sum(len(x) for x in gt[:-1])
+        gt = np.concatenate(gt); gb = np.concatenate(gb)
+        assert early >= len(gt) - 2 - (n - edges[-2]) // (240 * spc), "hits were held back until the flush"
+        assert np.array_equal(gt, wt), "streamed tags differ (cuts %s)" % (cuts,)
+        assert np.array_equal(u32(gb), u32(wb)), "streamed bursts differ"
+    # after the flush the stream starts over: the same input again gives the same hits (item 0 again, no old tags)
+    b1, t1 = blk.general_work(obb, oavg, flush=True)
+    b0, t0 = blk.work(obb, oavg)
+    assert np.array_equal(t1, t0) and np.array_equal(u32(b1), u32(b0))
+    # a half-fed stream is dropped by reset()
+    blk.general_work(obb[: n // 2], oavg[: n // 2])
+    blk.reset()
+    b1, t1 = blk.general_work(obb, oavg, flush=True)
+    assert np.array_equal(t1, t0)
+    return len(wt)
+
+
 def load_rx_time_golden(path):
     z = np.load(path)
     rx = [(int(o), int(s_), float(f)) for o, s_, f in zip(z["rx_offset"], z["rx_secs"], z["rx_frac"])]

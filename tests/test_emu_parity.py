@@ -350,3 +350,9 @@ def test_slicer_edge_vectors(emu_lib, oracle_mod):
 @pytest.mark.parametrize("rate,n,lam", [(4e6, 600000, 3000.0), (64e6, 2500000, 12000.0)])
 def test_framer_edge_formats_through_the_production_path(emu_lib, oracle_mod, rate, n, lam):
     assert pc.check_framer_edge_formats(emu_lib, rate, n, lam, 616) > 10
+
+
+@pytest.mark.parametrize("rate,n,lam", [(2e6, 150000, 3000.0), (4e6, 250000, 3000.0), (5e6, 300000, 2500.0), (20e6, 600000, 6000.0)])
+def test_preamble_block_as_a_stream(emu_lib, rate, n, lam):
+    """VERDICT r4 missing #4: preamble.general_work carries the block's state from call to call (lib/preamble_impl.cc:139-246)."""
+    assert pc.check_preamble_stream(emu_lib, rate, n, lam, seed=int(rate / 1e5) + 3) > 3

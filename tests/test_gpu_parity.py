@@ -238,6 +238,12 @@ def test_rx_time_tags(lib, rate, n):
     assert pc.check_rx_time(lib, rate, n, 3000.0, 91, G=4) >= 3
 
 
+@pytest.mark.parametrize("rate,n,lam", [(2e6, 600000, 3000.0), (4e6, 1000000, 3000.0), (5e6, 900000, 2500.0), (64e6, 6400000, 8000.0)])
+def test_preamble_block_as_a_stream(lib, rate, n, lam):
+    """preamble.general_work (am_preamble_stream): random pieces of the two input streams = one work() over them."""
+    assert pc.check_preamble_stream(lib, rate, n, lam, seed=int(rate / 1e5) + 3, trials=3) > 3
+
+
 def test_chain_walk_beyond_64k_of_lds(lib):
     """Between 256 and 288 blocks of 2048 first-stage candidates in ONE scan (low threshold, dense traffic):
     the block-to-block walk of the greedy chain then keeps 128 head links per block = more than 64 KB in LDS,
