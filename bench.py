@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (contexts/streams driven by host threads)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 3-batches-in-flight figure (profiling runs)")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
+    ap.add_argument("--streams", type=int, default=1, help="K independent streams (receivers) of the workload in ONE scan per step "
+                                                           "(am_process_multi): N = 1, value counts all K streams")
     ap.add_argument("--replicas", action="store_true", help="N independent receivers, one per GPU (configs[4])")
     ap.add_argument("--emu", action="store_true", help="tests only: CPU emulation of the kernels, gloo")
     return ap.parse_args()
@@ -139,13 +141,42 @@ def main():
 
     ctx = new_ctx()
     extra = {}
+    K = max(1, args.streams)
+    if K > 1 and mode != "single":
+        raise SystemExit("bench.py: --streams is a single-GPU figure (use --replicas for one receiver per GPU)")
+
+    def k_streams_setup(k, nbatch):
+        """k whole streams of the workload (different seeds) packed behind one another, zeros between them (am_multi_layout),
+        resident in HBM: (host streams, device buffers, lengths, samples in the scanned buffer)."""
+        lengths = np.full(k, n, np.uint64)
+        off, total = ctx.multi_layout(lengths)
+        hosts, devs = [], []
+        for b in range(nbatch):
+            st = [synth.synth_capture(rate, n, lam, seed + rank + 100 * b + 1000 * j)[0] for j in range(k)]
+            d = torch.zeros(2 * total, dtype=torch.float32, device=dev)
+            for j in range(k):
+                d[2 * int(off[j]): 2 * (int(off[j]) + n)].copy_(torch.from_numpy(st[j].view(np.float32)))
+            hosts.append(st)
+            devs.append(d)
+        return hosts, devs, lengths, total
 
     # ------------------------------------------------------------------------------------------------------------
     if mode in ("single", "replicas"):
         nb = max(1, args.batches if mode == "single" else 1)
-        host_batches = [synth.synth_capture(rate, n, lam, seed + rank + 100 * b)[0] for b in range(nb)]
-        d_batches = [torch.from_numpy(b.view(np.float32)).to(dev) for b in host_batches]
+        if K > 1:
+            # one packed buffer of K streams per step (K x %d samples: far beyond the Infinity Cache, one buffer is enough)
+            nb = 1
+            k_hosts, d_batches, k_lengths, k_total = k_streams_setup(K, nb)
+            host_batches = [k_hosts[0][0]]
+        else:
+            host_batches = [synth.synth_capture(rate, n, lam, seed + rank + 100 * b)[0] for b in range(nb)]
+            d_batches = [torch.from_numpy(b.view(np.float32)).to(dev) for b in host_batches]
         sync()
+
+        def scan(c, batch):
+            if K > 1:
+                return c.process_multi(None, k_lengths, device_ptr=batch.data_ptr())
+            return c.process_iq_device(batch.data_ptr(), n, flush=True)
         inflight = max(1, args.inflight) if mode == "single" else 1
         ctxs = [ctx] + [new_ctx() for _ in range(inflight - 1)]
 
@@ -157,7 +188,7 @@ def main():
             def worker(w):
                 c = ctxs_[w]
                 for k in range(w, count, flight):
-                    last[w] = (k, c.process_iq_device(batches[k % len(batches)].data_ptr(), n, flush=True))
+                    last[w] = (k, scan(c, batches[k % len(batches)]))
                     fe[w].append(c.last_dom_ms())
             if flight == 1:
                 worker(0)
@@ -185,12 +216,53 @@ def main():
         # untimed: every context past its first (allocating) and second (capacity) call, every batch seen once
         per_batch = []
         for b in range(nb):
-            per_batch.append(len(ctx.process_iq_device(d_batches[b].data_ptr(), n, flush=True)))
+            r0 = scan(ctx, d_batches[b])
+            per_batch.append(sum(len(x) for x in r0) if K > 1 else len(r0))
         run_steps(max(args.warmup, 2 * inflight), ctxs, inflight, d_batches)
         dt, k_last, pk, fe_ms = timed(args.steps, ctxs, inflight, d_batches)
         last_batch = (k_last % nb) if k_last is not None else 0
         npk_steps = sum(per_batch[k % nb] for k in range(args.steps))
-        if mode == "single" and not args.no_extra and not args.no_pipelined and inflight == 1 and args.steps >= 3:
+        if K > 1:
+            # parity: EVERY stream's packets against the oracle over that stream alone
+            parity_k = None
+            if not args.no_parity:
+                import oracle
+                parity_k = all(g.tobytes() == oracle.demod(x, rate, 7.0, True).tobytes() for g, x in zip(pk, k_hosts[0]))
+            one = ctx.process_iq_device(d_batches[0].data_ptr(), n, flush=True)      # (stream 0 lies at offset 0)
+            extra["k_streams"] = {"streams_per_scan": K, "samples_per_stream": n, "samples_scanned_per_step": int(k_total),
+                                  "parity_every_stream": parity_k,
+                                  "same_as_single_stream_call": bool(one.tobytes() == pk[0].tobytes()),
+                                  "packets_per_stream": [int(len(g)) for g in pk]}
+            pk = pk[0]
+        if mode == "single" and K == 1 and not args.no_extra and workload != "64msps" and args.steps >= 3:
+            # 2 / 20 Msps: one second of ONE receiver is a small job for the chip (the scan's launches are most of the step); eight
+            # receivers' seconds in one scan (am_process_multi: K whole streams in one buffer, zeros between them)
+            KX = 8
+            kh, kd, kl, kt = k_streams_setup(KX, 1)
+            for _ in range(3):
+                got = ctx.process_multi(None, kl, device_ptr=kd[0].data_ptr())
+            ks = max(5, args.steps // 2)
+            sync()
+            tk0 = time.perf_counter()
+            fek = []
+            for _ in range(ks):
+                got = ctx.process_multi(None, kl, device_ptr=kd[0].data_ptr())
+                fek.append(ctx.last_dom_ms())
+            sync()
+            dtk = (time.perf_counter() - tk0) / ks
+            fe_k = float(np.mean(fek))
+            extra["k_streams_per_scan"] = {
+                "streams_per_scan": KX, "samples_per_stream": n, "value": KX * n / dtk, "unit": "samples/s", "ms_per_step": dtk * 1e3,
+                "kernel_ms": fe_k, "roofline_frac": (8.0 * kt / (fe_k * 1e-3) / 1e9 / HBM_PEAK_GBS) if fe_k > 0 else 0.0,
+                "path_frac_of_hbm_peak": 8.0 * KX * n / dtk / 1e9 / HBM_PEAK_GBS,
+                "packets_per_stream": [int(len(g)) for g in got]}
+            if not args.no_parity:
+                import oracle
+                extra["k_streams_per_scan"]["parity_every_stream"] = all(
+                    g.tobytes() == oracle.demod(x, rate, 7.0, True).tobytes() for g, x in zip(got, kh[0]))
+            del kd, kh
+            run_steps(2, [ctx], 1, d_batches)
+        if mode == "single" and K == 1 and not args.no_extra and not args.no_pipelined and inflight == 1 and args.steps >= 3:
             # the same batches with four in flight from ONE host thread (am_pipe: four contexts behind one handle, submit /
             # collect): the launch-latency-bound tail of one batch overlaps the streaming kernel of the next.  Timed over
             # 24 batches including the filling and the draining of the pipe (depth 3: ~4 % less, 5 and more: less again --
@@ -225,7 +297,7 @@ def main():
                                   "same_packet_counts": counts3 == [per_batch[k % nb] for k in range(PIPE_BATCHES)],
                                   "same_packets_last_batch": bool(np.array_equal(last3, want_last))}
             pipe.close()
-        if mode == "single" and not args.no_extra and lam != REALISTIC_LAMBDA:
+        if mode == "single" and K == 1 and not args.no_extra and lam != REALISTIC_LAMBDA:
             iq_r = synth.synth_capture(rate, n, REALISTIC_LAMBDA, seed + 7)[0]
             d_r = [torch.from_numpy(iq_r.view(np.float32)).to(dev)]
             run_steps(3, [ctx], 1, d_r)
@@ -240,7 +312,7 @@ def main():
                 import oracle
                 extra["realistic_density"]["parity"] = bool(np.array_equal(pkr, oracle.demod(iq_r, rate, 7.0, True)))
             run_steps(2, [ctx], 1, d_batches)          # back to the main density (capacity estimate of the context)
-        if mode == "single" and not args.no_extra:
+        if mode == "single" and K == 1 and not args.no_extra:
             # the same step with the batch in HOST memory (a file source): pinned staging, two buffers in flight -- the PCIe copy
             # of batch k+1 overlaps the scan of batch k (am_uploader_*, what modes_rx does).  PCIe bound; reported separately,
             # never as `value`.  `pageable` = one synchronous host-to-device copy inside am_process_iq (round 2's figure).
@@ -391,10 +463,11 @@ def main():
         dist.all_reduce(one, op=dist.ReduceOp.SUM)               # (through the data-path backend itself: RCCL on the GPU box)
         ranks_seen = int(round(float(one[0].item())))
     if rank == 0:
-        total_samples = world * n * args.steps
+        total_samples = world * K * n * args.steps
         value = total_samples / dt
         fe_avg_ms = float(np.mean(fe_ranks))       # (one launch per rank and step, every rank the same n samples: the mean over ranks)
-        achieved = 8.0 * n / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
+        n_launch = int(k_total) if K > 1 else n    # samples the dominant kernel's launch reads (K streams: the zeros between them too)
+        achieved = 8.0 * n_launch / (fe_avg_ms * 1e-3) / 1e9 if fe_avg_ms > 0 else 0.0
         fe_kind = ctx.last_frontend()
         kernel_name = {3: ("am_k_fe3" if spc == 32 else "am_k_fe4<%d,G>" % spc) +
                           " (streaming fused |iq|^2 + PMF + reference level + preamble detection, sparse outputs)",
@@ -402,7 +475,7 @@ def main():
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "current_traffic.json")
-        if mode in ("single", "sharded") and os.path.exists(tj) and not args.emu:
+        if mode in ("single", "sharded") and K == 1 and os.path.exists(tj) and not args.emu:
             with open(tj) as f:
                 t = json.load(f)
             t = t.get(workload, {}) if "workload" not in t else t    # (one entry per workload)
@@ -419,7 +492,7 @@ def main():
                 else:
                     traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
                         t.get("kernel_source", "am_fe4.hip"), t.get("kernel_source_sha16"), sha)
-        par = {"single": "single GPU", "replicas": "%d independent receivers, one per GPU, no collective" % world,
+        par = {"single": "single GPU" if K == 1 else "single GPU, %d independent streams per scan (am_process_multi)" % K, "replicas": "%d independent receivers, one per GPU, no collective" % world,
                "sharded": "time-chunk shards x%d of one continuing stream, RCCL tail exchange + scan exit-table all-gather" % world}[mode]
         res = {
             "metric": "complex samples/sec demodulated (IQ -> Mode-S packet list)",
@@ -430,19 +503,19 @@ def main():
             "config": {"workload": "%s synthetic IQ, %.3g s per GPU per step (%d complex samples), Poisson %g "
                                    "bursts/s in AWGN, seed %d+rank(+100*batch), threshold 7 dB, pmf on%s"
                                    % (workload, secs, n, lam, seed,
-                                      {"single": "", "replicas": ", %d independent streams" % world,
+                                      {"single": "" if K == 1 else ", %d independent streams of that size per step, one scan" % K, "replicas": ", %d independent streams" % world,
                                        "sharded": ", one stream time-sharded over %d GPUs" % world}[mode]),
-                       "rate_sps": rate, "samples_per_gpu_per_step": n, "batches_in_flight": inflight,
+                       "rate_sps": rate, "samples_per_gpu_per_step": K * n, "streams_per_scan": K, "batches_in_flight": inflight,
                        "distinct_batches": nb, "packets_per_batch": per_batch, "bursts_per_second": lam,
                        "parallelism": par},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "kernel_ms": fe_avg_ms,
                          "kernel_ms_per_rank": {"min": min(fe_ranks), "max": max(fe_ranks)},
-                         "algorithmic_bytes_per_launch": 8 * n,
+                         "algorithmic_bytes_per_launch": 8 * n_launch,
                          # the whole path (all launches of a step, the host's turn-around included) priced the same way:
                          # algorithmic bytes per step / driver-timed step / HBM peak -- NOT the kernel's fraction
-                         "path_frac_of_hbm_peak": 8.0 * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "path_frac_of_hbm_peak": 8.0 * K * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
         coll = None
         if world > 1:
@@ -466,13 +539,15 @@ def main():
             cpu_dt = time.perf_counter() - t1
             if mode == "single":
                 res["parity"] = bool(np.array_equal(pk, want))
+                if K > 1:
+                    res["parity"] = bool(res["parity"] and extra["k_streams"]["parity_every_stream"])
             if not args.no_cpu_baseline or args.emu:
                 res["cpu_baseline"] = {"value": n / cpu_dt, "unit": "samples/s", "cores": 1, "kind": "port",
                                        "sample": "one %d-sample batch of this run, one pass of oracle/airmodes_oracle.c "
                                                  "(scalar C, gcc -O3, 1 thread), %.2f s" % (n, cpu_dt),
                                        "host_cores_available": os.cpu_count()}
                 res["speedup_vs_cpu_baseline"] = value / (n / cpu_dt)
-        if mode == "single" and not args.no_cpu_baseline and not args.emu:
+        if mode == "single" and K == 1 and not args.no_cpu_baseline and not args.emu:
             import oracle
             # the same port on every host core: the batch cut into one time chunk per thread (each with the
             # look-ahead a chunk needs), timed only -- SURVEY 8(d) asks for both figures

@@ -15,6 +15,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "csrc", "libairmodes_hip.so")
 
 AM_F_DEVICE_IN = 0x1
 AM_F_FLUSH = 0x2
+AM_F_ZERO_GAPS = 0x20
 AM_F_DEVICE_OUT = 0x4
 AM_F_KEEP_TAGS = 0x8
 AM_F_MORE = 0x10
@@ -94,6 +95,8 @@ class Library(object):
         L.am_last_num_tags.argtypes = [vp]
         L.am_frontend_work.argtypes = [vp, vp, u64, u32, vp, vp]
         L.am_preamble_work.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
+        L.am_multi_layout.argtypes = [vp, u32, vp, vp, pu64]
+        L.am_process_multi.argtypes = [vp, vp, u32, vp, u32, vp, u64, vp, pu64]
         L.am_preamble_stream.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
         L.am_slicer_work.argtypes = [vp, vp, vp, u64, u32, vp, u64, pu64]
         L.am_crc24.restype = u32
@@ -329,6 +332,53 @@ class Context(object):
         """Device-resident interleaved float32 IQ (e.g. torch tensor .data_ptr())."""
         return self._process(int(dev_ptr), int(n_complex), AM_F_DEVICE_IN | (AM_F_FLUSH if flush else 0) |
                              (AM_F_KEEP_TAGS if keep_tags else 0), capacity)
+
+    # K independent streams in one scan
+    def multi_layout(self, lengths):
+        """(offsets, total) in complex samples: where K whole streams of the given lengths lie in the ONE buffer
+        process_multi scans (zeros between them)."""
+        n = np.ascontiguousarray(lengths, np.uint64)
+        off = np.zeros(n.size, np.uint64)
+        total = C.c_uint64(0)
+        self._chk(self.lib.L.am_multi_layout(self._h, n.size, n.ctypes.data, off.ctypes.data, C.byref(total)))
+        return off, int(total.value)
+
+    def multi_pack(self, streams):
+        """Host helper: K streams (complex64 / interleaved float32) -> (buffer in the layout, lengths)."""
+        fs = [_iq_f32(x) for x in streams]
+        n = np.array([f.size // 2 for f in fs], np.uint64)
+        off, total = self.multi_layout(n)
+        buf = np.zeros(2 * total, np.float32)
+        for f, o in zip(fs, off):
+            buf[2 * int(o): 2 * int(o) + f.size] = f
+        return buf, n
+
+    def process_multi(self, buf, lengths, device_ptr=None, zero_gaps=False, capacity=None):
+        """One scan over K whole streams (am_process_multi): list of K packet arrays, each what
+        process_iq(stream, flush=True) gives.  buf: the packed host buffer, or device_ptr = the same on the device."""
+        n = np.ascontiguousarray(lengths, np.uint64)
+        _, total = self.multi_layout(n)
+        flags = AM_F_ZERO_GAPS if zero_gaps else 0
+        if device_ptr is not None:
+            ptr, flags = int(device_ptr), flags | AM_F_DEVICE_IN
+        else:
+            f = _iq_f32(buf)
+            assert f.size >= 2 * total
+            ptr = f.ctypes.data if total else None
+        cap = int(capacity) if capacity is not None else max(64, total // 2000 + 64)
+        out = self._receive_buffer(cap)
+        got = C.c_uint64(0)
+        cnt = np.zeros(n.size, np.uint64)
+        rc = self.lib.L.am_process_multi(self._h, ptr, n.size, n.ctypes.data, flags, out.ctypes.data, cap, cnt.ctypes.data,
+                                         C.byref(got))
+        if rc == AM_ECAPACITY:
+            pk = self._fetch(int(got.value))
+        else:
+            self._chk(rc)
+            pk = self._received(out, got.value)
+        assert int(cnt.sum()) == len(pk)
+        edges = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        return [pk[edges[j]:edges[j + 1]] for j in range(n.size)]
 
     def fetch_tags(self):
         """(bursts [n, 240] float32, tags) of the last process_iq(..., keep_tags=True) call: what the preamble block

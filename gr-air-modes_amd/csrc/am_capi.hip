@@ -117,6 +117,10 @@ struct am_ctx {
     DevBuf tt_dev;
 
     // stream state (absolute sample indices)
+    // K independent streams in one scan (am_process_multi): where stream j starts in the scanned buffer, the last position it may
+    // emit (-1: none), and the packets each one got; hand_out() sorts the scan's packets into streams while this is set
+    std::vector<uint64_t> multi_off, multi_cnt;
+    std::vector<int64_t> multi_em;
     // the block-level preamble as a STREAM (am_preamble_stream): items so far, first undecided position, where the greedy scan
     // resumes, and the tail of both inputs that the next call's decisions still read
     uint64_t pb_total = 0, pb_next = 0, pb_cur = 0, pb_carry_abs0 = 0, pb_carry_n = 0;
@@ -831,8 +835,37 @@ void collect_accepted(am_ctx *c)
     }
 }
 
+// The scan ran over K streams laid out one behind the other (am_multi_layout): a packet belongs to the stream whose items its
+// preamble lies in; positions a stream of its own would not have emitted (end-of-buffer rule, preamble_impl.cc:150,212 -- here they
+// see the zeros of the gap, there the scan ends) are dropped, which changes nothing for the others: a hit only ever suppresses LATER
+// positions, and the gap is longer than anything it can reach.  The item count becomes the stream's own; the time stamp already is
+// (one internal "rx_time" tag of 0 s at every stream's first item).
+void sort_into_streams(am_ctx *c)
+{
+    const uint64_t h0 = (uint64_t)c->geom.hist0;
+    const size_t K = c->multi_off.size();
+    c->multi_cnt.assign(K, 0);
+    size_t w = 0;
+    for (size_t i = 0; i < c->pending.size(); i++) {
+        am_packet p = c->pending[i];
+        const uint64_t pos = p.sample - h0;                       // position of the preamble in the scanned buffer
+        size_t j = (size_t)(std::upper_bound(c->multi_off.begin(), c->multi_off.end(), pos) - c->multi_off.begin());
+        if (j == 0) continue;
+        j--;
+        const uint64_t e = pos - c->multi_off[j];
+        if (c->multi_em[j] < 0 || e > (uint64_t)c->multi_em[j]) continue;
+        p.sample = e + h0;
+        c->pending[w++] = p;
+        c->multi_cnt[j]++;
+    }
+    c->pending.resize(w);
+    c->multi_off.clear();
+    c->multi_em.clear();
+}
+
 int hand_out(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
 {
+    if (!c->multi_off.empty()) sort_into_streams(c);
     const uint64_t n = c->pending.size();
     if (n_out) *n_out = n;
     if (n > cap) return fail(c, AM_ECAPACITY, "packet array too small; call am_fetch_packets");
@@ -1243,6 +1276,73 @@ int am_process_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags, am_pac
                   uint64_t *n_out)
 {
     return process_iq_core(c, iq, n, flags, out, cap, n_out, false);
+}
+
+// ---- K independent streams in ONE scan (the 2 / 20 Msps configurations off the launch floor) -----------------
+// Every stream is what am_process_iq(..., AM_F_FLUSH) takes: a whole stream from item 0.  They lie in ONE buffer, stream j at
+// sample offset[j], zeros between them; one scan of the whole buffer serves all of them -- the eight launches of a scan then carry
+// K streams' worth of samples.  Why this is exact and not an approximation:
+//  * offsets are multiples of 48 samples-per-chip, so every sum of the canonical order (blocks aligned to the absolute
+//    sample index) has the operands it has in the stream alone, and x + 0 = x;
+//  * the gap is longer than the reference level's window behind a stream's first item and than the reach of a hit behind a
+//    stream's last one (late shifts, 240 chips of skipped positions, the filter's tail), and a position whose own filter window is
+//    all zeros is never a candidate (in[i] > inavg[i] * threshold is strict, preamble_impl.cc:174);
+//  * what a stream of its own would not emit at its end is dropped afterwards (sort_into_streams).
+static uint64_t multi_gap(const am_ctx *c) { return (uint64_t)(AM_BURST + 4 + 48 + 16) * (uint64_t)c->spc_hi + (uint64_t)c->geom.hist0; }
+
+int am_multi_layout(am_ctx *c, uint32_t k, const uint64_t *n, uint64_t *offset, uint64_t *total)
+{
+    if (!c) return AM_EINVAL;
+    if (!k || !n || !offset) return fail(c, AM_EINVAL, "multi: no streams");
+    const uint64_t A = 48ull * (uint64_t)c->spc, G = multi_gap(c);
+    uint64_t at = 0;
+    for (uint32_t j = 0; j < k; j++) {
+        offset[j] = at;
+        const uint64_t end = at + n[j] + G;
+        at = (end + A - 1) / A * A;
+        if (j + 1 == k && total) *total = offset[j] + n[j];
+    }
+    return AM_OK;
+}
+
+int am_process_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32_t flags, am_packet *out, uint64_t cap,
+                     uint64_t *count, uint64_t *n_out)
+{
+    if (!c) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    if (!k || !n) return fail(c, AM_EINVAL, "multi: no streams");
+    if (k > AM_MAX_TIME_TAGS) return fail(c, AM_EINVAL, "multi: too many streams");
+    if (c->use_dcblock) return fail(c, AM_EINVAL, "multi: not with the DC blocker (its delay line outlasts the gaps)");
+    if (c->pend.active) return fail(c, AM_EINVAL, "multi: a submitted batch is waiting for am_collect");
+    HIPCHK(c, hipSetDevice(c->device));
+    reset_stream(c);                                              // every stream starts at item 0; pending rx_time tags are dropped
+    std::vector<uint64_t> off(k);
+    uint64_t total = 0;
+    int rc = am_multi_layout(c, k, n, off.data(), &total);
+    if (rc != AM_OK) return rc;
+    if (total >= ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "multi: more than 2^31 samples in one scan");
+    if (total && !iq) return fail(c, AM_EINVAL, "null input");
+    if (flags & AM_F_ZERO_GAPS)
+        for (uint32_t j = 0; j + 1 < k; j++) {
+            const uint64_t a = off[j] + n[j], b = off[j + 1];
+            if (flags & AM_F_DEVICE_IN) HIPCHK(c, hipMemsetAsync(iq + 2 * a, 0, (b - a) * 2 * sizeof(float), c->stream));
+            else memset(iq + 2 * a, 0, (b - a) * 2 * sizeof(float));
+        }
+    c->multi_off = off;
+    c->multi_em.assign(k, -1);
+    c->tt.clear();
+    for (uint32_t j = 0; j < k; j++) {
+        uint64_t em;
+        if (flush_limits(c, n[j], &em)) c->multi_em[j] = (int64_t)em;
+        const am_time_tag t = {off[j], 0, 0.0};                   // item counts and time restart with every stream
+        c->tt.push_back(t);
+    }
+    ENSURE(c, c->tt_dev, AM_MAX_TIME_TAGS * sizeof(am_time_tag));
+    HIPCHK(c, hipMemcpy(c->tt_dev.p, c->tt.data(), c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice));
+    rc = process_iq_core(c, iq, total, (flags & AM_F_DEVICE_IN) | AM_F_FLUSH, out, cap, n_out, false);
+    if (count) for (uint32_t j = 0; j < k; j++) count[j] = j < c->multi_cnt.size() ? c->multi_cnt[j] : 0;
+    if (rc != AM_OK && rc != AM_ECAPACITY) { c->multi_off.clear(); c->multi_em.clear(); }
+    return rc;
 }
 
 int am_submit_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags)

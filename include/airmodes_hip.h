@@ -52,6 +52,7 @@ extern "C" {
 #define AM_F_DEVICE_OUT 0x4u  /* am_frontend_work only: bb/avg are device pointers          */
 #define AM_F_MORE       0x10u /* am_shard_scan / am_shard_scan_async: the stream goes on beyond total_n (= the samples so
                                  far): no end-of-stream rule; the chunk must come with its whole right halo            */
+#define AM_F_ZERO_GAPS  0x20u /* am_process_multi: the library writes the zeros between the streams into the caller's buffer  */
 #define AM_F_KEEP_TAGS  0x8u  /* am_process_iq / am_submit_iq: also keep what the preamble block hands the slicer for
                                  this call's hits -- 240-float bursts + "preamble_found" tags (lib/preamble_impl.cc:
                                  219-232) -- for am_fetch_tags                                  */
@@ -196,6 +197,21 @@ AM_API int    am_reset(am_ctx *ctx);
 AM_API int am_process_iq(am_ctx *ctx, const float *iq, uint64_t n_complex, uint32_t flags,
                   am_packet *out, uint64_t cap, uint64_t *n_out);
 AM_API int am_fetch_packets(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out);
+
+/* K independent streams in ONE scan (many receivers / channels on one GPU: at 2 and 20 Msps one second of one receiver is too
+ * small a job for the chip, the scan's launches are what it costs).  Every stream is a WHOLE stream, as am_process_iq(...,
+ * AM_F_FLUSH) takes it -- rx_path.work over one finite capture (python/rx_path.py:27-65) -- and gets exactly the packets that call
+ * gives (bit for bit; item counts and time stamps are the stream's own, from its item 0).
+ * am_multi_layout   where the streams go in the ONE buffer the scan reads: offset[j] (in complex samples) for stream j of n[j]
+ *                   samples, *total = samples up to the end of the last one.  The samples between the streams must be ZERO (the
+ *                   caller writes them once, or passes AM_F_ZERO_GAPS and the library writes them on every call).
+ * am_process_multi  iq: that buffer (host, or device with AM_F_DEVICE_IN); out/cap/n_out as am_process_iq; the packets come
+ *                   stream by stream, in stream order inside each; count[j] (may be NULL) = packets of stream j.
+ *                   Not with use_dcblock; "rx_time" tags do not apply (every stream starts at 0 s);
+ *                   the context's stream state is reset before and after. */
+AM_API int am_multi_layout(am_ctx *ctx, uint32_t k, const uint64_t *n, uint64_t *offset, uint64_t *total);
+AM_API int am_process_multi(am_ctx *ctx, float *iq, uint32_t k, const uint64_t *n, uint32_t flags,
+                            am_packet *out, uint64_t cap, uint64_t *count, uint64_t *n_out);
 /* preamble hits (tags) seen by the last am_process_iq call, accepted or not */
 AM_API uint64_t am_last_num_tags(const am_ctx *ctx);
 /* The inter-block stream of the last am_process_iq / am_collect call that ran with AM_F_KEEP_TAGS: one 240-float burst

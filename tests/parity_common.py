@@ -284,6 +284,55 @@ def check_preamble_stream(lib, rate, n, lam, seed, thr=7.0, pmf=True, trials=4):
     return len(wt)
 
 
+def check_multi_streams(lib, rate, lengths, lam, seed, thr=7.0, pmf=True):
+    """K independent streams in ONE scan (am_process_multi) = K calls of process_iq(stream, flush=True), bit for bit, and = the
+    oracle on every stream: streams of different lengths, an empty one, one shorter than a burst, one that is all noise, bursts that
+    end exactly at a stream's end / start at its first sample; gaps zeroed by the caller and by the library."""
+    spc = max(int(rate / 2e6), 1)
+    rng = np.random.default_rng(seed)
+    streams = []
+    for j, n in enumerate(lengths):
+        if n < 300 * spc:
+            streams.append((rng.standard_normal(2 * n).astype(np.float32) * 0.01).view(np.complex64))
+            continue
+        iq, _ = synth.synth_capture(rate, n, lam if j != 2 else 0.0, seed + 17 * j)
+        iq = np.array(iq)
+        # a strong burst whose first pulse is the stream's first sample, and one that ends j chips before the stream does (around
+        # the end-of-buffer rule: some of these are emitted, some are not -- and their tails reach into the gap)
+        frame = synth.make_frame(rng, 17)
+        b = (np.repeat(synth.frame_chips(frame), spc) * np.float32(0.4)).astype(np.complex64)
+        if len(b) < n // 4:
+            iq[:len(b)] += b
+            e1 = n - j * spc - (j % 2)
+            iq[e1 - len(b):e1] += b * np.complex64(1j)
+        streams.append(iq)
+    ctx = _capi.Context(rate, thr, pmf, lib=lib)
+    want = [ctx.process_iq(x, flush=True) for x in streams]
+    whole = float(rate) == 2e6 * spc
+    if whole:
+        for x, w in zip(streams, want):
+            assert np.array_equal(oracle.demod(x, rate, thr, pmf), w)
+    buf, n = ctx.multi_pack(streams)
+    got = ctx.process_multi(buf, n)
+    assert len(got) == len(streams)
+    for j, (g, w) in enumerate(zip(got, want)):
+        assert g.tobytes() == w.tobytes(), "stream %d of %d differs: %d vs %d packets" % (j, len(streams), len(g), len(w))
+    # garbage between the streams, zeroed by the library
+    off, total = ctx.multi_layout(n)
+    dirty = buf.copy()
+    for j in range(len(streams) - 1):
+        a, b_ = int(off[j] + n[j]), int(off[j + 1])
+        dirty[2 * a:2 * b_] = 3.0
+    got2 = ctx.process_multi(dirty, n, zero_gaps=True)
+    assert all(g.tobytes() == w.tobytes() for g, w in zip(got2, want))
+    # a too small receive array: nothing is lost; the context is a plain single-stream receiver again afterwards
+    got3 = ctx.process_multi(buf, n, capacity=1)
+    assert all(g.tobytes() == w.tobytes() for g, w in zip(got3, want))
+    assert ctx.process_iq(streams[0], flush=True).tobytes() == want[0].tobytes()
+    ctx.close()
+    return sum(len(w) for w in want)
+
+
 def load_rx_time_golden(path):
     z = np.load(path)
     rx = [(int(o), int(s_), float(f)) for o, s_, f in zip(z["rx_offset"], z["rx_secs"], z["rx_frac"])]

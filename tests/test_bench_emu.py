@@ -74,3 +74,14 @@ def test_gpus_2_line_names_its_ranks_and_times_the_collectives(emu_lib):
     assert d["ranks"]["ranks_seen"] == 2 and len(d["ranks"]["per_rank"]) == 2
     h = d["host_dist_us_per_step"]
     assert h["steps_counted"] >= 2 and h["exit_table_all_gather_into_tensor"] > 0 and h["tail_exchange_batch_isend_irecv"] > 0
+
+
+def test_k_streams_per_scan_line(emu_lib):
+    """--streams K: K receivers' seconds in one scan per step (am_process_multi); value counts all of them, parity is every
+    stream's against the oracle."""
+    d = run_bench("--workload", "20msps", "--seconds", "0.01", "--streams", "3", "--no-cpu-baseline")
+    assert d["parity"] is True and d["config"]["streams_per_scan"] == 3
+    k = d["k_streams"]
+    assert k["parity_every_stream"] is True and k["same_as_single_stream_call"] is True and len(k["packets_per_stream"]) == 3
+    assert d["config"]["samples_per_gpu_per_step"] == 3 * k["samples_per_stream"]
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * k["samples_scanned_per_step"] > 8 * 3 * k["samples_per_stream"]

@@ -244,6 +244,16 @@ def test_preamble_block_as_a_stream(lib, rate, n, lam):
     assert pc.check_preamble_stream(lib, rate, n, lam, seed=int(rate / 1e5) + 3, trials=3) > 3
 
 
+@pytest.mark.parametrize("rate,lengths,lam", [(2e6, [600000, 0, 450000, 100, 800000, 523110, 700001, 640000], 3000.0),
+                                              (5e6, [900000, 750003, 800000], 2500.0),
+                                              (20e6, [4000000, 3000000, 3500001, 2500000, 777, 3200000, 2000000, 4100000], 6000.0),
+                                              (64e6, [6400000, 5000001, 6500000], 12000.0)])
+def test_k_streams_in_one_scan(lib, rate, lengths, lam):
+    """am_process_multi: K whole streams in one buffer, one scan; every stream's packets = its own am_process_iq(AM_F_FLUSH)
+    = the oracle's (streams of different lengths, empty, shorter than a burst, all noise; bursts at the very start / end)."""
+    assert pc.check_multi_streams(lib, rate, lengths, lam, seed=int(rate / 1e5) + 11) > 3 * len(lengths) // 2
+
+
 def test_chain_walk_beyond_64k_of_lds(lib):
     """Between 256 and 288 blocks of 2048 first-stage candidates in ONE scan (low threshold, dense traffic):
     the block-to-block walk of the greedy chain then keeps 128 head links per block = more than 64 KB in LDS,
