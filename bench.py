@@ -142,8 +142,8 @@ def main():
     ctx = new_ctx()
     extra = {}
     K = max(1, args.streams)
-    if K > 1 and mode != "single":
-        raise SystemExit("bench.py: --streams is a single-GPU figure (use --replicas for one receiver per GPU)")
+    if K > 1 and mode == "sharded":
+        raise SystemExit("bench.py: --streams goes with independent receivers (N = 1, or --replicas), not with one time-sharded stream")
 
     def k_streams_setup(k, nbatch):
         """k whole streams of the workload (different seeds) packed behind one another, zeros between them (am_multi_layout),
@@ -353,6 +353,8 @@ def main():
         if mode == "replicas":
             import oracle
             ok = bool(np.array_equal(pk, oracle.demod(iq_check, rate, 7.0, True)))
+            if K > 1:
+                ok = bool(ok and extra["k_streams"]["parity_every_stream"])
             if world > 1:
                 t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -492,7 +494,7 @@ def main():
                 else:
                     traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
                         t.get("kernel_source", "am_fe4.hip"), t.get("kernel_source_sha16"), sha)
-        par = {"single": "single GPU" if K == 1 else "single GPU, %d independent streams per scan (am_process_multi)" % K, "replicas": "%d independent receivers, one per GPU, no collective" % world,
+        par = {"single": "single GPU" if K == 1 else "single GPU, %d independent streams per scan (am_process_multi)" % K, "replicas": "%d independent receivers%s, one per GPU, no collective" % (world, "" if K == 1 else " x %d streams per scan" % K),
                "sharded": "time-chunk shards x%d of one continuing stream, RCCL tail exchange + scan exit-table all-gather" % world}[mode]
         res = {
             "metric": "complex samples/sec demodulated (IQ -> Mode-S packet list)",
@@ -503,7 +505,7 @@ def main():
             "config": {"workload": "%s synthetic IQ, %.3g s per GPU per step (%d complex samples), Poisson %g "
                                    "bursts/s in AWGN, seed %d+rank(+100*batch), threshold 7 dB, pmf on%s"
                                    % (workload, secs, n, lam, seed,
-                                      {"single": "" if K == 1 else ", %d independent streams of that size per step, one scan" % K, "replicas": ", %d independent streams" % world,
+                                      {"single": "" if K == 1 else ", %d independent streams of that size per step, one scan" % K, "replicas": ", %d independent streams" % (world * K),
                                        "sharded": ", one stream time-sharded over %d GPUs" % world}[mode]),
                        "rate_sps": rate, "samples_per_gpu_per_step": K * n, "streams_per_scan": K, "batches_in_flight": inflight,
                        "distinct_batches": nb, "packets_per_batch": per_batch, "bursts_per_second": lam,

@@ -16,7 +16,7 @@ a block does, and raises if the library or a HIP device is missing (no CPU fallb
 """
 from .msg_queue import message, msg_queue
 from .blocks import preamble, slicer
-from .rx_path import rx_path
+from .rx_path import rx_path, rx_path_bank
 from ._capi import AirModesError, Context, Library, PACKET_DTYPE, TAG_DTYPE, EXIT_DTYPE, shard_entries
 # message consumers (host side, after the hot path): python/__init__.py:45-63 exports the same names
 from .exceptions import *            # noqa: F401,F403
@@ -32,7 +32,7 @@ from .parse import (data_field, modes_reply, me_reply, mb_reply, mv_reply, bds09
 from .msprint import output_print
 from .pubsub import pubsub
 
-__all__ = ["message", "msg_queue", "preamble", "slicer", "rx_path", "AirModesError", "Context",
+__all__ = ["message", "msg_queue", "preamble", "slicer", "rx_path", "rx_path_bank", "AirModesError", "Context",
            "Library", "PACKET_DTYPE", "TAG_DTYPE", "EXIT_DTYPE", "shard_entries",
            "make_parser", "modes_reply", "output_print", "cpr_decoder", "decode_alt", "decode_id", "stamp",
            "modes_report", "pubsub", "ADSBError"]

@@ -74,3 +74,35 @@ class rx_path(object):
 
     def context(self):
         return self._ctx
+
+
+class rx_path_bank(object):
+    """K receivers of one kind on one GPU: what K rx_path instances (python/rx_path.py:25-88) give on K finite captures, from
+    ONE scan per call (am_process_multi: the captures lie behind one another in one buffer, zeros between them).  queues: one
+    gr.msg_queue per receiver -- receiver j's messages go to queues[j], formatted as its own slicer would (the first message of
+    every receiver carries the six significant digits of a fresh ostringstream, lib/slicer_impl.cc:186-192).  Every call is a set
+    of WHOLE streams (item counts and time stamps start at 0): the batch form of rx_path.work(capture, flush=True)."""
+
+    def __init__(self, rate, threshold, queues, use_pmf=False, device=-1, lib=None):
+        self._ctx = _capi.Context(float(int(rate)), float(threshold), use_pmf=use_pmf, device=device, lib=lib)
+        self._slicers = [_slicer(q, _ctx=self._ctx) for q in queues]
+        self.packets = [0] * len(queues)
+
+    def work(self, captures):
+        """captures: K complex64 (or interleaved float32) arrays, one per receiver; returns the K packet arrays."""
+        assert len(captures) == len(self._slicers)
+        buf, n = self._ctx.multi_pack(captures)
+        return self._post(self._ctx.process_multi(buf, n))
+
+    def work_device(self, dev_ptr, lengths):
+        """The same with the packed buffer (layout: context().multi_layout(lengths), zeros between the streams) already on the GPU."""
+        return self._post(self._ctx.process_multi(None, lengths, device_ptr=dev_ptr))
+
+    def _post(self, per_stream):
+        for j, pk in enumerate(per_stream):
+            self._slicers[j].post(pk)
+            self.packets[j] += len(pk)
+        return per_stream
+
+    def context(self):
+        return self._ctx

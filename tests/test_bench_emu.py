@@ -85,3 +85,9 @@ def test_k_streams_per_scan_line(emu_lib):
     assert k["parity_every_stream"] is True and k["same_as_single_stream_call"] is True and len(k["packets_per_stream"]) == 3
     assert d["config"]["samples_per_gpu_per_step"] == 3 * k["samples_per_stream"]
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 8 * k["samples_scanned_per_step"] > 8 * 3 * k["samples_per_stream"]
+
+
+def test_replicas_with_k_streams_each(emu_lib):
+    d = run_bench("--gpus", "2", "--replicas", "--streams", "2", "--seconds", "0.008", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["parity"] is True and d["config"]["streams_per_scan"] == 2
+    assert "x 2 streams per scan" in d["config"]["parallelism"] and "4 independent streams" in d["config"]["workload"]

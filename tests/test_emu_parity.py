@@ -367,3 +367,32 @@ def test_k_streams_in_one_scan(emu_lib, rate, lengths, lam):
     """am_process_multi -- K whole streams behind one another in one buffer, one scan, every stream's packets
     bit-identical to its own am_process_iq(..., AM_F_FLUSH)."""
     assert pc.check_multi_streams(emu_lib, rate, lengths, lam, seed=int(rate / 1e5) + 11) > 3 * len(lengths) // 2
+
+
+def test_rx_path_bank_posts_every_receivers_messages(emu_lib):
+    """air_modes.rx_path_bank: K receivers' captures in one scan; queue j gets what receiver j's own rx_path posts (text for text,
+    including the six-digit first message of every receiver's own slicer), twice in a row."""
+    import air_modes
+    rate, lens = 4e6, (120000, 90001, 0, 100000)
+    caps = [synth.synth_capture(rate, n, 3000.0, 77 + j)[0] for j, n in enumerate(lens)]
+
+    def drain(q):
+        out = []
+        while not q.empty_p():
+            out.append(q.delete_head().to_string())
+        return out
+    qs = [air_modes.msg_queue() for _ in caps]
+    bank = air_modes.rx_path_bank(rate, 7.0, qs, use_pmf=True, lib=emu_lib)
+    singles = []
+    for iq in caps:
+        q = air_modes.msg_queue()
+        rx = air_modes.rx_path(rate, 7.0, q, use_pmf=True, lib=emu_lib)
+        first = (rx.work(iq, flush=True), drain(q))[1]
+        second = (rx.work(iq, flush=True), drain(q))[1]
+        singles.append((first, second))
+    for rnd in range(2):
+        got = bank.work(caps)
+        assert [len(g) for g in got] == [len(s[rnd]) for s in singles]
+        for j, q in enumerate(qs):
+            assert drain(q) == singles[j][rnd]
+    assert sum(bank.packets) == 2 * sum(len(s[0]) for s in singles) > 20
