@@ -260,6 +260,30 @@ def main():
                 import oracle
                 extra["k_streams_per_scan"]["parity_every_stream"] = all(
                     g.tobytes() == oracle.demod(x, rate, 7.0, True).tobytes() for g, x in zip(got, kh[0]))
+            # the same with two scans in flight (two contexts, a host thread each): the host's share of a step -- copying ~20 k
+            # packets out of pinned memory, sorting them into streams -- hides behind the other scan's kernels
+            import threading
+            ctx2 = [ctx, new_ctx()]
+            ks2 = 2 * ks if not args.emu else 0          # (the CPU emulation of the kernels is not re-entrant)
+
+            def fly(w, count):
+                for _ in range(count):
+                    ctx2[w].process_multi(None, kl, device_ptr=kd[0].data_ptr())
+            for w in range(2):
+                fly(w, 3 if ks2 else 0)
+            sync()
+            tk1 = time.perf_counter()
+            ths = [threading.Thread(target=fly, args=(w, ks2 // 2)) for w in range(2)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            sync()
+            dtk2 = (time.perf_counter() - tk1) / max(ks2, 1)
+            extra["k_streams_per_scan"]["two_scans_in_flight"] = None if not ks2 else {
+                "value": KX * n / dtk2, "unit": "samples/s", "ms_per_step": dtk2 * 1e3, "host_threads": 2,
+                "path_frac_of_hbm_peak": 8.0 * KX * n / dtk2 / 1e9 / HBM_PEAK_GBS}
+            ctx2[1].close()
             del kd, kh
             run_steps(2, [ctx], 1, d_batches)
         if mode == "single" and K == 1 and not args.no_extra and not args.no_pipelined and inflight == 1 and args.steps >= 3:
