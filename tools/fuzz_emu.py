@@ -98,6 +98,35 @@ def main():
             with np.errstate(all="ignore"):
                 want2 = want if m * W * K == n else oracle.demod(iq[:m * W * K], rate, thr, pmf, use_dcblock=dc)
             assert same(got, want2), "case %d: streamed shards differ (%d vs %d packets, W=%d K=%d)" % (case, len(got), len(want2), W, K)
+        if not dc:
+            # K streams in one scan (am_process_multi): the capture cut into independent streams, an empty one and a stub among them
+            J = int(rng.integers(2, 6))
+            jc = sorted(int(x) for x in rng.integers(0, n + 1, J - 1))
+            pieces = [iq[a:b] for a, b in zip([0] + jc, jc + [n])]
+            if rng.integers(0, 2):
+                pieces.insert(int(rng.integers(0, len(pieces) + 1)), iq[:int(rng.integers(0, 200))])
+            ctx = _capi.Context(rate, thr, pmf, lib=lib)
+            buf, lens = ctx.multi_pack(pieces)
+            got_k = ctx.process_multi(buf, lens, zero_gaps=bool(rng.integers(0, 2)))
+            for j, (g, x) in enumerate(zip(got_k, pieces)):
+                with np.errstate(all="ignore"):
+                    w = oracle.demod(x, rate, thr, pmf)
+                assert same(g, w), "case %d: stream %d of %d in one scan differs (%d vs %d packets)" % (case, j, len(pieces), len(g), len(w))
+            # the preamble block as a stream (am_preamble_stream): random pieces of its two inputs against one work() over them
+            bb, avg = ctx.frontend_work(iq)
+            ctx.reset()
+            wb, wt = ctx.preamble_work(bb, avg)
+            ctx.reset()
+            pc_ = sorted(int(x) for x in rng.integers(0, n + 1, int(rng.integers(1, 7))))
+            gb, gt = [], []
+            for a, b in zip([0] + pc_, pc_ + [n]):
+                b_, t_ = ctx.preamble_stream(bb[a:b], avg[a:b], flush=False)
+                gb.append(b_); gt.append(t_)
+            b_, t_ = ctx.preamble_stream(bb[:0], avg[:0], flush=True)
+            gb.append(b_); gt.append(t_)
+            assert np.concatenate(gt).tobytes() == wt.tobytes() and np.concatenate(gb).tobytes() == wb.tobytes(), \
+                "case %d: the preamble block as a stream differs (cuts %s)" % (case, pc_)
+            ctx.close()
         print("case %3d ok: %5.0f Msps n=%8d lambda=%6.0f thr=%4.1f pmf=%d dc=%d kind=%d cuts=%s shards=%d packets=%d (%s build)"
               % (case, rate / 1e6, n, lam, thr, pmf, dc, kind, cuts, G, len(want), "rare" if case % 2 else "plain"), flush=True)
 
