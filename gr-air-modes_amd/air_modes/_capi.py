@@ -19,7 +19,7 @@ AM_F_ZERO_GAPS = 0x20
 AM_F_DEVICE_OUT = 0x4
 AM_F_KEEP_TAGS = 0x8
 AM_F_MORE = 0x10
-ABI_VERSION = 3
+ABI_VERSION = 4
 SHARD_MSG_HEADER = 2          # header entries of a device-side exit-table message (am_shard_scan_async)
 
 AM_OK, AM_EINVAL, AM_ENODEV, AM_ENOMEM, AM_EHIP, AM_ECAPACITY, AM_ENOTSUP = 0, -1, -2, -3, -4, -5, -6

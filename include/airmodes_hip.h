@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AM_ABI_VERSION 3
+#define AM_ABI_VERSION 4
 
 /* Export marker.  The library is built with -fvisibility=hidden: only what carries AM_API leaves the
  * shared object (the role AIR_MODES_API plays in the reference: include/gr_air_modes/api.h:27-31,

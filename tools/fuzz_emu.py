@@ -57,7 +57,14 @@ def main():
     emu = os.path.join(ROOT, "tests", "emu")
     subprocess.check_call(["make", "-s", "-C", emu])
     subprocess.check_call(["make", "-s", "-C", emu, "libairmodes_emu_rare.so"])
-    libs = [_capi.Library(os.path.join(emu, "libairmodes_emu.so")), _capi.Library(os.path.join(emu, "libairmodes_emu_rare.so"))]
+    # private copies: a campaign runs for an hour or two, and a rebuild of tests/emu in the meantime must not pull the file out from
+    # under it
+    import shutil
+    import tempfile
+    priv = tempfile.mkdtemp(prefix="fuzz_emu_")
+    for f in ("libairmodes_emu.so", "libairmodes_emu_rare.so"):
+        shutil.copy(os.path.join(emu, f), os.path.join(priv, f))
+    libs = [_capi.Library(os.path.join(priv, "libairmodes_emu.so")), _capi.Library(os.path.join(priv, "libairmodes_emu_rare.so"))]
     rng = np.random.default_rng(args.seed)
     rates = (2e6, 2e6, 4e6, 8e6, 10e6, 10e6, 16e6, 20e6, 20e6, 32e6, 40e6, 64e6, 64e6,
              3e6, 4.8e6, 5e6, 6.25e6, 7e6, 13e6, 25.5e6)       # (and rates that are not multiples of 2 MHz)
