@@ -97,6 +97,8 @@ class Library(object):
         L.am_preamble_work.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
         L.am_multi_layout.argtypes = [vp, u32, vp, vp, pu64]
         L.am_process_multi.argtypes = [vp, vp, u32, vp, u32, vp, u64, vp, pu64]
+        L.am_submit_multi.argtypes = [vp, vp, u32, vp, u32]
+        L.am_multi_counts.argtypes = [vp, vp, u32]
         L.am_preamble_stream.argtypes = [vp, vp, vp, u64, u32, vp, vp, u64, pu64]
         L.am_slicer_work.argtypes = [vp, vp, vp, u64, u32, vp, u64, pu64]
         L.am_crc24.restype = u32
@@ -379,6 +381,40 @@ class Context(object):
         assert int(cnt.sum()) == len(pk)
         edges = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         return [pk[edges[j]:edges[j + 1]] for j in range(n.size)]
+
+    def submit_multi(self, buf, lengths, device_ptr=None, zero_gaps=False):
+        """First half of process_multi (am_submit_multi): the scan is enqueued, nothing is waited for."""
+        n = np.ascontiguousarray(lengths, np.uint64)
+        flags = AM_F_ZERO_GAPS if zero_gaps else 0
+        if device_ptr is not None:
+            ptr, flags = int(device_ptr), flags | AM_F_DEVICE_IN
+            self._held_multi = None
+        else:
+            f = _iq_f32(buf)
+            ptr = f.ctypes.data if f.size else None
+            self._held_multi = f                      # the samples must stay valid until collect_multi
+        self._chk(self.lib.L.am_submit_multi(self._h, ptr, n.size, n.ctypes.data, flags))
+        self._multi_k = n.size
+
+    def collect_multi(self, capacity=None):
+        """Second half (am_collect + am_multi_counts): the K packet arrays of the scan submitted last."""
+        cap = int(capacity) if capacity is not None else max(4096, len(getattr(self, "_rxbuf", ())))
+        out = self._receive_buffer(cap)
+        got = C.c_uint64(0)
+        rc = self.lib.L.am_collect(self._h, out.ctypes.data, cap, C.byref(got))
+        if rc == AM_ECAPACITY:
+            pk = self._fetch(int(got.value))
+            if capacity is None:
+                self._rxbuf = np.zeros(int(got.value) + 1024, PACKET_DTYPE)
+        else:
+            self._chk(rc)
+            pk = self._received(out, got.value)
+        self._held_multi = None
+        cnt = np.zeros(self._multi_k, np.uint64)
+        self._chk(self.lib.L.am_multi_counts(self._h, cnt.ctypes.data, cnt.size))
+        edges = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        assert int(edges[-1]) == len(pk)
+        return [pk[edges[j]:edges[j + 1]] for j in range(cnt.size)]
 
     def fetch_tags(self):
         """(bursts [n, 240] float32, tags) of the last process_iq(..., keep_tags=True) call: what the preamble block

@@ -1102,6 +1102,8 @@ int am_reset(am_ctx *c)
     if (!c) return AM_EINVAL;
     reset_stream(c);
     c->pending.clear();
+    c->multi_off.clear();
+    c->multi_em.clear();
     return AM_OK;
 }
 
@@ -1305,11 +1307,9 @@ int am_multi_layout(am_ctx *c, uint32_t k, const uint64_t *n, uint64_t *offset, 
     return AM_OK;
 }
 
-int am_process_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32_t flags, am_packet *out, uint64_t cap,
-                     uint64_t *count, uint64_t *n_out)
+// what am_process_multi and am_submit_multi share: the layout, the zeros, the per-stream limits and the internal time tags
+static int multi_begin(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32_t flags, uint64_t *total)
 {
-    if (!c) return AM_EINVAL;
-    if (n_out) *n_out = 0;
     if (!k || !n) return fail(c, AM_EINVAL, "multi: no streams");
     if (k > AM_MAX_TIME_TAGS) return fail(c, AM_EINVAL, "multi: too many streams");
     if (c->use_dcblock) return fail(c, AM_EINVAL, "multi: not with the DC blocker (its delay line outlasts the gaps)");
@@ -1317,11 +1317,10 @@ int am_process_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32
     HIPCHK(c, hipSetDevice(c->device));
     reset_stream(c);                                              // every stream starts at item 0; pending rx_time tags are dropped
     std::vector<uint64_t> off(k);
-    uint64_t total = 0;
-    int rc = am_multi_layout(c, k, n, off.data(), &total);
+    int rc = am_multi_layout(c, k, n, off.data(), total);
     if (rc != AM_OK) return rc;
-    if (total >= ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "multi: more than 2^31 samples in one scan");
-    if (total && !iq) return fail(c, AM_EINVAL, "null input");
+    if (*total >= ((uint64_t)1 << 31)) return fail(c, AM_EINVAL, "multi: more than 2^31 samples in one scan");
+    if (*total && !iq) return fail(c, AM_EINVAL, "null input");
     if (flags & AM_F_ZERO_GAPS)
         for (uint32_t j = 0; j + 1 < k; j++) {
             const uint64_t a = off[j] + n[j], b = off[j + 1];
@@ -1330,6 +1329,7 @@ int am_process_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32
         }
     c->multi_off = off;
     c->multi_em.assign(k, -1);
+    c->multi_cnt.assign(k, 0);
     c->tt.clear();
     for (uint32_t j = 0; j < k; j++) {
         uint64_t em;
@@ -1338,11 +1338,46 @@ int am_process_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32
         c->tt.push_back(t);
     }
     ENSURE(c, c->tt_dev, AM_MAX_TIME_TAGS * sizeof(am_time_tag));
+    // (a plain copy: the context is idle -- its last scan was collected -- so nothing on its stream still reads the table)
     HIPCHK(c, hipMemcpy(c->tt_dev.p, c->tt.data(), c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice));
+    return AM_OK;
+}
+
+int am_process_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32_t flags, am_packet *out, uint64_t cap,
+                     uint64_t *count, uint64_t *n_out)
+{
+    if (!c) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    uint64_t total = 0;
+    int rc = multi_begin(c, iq, k, n, flags, &total);
+    if (rc != AM_OK) return rc;
     rc = process_iq_core(c, iq, total, (flags & AM_F_DEVICE_IN) | AM_F_FLUSH, out, cap, n_out, false);
     if (count) for (uint32_t j = 0; j < k; j++) count[j] = j < c->multi_cnt.size() ? c->multi_cnt[j] : 0;
     if (rc != AM_OK && rc != AM_ECAPACITY) { c->multi_off.clear(); c->multi_em.clear(); }
     return rc;
+}
+
+// The two halves, as am_submit_iq / am_collect are the halves of am_process_iq: am_submit_multi enqueues the scan of the K streams
+// and returns; am_collect (the same call as for a single stream) waits for it and hands the packets out stream by stream;
+// am_multi_counts then says how many each stream got.  Two contexts used alternately by one host thread keep the GPU busy while
+// the host copies the previous scan's packets.
+int am_submit_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32_t flags)
+{
+    if (!c) return AM_EINVAL;
+    uint64_t total = 0;
+    int rc = multi_begin(c, iq, k, n, flags, &total);
+    if (rc != AM_OK) return rc;
+    rc = process_iq_core(c, iq, total, (flags & AM_F_DEVICE_IN) | AM_F_FLUSH, nullptr, 0, nullptr, true);
+    if (rc != AM_OK) { c->multi_off.clear(); c->multi_em.clear(); }
+    return rc;
+}
+
+int am_multi_counts(am_ctx *c, uint64_t *count, uint32_t k)
+{
+    if (!c) return AM_EINVAL;
+    if (!count || k != c->multi_cnt.size()) return fail(c, AM_EINVAL, "multi: the last collected scan had another number of streams");
+    for (uint32_t j = 0; j < k; j++) count[j] = c->multi_cnt[j];
+    return AM_OK;
 }
 
 int am_submit_iq(am_ctx *c, const float *iq, uint64_t n, uint32_t flags)
@@ -1372,7 +1407,7 @@ int am_collect(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out)
                                          P.max_hits);
             }
         }
-        if (rc != AM_OK) { P.active = false; P.scanned = false; reset_stream(c); return rc; }
+        if (rc != AM_OK) { P.active = false; P.scanned = false; reset_stream(c); c->multi_off.clear(); c->multi_em.clear(); return rc; }
         c->spec_density = (P.j1 > P.j0) ? (double)c->last_M / (double)(P.j1 - P.j0) : 0.0;
         c->last_tags = c->n_hits;
     }

@@ -212,6 +212,11 @@ AM_API int am_fetch_packets(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t 
 AM_API int am_multi_layout(am_ctx *ctx, uint32_t k, const uint64_t *n, uint64_t *offset, uint64_t *total);
 AM_API int am_process_multi(am_ctx *ctx, float *iq, uint32_t k, const uint64_t *n, uint32_t flags,
                             am_packet *out, uint64_t cap, uint64_t *count, uint64_t *n_out);
+/* The same in two halves (as am_submit_iq / am_collect): am_submit_multi enqueues the scan and returns (the buffer must stay valid
+ * until the scan is collected); am_collect -- the call that collects a single-stream batch -- waits for it and hands out the
+ * packets, stream by stream; am_multi_counts(count, k) then gives the packets per stream of the scan just collected. */
+AM_API int am_submit_multi(am_ctx *ctx, float *iq, uint32_t k, const uint64_t *n, uint32_t flags);
+AM_API int am_multi_counts(am_ctx *ctx, uint64_t *count, uint32_t k);
 /* preamble hits (tags) seen by the last am_process_iq call, accepted or not */
 AM_API uint64_t am_last_num_tags(const am_ctx *ctx);
 /* The inter-block stream of the last am_process_iq / am_collect call that ran with AM_F_KEEP_TAGS: one 240-float burst

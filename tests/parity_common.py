@@ -329,6 +329,28 @@ def check_multi_streams(lib, rate, lengths, lam, seed, thr=7.0, pmf=True):
     got3 = ctx.process_multi(buf, n, capacity=1)
     assert all(g.tobytes() == w.tobytes() for g, w in zip(got3, want))
     assert ctx.process_iq(streams[0], flush=True).tobytes() == want[0].tobytes()
+    # the two halves (am_submit_multi / am_collect / am_multi_counts), two contexts used alternately by this one thread
+    ctx2 = _capi.Context(rate, thr, pmf, lib=lib)
+    half = max(1, len(streams) // 2)
+    bufa, na = ctx.multi_pack(streams[:half])
+    bufb, nb_ = ctx2.multi_pack(streams[half:] or streams[:1])
+    ctx.submit_multi(bufa, na)
+    ctx2.submit_multi(bufb, nb_)
+    try:
+        ctx.submit_multi(bufa, na)                          # not collected yet
+        raise AssertionError("second submit accepted")
+    except _capi.AirModesError:
+        pass
+    ga = ctx.collect_multi(capacity=1)                      # (too small: am_fetch_packets serves it)
+    ctx.submit_multi(bufa, na)
+    gb = ctx2.collect_multi()
+    ga2 = ctx.collect_multi()
+    wb = want[half:] or want[:1]
+    assert all(g.tobytes() == w.tobytes() for g, w in zip(ga, want[:half])) and len(ga) == half
+    assert all(g.tobytes() == w.tobytes() for g, w in zip(ga2, want[:half]))
+    assert all(g.tobytes() == w.tobytes() for g, w in zip(gb, wb)) and len(gb) == len(wb)
+    assert ctx.process_iq(streams[0], flush=True).tobytes() == want[0].tobytes()
+    ctx2.close()
     ctx.close()
     return sum(len(w) for w in want)
 

@@ -396,3 +396,23 @@ def test_rx_path_bank_posts_every_receivers_messages(emu_lib):
         for j, q in enumerate(qs):
             assert drain(q) == singles[j][rnd]
     assert sum(bank.packets) == 2 * sum(len(s[0]) for s in singles) > 20
+
+
+def test_k_streams_usage_errors(emu_lib):
+    """am_process_multi refuses what it cannot do exactly: the DC blocker (its delay line outlasts the gaps), no streams at all;
+    one stream is the plain flush call; the layout's offsets are multiples of 48 samples-per-chip with room for a hit's reach."""
+    ctx = _capi.Context(8e6, 7.0, True, use_dcblock=True, lib=emu_lib)
+    iq, _ = synth.synth_capture(8e6, 60000, 3000.0, 5)
+    buf, n = ctx.multi_pack([iq, iq[:30000]])
+    with pytest.raises(_capi.AirModesError):
+        ctx.process_multi(buf, n)
+    ctx.close()
+    ctx = _capi.Context(8e6, 7.0, True, lib=emu_lib)
+    with pytest.raises(_capi.AirModesError):
+        ctx.multi_layout(np.zeros(0, np.uint64))
+    off, total = ctx.multi_layout([60000, 1, 0, 30000])
+    assert off[0] == 0 and all(int(o) % (48 * 4) == 0 for o in off) and total == int(off[3]) + 30000
+    assert all(int(off[j + 1]) - int(off[j]) - m >= (240 + 4 + 48) * 4 for j, m in enumerate([60000, 1, 0]))
+    one = ctx.process_multi(*ctx.multi_pack([iq]))
+    assert len(one) == 1 and one[0].tobytes() == ctx.process_iq(iq, flush=True).tobytes() and len(one[0]) > 3
+    ctx.close()
