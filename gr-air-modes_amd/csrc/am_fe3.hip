@@ -34,6 +34,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 #include <vector>
@@ -617,6 +618,10 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     for (int k = 0; k < 12; ++k) PR.acc[k] = 0;
     PR.last = (long long)__builtin_readcyclecounter();
+    PR.acc[8] = (long long)wall_clock64();                            // the workgroup's timeline (100 MHz): start,
+    // where it runs: HW_ID (register 4: cu_id [11:8], sh_id [12], se_id [15:13]) and XCC_ID (register 20, [3:0])
+    PR.acc[7] = (long long)(((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                            (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));
 #endif
     float mxrun = 0.0f;                                               // largest bb this thread has formed
     bool badrun = false;                                              // ... or one that is not finite
@@ -629,6 +634,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
 #if defined(__HIP_DEVICE_COMPILE__)                                   //  hoisted out of the loop those values cost 15 VGPRs of 168)
         asm volatile("" : "+v"(tid));
 #endif
+        fes_step_priority((unsigned)(step - sb + 1));                   // (am_fe_stream.h: the CU's workgroups end together)
         FE3_STAMP(4);
         // (the ring slots about to be staged were read by the previous step's phase B: its last barrier is behind us)
         // load, wait, stage.  The step before the segment only feeds the rings: the first chip tested is chip
@@ -646,6 +652,10 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         par ^= 1;
         FE3_STAMP(6);
         fes_barrier();                                                // B5: every ring read of this step done
+#if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        if (step == sb - 1) PR.acc[9] = (long long)wall_clock64();    // rings rebuilt,
+        if (step == sb) PR.acc[11] = (long long)wall_clock64();       // first tested step done,
+#endif
     }
     // the largest sample of the segment (with the chips the ring rebuild went through): +inf if one was not finite
     {
@@ -668,6 +678,7 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
         }
     }
 #if defined(FE3_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    PR.acc[10] = (long long)wall_clock64();                           // end
     if (a.prof && (tid0 & (AM_WAVE - 1)) == 0)
         for (int k = 0; k < 12; ++k) a.prof[((size_t)blockIdx.x * FE3_NW + tid0 / AM_WAVE) * 12 + k] = PR.acc[k];
 #endif
@@ -756,11 +767,74 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
                 for (int k = 0; k < 12; ++k) acc[k] += (double)h[((size_t)b * FE3_NW + w) * 12 + k];
             const double steps = (double)grid * (double)(spw + 1);
             double tot = 0;
-            for (int k = 0; k < 11; ++k) tot += acc[k];
+            for (int k = 0; k < 7; ++k) tot += acc[k];
             fprintf(stderr, "fe3 clocks/step wave %d (total %.0f):", w, tot / steps);
             static const int order[7] = {5, 0, 1, 2, 3, 6, 4};       // order of execution
             for (int k = 0; k < 7; ++k) fprintf(stderr, " %s:%.0f", names[order[k]], acc[order[k]] / steps);
             fprintf(stderr, "\n");
+        }
+        // the launch's timeline from wave 0 of every workgroup (wall clock, 10 ns ticks): when the workgroups start, when their rings
+        // are rebuilt, when the first tested step is done, when they end -- in microseconds after the first start
+        {
+            std::vector<double> t0(grid), t1(grid), t2(grid), t3(grid);
+            long long first = h[8];
+            for (unsigned b = 0; b < grid; ++b) first = std::min(first, h[(size_t)b * FE3_NW * 12 + 8]);
+            for (unsigned b = 0; b < grid; ++b) {
+                const long long *q = &h[(size_t)b * FE3_NW * 12];
+                t0[b] = (double)(q[8] - first) * 0.01; t1[b] = (double)(q[9] - first) * 0.01;
+                t2[b] = (double)(q[11] - first) * 0.01; t3[b] = (double)(q[10] - first) * 0.01;
+            }
+            auto pct = [&](std::vector<double> v, const char *name) {
+                std::sort(v.begin(), v.end());
+                const size_t n = v.size();
+                fprintf(stderr, "fe3 timeline %-22s us after the first start: min %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f\n", name, v[0],
+                        v[n / 10], v[n / 2], v[(size_t)(n * 0.9)], v[(size_t)(n * 0.99)], v[n - 1]);
+            };
+            pct(t0, "start"); pct(t1, "rings rebuilt"); pct(t2, "first tested step done"); pct(t3, "end");
+            std::vector<double> dur(grid), per(grid);
+            for (unsigned b = 0; b < grid; ++b) { dur[b] = t3[b] - t0[b]; per[b] = (t3[b] - t2[b]) / (double)(spw > 1 ? spw - 1 : 1); }
+            pct(dur, "duration");
+            pct(per, "per step after the 1st");
+            // by CU: do a CU's workgroups end together (the chip drains CU by CU) or one after the other (every CU is busy to the end)?
+            {
+                std::vector<std::pair<unsigned, unsigned>> key(grid);      // (cu key, workgroup)
+                for (unsigned b = 0; b < grid; ++b) {
+                    const unsigned long long w = (unsigned long long)h[(size_t)b * FE3_NW * 12 + 7];
+                    const unsigned hw = (unsigned)w, xcc = (unsigned)(w >> 32) & 15u;
+                    key[b] = {(xcc << 12) | (((hw >> 13) & 7u) << 8) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u), b};
+                }
+                std::sort(key.begin(), key.end());
+                std::vector<double> cu_first, cu_last, cu_n, rank_end[8];
+                for (size_t i = 0; i < key.size();) {
+                    size_t j = i;
+                    std::vector<std::pair<double, double>> se;          // (start, end) of the CU's workgroups
+                    while (j < key.size() && key[j].first == key[i].first) { se.push_back({t0[key[j].second], t3[key[j].second]}); j++; }
+                    std::sort(se.begin(), se.end());
+                    double lo = se[0].second, hi = se[0].second;
+                    for (size_t k = 0; k < se.size(); ++k) {
+                        lo = std::min(lo, se[k].second); hi = std::max(hi, se[k].second);
+                        if (k < 8) rank_end[k].push_back(se[k].second);
+                    }
+                    cu_first.push_back(lo); cu_last.push_back(hi); cu_n.push_back((double)se.size());
+                    i = j;
+                }
+                fprintf(stderr, "fe3 timeline: %zu CUs seen\n", cu_n.size());
+                pct(cu_n, "workgroups per CU");
+                pct(cu_first, "a CU's first end");
+                pct(cu_last, "a CU's last end");
+                for (int k = 0; k < 8; ++k)
+                    if (!rank_end[k].empty()) {
+                        char nm[64];
+                        snprintf(nm, sizeof nm, "end of a CU's %d. started", k + 1);
+                        pct(rank_end[k], nm);
+                    }
+            }
+            // by XCD (workgroups are dealt round-robin over the eight XCDs)
+            for (int x = 0; x < 8; ++x) {
+                double e = 0, m = 0; unsigned n = 0;
+                for (unsigned b = (unsigned)x; b < grid; b += 8) { e += t3[b]; m = std::max(m, t3[b]); n++; }
+                fprintf(stderr, "fe3 timeline xcd %d: mean end %.1f last end %.1f (%u workgroups)\n", x, n ? e / n : 0.0, m, n);
+            }
         }
     }
 #endif

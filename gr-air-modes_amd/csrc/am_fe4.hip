@@ -784,6 +784,7 @@ __global__ void __launch_bounds__(AM_WAVE * NW, (fe4_cfg<SPC, G, NW>::MINW)) am_
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(tid));
 #endif
+        fes_step_priority((unsigned)(step - sb + 1));                   // (am_fe_stream.h: the CU's workgroups end together)
         FE4_STAMP(4);
         if (have) {
             if (test) fe4_stage_rows<SPC, G, NW, 0>(a, L, a.out_abs0 + (long long)step * C::T, slot0, tid);

@@ -147,6 +147,28 @@ __device__ __forceinline__ float4 fes_gload16_cached_at(unsigned long long base,
 #endif
 }
 
+// Wave priority by step (round 5).  A CU's arbiters serve the OLDEST wave first, so of the six persistent workgroups of a CU the
+// first started ran ahead of the others all the way: it ended at ~78 us of a 110 us launch, the last started at ~104 (profiling
+// build's timeline, profiles/r5_prio) -- every CU worked through its last quarter with ever fewer workgroups to hide latency
+// behind, and the chip's memory system with ever fewer requests in flight.  A priority that falls with the step index modulo 4
+// puts a workgroup that is one step behind one level ABOVE its neighbour three times out of four: the six stay within a step
+// of each other and end together (first / last end of a CU: 88 / 97 us).  Scheduling only: no result depends on it.
+#ifndef FES_STEP_PRIO
+#define FES_STEP_PRIO 1
+#endif
+__device__ __forceinline__ void fes_step_priority(unsigned k)
+{
+#if FES_STEP_PRIO && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lvl = 3u - (k & 3u);
+    if (lvl == 0u) __builtin_amdgcn_s_setprio(0);
+    else if (lvl == 1u) __builtin_amdgcn_s_setprio(1);
+    else if (lvl == 2u) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+#else
+    (void)k;
+#endif
+}
+
 static inline long long fes_floor_div(long long x, long long d) { return x >= 0 ? x / d : -((-x + d - 1) / d); }
 static inline long long fes_ceil_div(long long x, long long d) { return -fes_floor_div(-x, d); }
 
