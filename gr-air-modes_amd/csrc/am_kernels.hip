@@ -2448,6 +2448,8 @@ am_k_extract_slice_iq(const float *__restrict__ iq, long long src_abs0, long lon
     // twice as many hits in flight, the second 112 chips by the same threads: 62.8 us.)
     // (Taking a hit's candidate index, refined position, reference level and first-stage position one hit AHEAD, so that
     // those two dependent round trips ride along with the current hit's sample loads, changed nothing: 54.8 against 54.7 us.)
+    // (A wave priority that falls with the turn of this loop, as in the streaming front ends -- am_fe_stream.h -- changed nothing here:
+    // 37.7 against 37.6 us, profiles/r5_prio.  Eight workgroups of ~10 short turns each do not run apart the way six long-lived ones do.)
     for (uint32_t i = blockIdx.x; i < nhit; i += gridDim.x) {                 // (uniform)
         const uint4 rec = emit_idx[i];                                        // one load per hit (am_k_cblk_mark filed everything)
         const uint32_t e = rec.z;
