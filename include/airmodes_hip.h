@@ -245,7 +245,8 @@ AM_API int am_preamble_work(am_ctx *ctx, const float *in, const float *inavg, ui
  * samples-per-chip items of look-ahead, the undecided tail of both inputs is carried inside the context, the greedy scan resumes
  * where it stopped (consume_each, :213,237,244), item counts and time stamps keep counting.  AM_F_FLUSH: these are the stream's last
  * items (end-of-buffer rule :150,212); the next call starts a new stream at item 0.  am_reset() drops the carried state.
- * bursts / tags: this call's hits, cap entries; AM_ECAPACITY with *n_out = the number needed if they do not fit. */
+ * bursts / tags: this call's hits, cap entries; AM_ECAPACITY with *n_out = the number needed if they do not fit (nothing is lost,
+ * the stream has moved on: am_fetch_tags hands them out).  With AM_F_DEVICE_IN both inputs are device pointers. */
 AM_API int am_preamble_stream(am_ctx *ctx, const float *in, const float *inavg, uint64_t n, uint32_t flags,
                               float *bursts, am_tag *tags, uint64_t cap, uint64_t *n_out);
 AM_API int am_slicer_work(am_ctx *ctx, const float *bursts, const am_tag *tags, uint64_t nbursts,

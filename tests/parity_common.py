@@ -281,6 +281,15 @@ def check_preamble_stream(lib, rate, n, lam, seed, thr=7.0, pmf=True, trials=4):
     blk.reset()
     b1, t1 = blk.general_work(obb, oavg, flush=True)
     assert np.array_equal(t1, t0)
+    # arrays too small: AM_ECAPACITY says how many, the hits wait for am_fetch_tags
+    import ctypes as C
+    cx = blk._ctx
+    got = C.c_uint64(0)
+    a_, b_ = np.ascontiguousarray(obb, np.float32), np.ascontiguousarray(oavg, np.float32)
+    rc = lib.L.am_preamble_stream(cx._h, a_.ctypes.data, b_.ctypes.data, n, _capi.AM_F_FLUSH, None, None, 0, C.byref(got))
+    assert rc == _capi.AM_ECAPACITY and got.value == len(t0)
+    fb, ft = cx.fetch_tags()
+    assert np.array_equal(ft, t0) and np.array_equal(u32(fb), u32(b0))
     return len(wt)
 
 
