@@ -2,7 +2,8 @@
 #   fe3prof : streaming front end with per-phase cycle stamps (-DFE3_PROFILE; prints on stderr, blocking)
 #   extra -D flags for an ad-hoc variant:  NAME=foo DEFS="-DFE3_X=1" bash tools/build_variants.sh
 # Compile-time knobs the sources understand (none of them exists in the default build):
-#   front end   -DFE3_PROFILE (phase clocks)  -DFE3_ABLATE=mask (results invalid: 1 no sparse outputs, 16 no reference-level rows,
+#   front end   -DFE3_PROFILE (phase clocks + the launch's timeline: every workgroup's start / end / CU)  -DFES_STEP_PRIO=0 (no wave priority by step)
+#               -DFE3_ABLATE=mask (results invalid: 1 no sparse outputs, 16 no reference-level rows,
 #               32 no bb rows)  -DFE3_NW -DFE3_WG_PER_CU -DFE3_CR_EXTRA=n (ring chips)  -DFE3_FORCE_SPW=n (steps per workgroup)
 #               -DFE4_PROFILE -DFE4_ABLATE=mask -DFE4_64MSPS (64 Msps through am_k_fe4<32,1,FE4_NW64>)  -DFE2_PROFILING (tile kernel)
 #   extraction  -DAM_XPROF (phase clocks + per-workgroup lifetimes, printed when a context is destroyed)
