@@ -1042,9 +1042,10 @@ int am_set_rx_time(am_ctx *c, uint64_t offset, uint64_t secs, double frac)
     if (!c->tt.empty() && offset < c->tt.back().offset)
         return fail(c, AM_EINVAL, "rx_time: tag offsets must not go backwards");
     // tags no future preamble can refer to: all but the newest one at or before the scan position
+    const uint64_t scanned = std::max<uint64_t>(c->chain_cur, c->pb_cur);     // (am_process_iq's stream or am_preamble_stream's)
     size_t keep_from = 0;
     for (size_t i = 0; i < c->tt.size(); i++)
-        if (c->tt[i].offset <= c->chain_cur) keep_from = i;
+        if (c->tt[i].offset <= scanned) keep_from = i;
     if (keep_from) c->tt.erase(c->tt.begin(), c->tt.begin() + (long)keep_from);
     const am_time_tag t = {offset, secs, frac};
     if (!c->tt.empty() && c->tt.back().offset == offset) c->tt.back() = t;    // tstamp_tags.back(): the later one wins
