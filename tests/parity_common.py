@@ -364,6 +364,31 @@ def check_multi_streams(lib, rate, lengths, lam, seed, thr=7.0, pmf=True):
     return sum(len(w) for w in want)
 
 
+def check_streamed_preamble_many_rx_time_tags(lib):
+    """A long block-level stream with more "rx_time" tags than the context's table holds at once (4096): tags no future hit can
+    refer to are dropped as the scan moves on (am_set_rx_time prunes by the streamed block's position too); the oracle, which takes
+    all of them at once, is the witness."""
+    import air_modes
+    rate, n, spc = 2e6, 160000, 1
+    iq, _ = synth.synth_capture(rate, n, 4000.0, 321)
+    bb, avg = oracle.frontend(iq, spc, True)
+    rx = [(k * 32, 1600000000 + k, 0.25) for k in range(n // 32)]         # 5 000 tags
+    assert len(rx) > 4096
+    ob, ot = oracle.preamble_scan(bb, avg, spc, 7.0, rate, rx_time=rx)
+    blk = air_modes.preamble(rate, 7.0, lib=lib)
+    gt = []
+    step = 4000
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        _, t = blk.general_work(bb[a:b], avg[a:b], rx_time=[x for x in rx if a <= x[0] < b])
+        gt.append(t)
+    _, t = blk.general_work(bb[:0], avg[:0], flush=True)
+    gt.append(t)
+    gt = np.concatenate(gt)
+    assert len(gt) > 100 and np.array_equal(gt, ot)
+    return len(gt)
+
+
 def load_rx_time_golden(path):
     z = np.load(path)
     rx = [(int(o), int(s_), float(f)) for o, s_, f in zip(z["rx_offset"], z["rx_secs"], z["rx_frac"])]

@@ -419,24 +419,5 @@ def test_k_streams_usage_errors(emu_lib):
 
 
 def test_streamed_preamble_block_drops_spent_rx_time_tags(emu_lib):
-    """A long block-level stream with more "rx_time" tags than the context's table holds at once (4096): tags no future hit can
-    refer to are dropped as the scan moves on (am_set_rx_time prunes by the streamed block's position too), the time stamps are
-    those of one work() -- which is handed the tags a few at a time as well, so the oracle is the witness for all of them."""
-    import air_modes
-    rate, n, spc = 2e6, 160000, 1
-    iq, _ = synth.synth_capture(rate, n, 4000.0, 321)
-    bb, avg = oracle.frontend(iq, spc, True)
-    rx = [(k * 32, 1600000000 + k, 0.25) for k in range(n // 32)]         # 5 000 tags
-    assert len(rx) > 4096
-    ob, ot = oracle.preamble_scan(bb, avg, spc, 7.0, rate, rx_time=rx)
-    blk = air_modes.preamble(rate, 7.0, lib=emu_lib)
-    gt = []
-    step = 4000
-    for a in range(0, n, step):
-        b = min(n, a + step)
-        _, t = blk.general_work(bb[a:b], avg[a:b], rx_time=[x for x in rx if a <= x[0] < b])
-        gt.append(t)
-    _, t = blk.general_work(bb[:0], avg[:0], flush=True)
-    gt.append(t)
-    gt = np.concatenate(gt)
-    assert len(gt) > 100 and np.array_equal(gt, ot)
+    """5 000 "rx_time" tags through the streamed preamble block (the table holds 4 096 at once)."""
+    assert pc.check_streamed_preamble_many_rx_time_tags(emu_lib) > 100

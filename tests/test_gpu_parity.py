@@ -254,6 +254,11 @@ def test_k_streams_in_one_scan(lib, rate, lengths, lam):
     assert pc.check_multi_streams(lib, rate, lengths, lam, seed=int(rate / 1e5) + 11) > 3 * len(lengths) // 2
 
 
+def test_streamed_preamble_block_drops_spent_rx_time_tags(lib):
+    """5 000 "rx_time" tags through the streamed preamble block on the device (the table holds 4 096 at once)."""
+    assert pc.check_streamed_preamble_many_rx_time_tags(lib) > 100
+
+
 def test_chain_walk_beyond_64k_of_lds(lib):
     """Between 256 and 288 blocks of 2048 first-stage candidates in ONE scan (low threshold, dense traffic):
     the block-to-block walk of the greedy chain then keeps 128 head links per block = more than 64 KB in LDS,
