@@ -355,13 +355,13 @@ def test_framer_edge_formats_through_the_production_path(emu_lib, oracle_mod, ra
 @pytest.mark.parametrize("rate,n,lam", [(2e6, 150000, 3000.0), (4e6, 250000, 3000.0), (5e6, 300000, 2500.0), (20e6, 600000, 6000.0)])
 def test_preamble_block_as_a_stream(emu_lib, rate, n, lam):
     """VERDICT r4 missing #4: preamble.general_work carries the block's state from call to call (lib/preamble_impl.cc:139-246)."""
-    assert pc.check_preamble_stream(emu_lib, rate, n, lam, seed=int(rate / 1e5) + 3) > 3
+    assert pc.check_preamble_stream(emu_lib, rate, n, lam, seed=int(rate / 1e5) + 3, trials=3) > 3
 
 
 @pytest.mark.parametrize("rate,lengths,lam", [(2e6, [60000, 0, 45000, 100, 80000, 52311, 70001], 3000.0),
-                                              (4e6, [150000, 99999, 120000, 130001, 110007, 125000], 3000.0),
+                                              (4e6, [150000, 99999, 120000, 110007], 3000.0),
                                               (5e6, [200000, 150003, 160000], 2500.0),
-                                              (20e6, [400000, 300000, 350001, 250000, 777, 320000], 6000.0),
+                                              (20e6, [400000, 300000, 777, 250001], 6000.0),
                                               (64e6, [420000, 300001], 12000.0)])
 def test_k_streams_in_one_scan(emu_lib, rate, lengths, lam):
     """am_process_multi -- K whole streams behind one another in one buffer, one scan, every stream's packets
