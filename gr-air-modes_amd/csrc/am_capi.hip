@@ -100,6 +100,8 @@ struct am_ctx {
     bool rows_in_gather = true;      // 64 Msps: bb rows around candidates from IQ in am_k_gather_wg (test builds: AIRMODES_ROWS_FE=1 keeps the front end's)
     bool rows_from_iq = false;       // ... in force for the scan in flight
     bool rows_max = true;            // ... with a maximum per row for am_k_refine_late (test builds: AIRMODES_ROWS_MAX=0 keeps round 5's first form)
+    bool fused_refine = false;       // 64 Msps (round 6): list + rows + refinement in one launch, the rows in LDS (am_k_refine_seg); test builds:
+                                     // AIRMODES_FUSED_REFINE=0 keeps am_k_gather_wg<1> + am_k_refine_late
     DevBuf bbmax;
     am_rows_args rows = {};
     bool allow_stream = true;        // (test builds: AIRMODES_FE=2) keeps the tile kernel (am_k_fe2, dense bb) where the streaming one would run
@@ -485,7 +487,19 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
         ENSURE(c, c->tgt, ((size_t)M + 1) * sizeof(uint32_t));
         ENSURE(c, c->inavg, ((size_t)M + 1) * sizeof(float));
         ENSURE(c, c->valid, (size_t)M + 1);
-        if (mode == 3) {
+        if (mode == 3 && c->rows_from_iq && c->fused_refine) {
+            // 64 Msps: flat positions, bb rows (in LDS), late-peak decisions, quiet zones, records and the chain's successors in ONE
+            // launch, one workgroup per front-end workgroup (am_k_refine_seg)
+            ENSURE(c, c->jump, ((size_t)M + 1) * sizeof(uint32_t));
+#if defined(AM_TEST_KNOBS)
+            if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: am_k_refine_seg, %u segments of %u words, capacity %u\n", c->fe_nwg, c->fe_wpw, M);
+#endif
+            HIPCHK(c, am_launch_refine_seg((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (const float *)c->wgmax.p, c->fe_nwg, c->fe_wpw,
+                                           c->fe_nwords, M, c->fe_lag, c->fe_wbits, c->fe_vspan, c->fe_nv, c->rows, avg, c->thr_lin, end_j,
+                                           (uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, (float *)c->inavg.p,
+                                           (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, (uint32_t *)c->blk_off.p, c->stream));
+            c->jump_ready = true;
+        } else if (mode == 3) {
             // streaming front end: candidates arrive as a bitmap; flat positions, then late-peak decisions, quiet zones,
             // records and the chain's successors in one launch (am_k_refine_late)
             HIPCHK(c, am_launch_gather_wg((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, c->fe_nwg, c->fe_wpw, c->fe_nwords, M,
@@ -596,7 +610,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         c->rows.src_abs0 = (long long)src_abs0; c->rows.src_abs1 = (long long)src_abs1; c->rows.out_abs0 = (long long)out_abs0;
         c->rows.out_n = (long long)out_n; c->rows.bb_sparse = bb; c->rows.use_pmf = c->use_pmf;
         c->rows.bb_max = nullptr;
-        if (c->rows_from_iq && c->rows_max) {
+        if (c->rows_from_iq && c->rows_max && !c->fused_refine) {
             // one float per array chip: the largest bb of every row formed (am_k_refine_late: whole chips of a quiet zone)
             ENSURE(c, c->bbmax, ((size_t)(out_n / 32) + 64) * sizeof(float));
             c->rows.bb_max = (float *)c->bbmax.p;
@@ -954,6 +968,8 @@ am_ctx *am_create(int device, double rate, float threshold_db, int use_pmf, int 
             c->rows_in_gather = !(rf && rf[0] == '1');
             const char *rm = getenv("AIRMODES_ROWS_MAX");
             c->rows_max = !(rm && rm[0] == '0');
+            const char *fr = getenv("AIRMODES_FUSED_REFINE");
+            c->fused_refine = fr ? fr[0] == '1' : c->fused_refine;
             const char *po = getenv("AIRMODES_POISON");
             c->poison = po && po[0] == '1';
             const char *sp = getenv("AIRMODES_NO_SPEC");

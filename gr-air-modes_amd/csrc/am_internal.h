@@ -110,6 +110,14 @@ struct am_rows_args {
 hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uint32_t nwg, uint32_t words_per_wg,
                                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t *pos,
                                uint32_t *total_out, hipStream_t s, const am_rows_args *rows = nullptr);
+/* 64 Msps (round 6): candidate list + bb rows + refinement in ONE launch, one workgroup per front-end workgroup, the rows in LDS
+ * (am_refine_seg.hip): what am_launch_gather_wg(rows) + am_launch_refine_late(bb_max) leave in pos / e / tgt / inavg / valid / jump0,
+ * bit for bit, without the bb rows ever reaching memory.  rows: the samples (bb_sparse / bb_max are not used) */
+hipError_t am_launch_refine_seg(const uint32_t *bits, const uint32_t *wg_cnt, const float *wg_max, uint32_t nwg, uint32_t words_per_wg,
+                                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t vspan, uint32_t nv,
+                                const am_rows_args &rows, const float *avg_sparse, float thr_lin, uint32_t end_j, uint32_t *pos,
+                                uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid, uint32_t *jump0, uint32_t *total_out,
+                                hipStream_t s);
 /* split refinement (after the fused kernel in split mode): flat candidate positions, one energy per
  * reachable position (deduplicated across neighbouring candidates), then one lane per candidate */
 hipError_t am_launch_gather_pos(const uint32_t *seg_pos, uint32_t seg_stride, const uint32_t *blk_off,

@@ -9,13 +9,13 @@
 #   extraction  -DAM_XPROF (phase clocks + per-workgroup lifetimes, printed when a context is destroyed)
 #   chain       -DAM_WALK_DEBUG (the block walk's lane 0 prints hop counts and cycles)  -DAM_MARK_PROF (phase clocks of the marking kernel, printed by four blocks)  -DAM_CB_HEADW -DAM_CB_GROUP
 #
-#   refinement  -DAM_ECB (candidates per workgroup of the energy kernel)
+#   refinement  -DRS_PROFILE (am_k_refine_seg: us per phase and workgroup, the launch's timeline)  -DRS_WPS=n (waves per SIMD it is compiled for)
 # Run every variant on the GPU box under `timeout`: a variant that computes garbage can loop for ever.
 set -e
 cd "$(dirname "$0")/../gr-air-modes_amd/csrc"
 mkdir -p ../../build/var
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fvisibility=hidden -mllvm -amdgpu-sched-strategy=iterative-ilp -shared -I. -I../../include"
-SRC="am_kernels.hip am_fe3.hip am_fe4.hip am_dcblock.hip am_resample.hip am_capi.hip"
+SRC="am_kernels.hip am_refine_seg.hip am_fe3.hip am_fe4.hip am_dcblock.hip am_resample.hip am_capi.hip"
 if [ -n "$NAME" ]; then
   /opt/rocm/bin/hipcc $FLAGS $DEFS -o ../../build/var/lib_$NAME.so $SRC
 else
