@@ -100,7 +100,7 @@ struct am_ctx {
     bool rows_in_gather = true;      // 64 Msps: bb rows around candidates from IQ in am_k_gather_wg (test builds: AIRMODES_ROWS_FE=1 keeps the front end's)
     bool rows_from_iq = false;       // ... in force for the scan in flight
     bool rows_max = true;            // ... with a maximum per row for am_k_refine_late (test builds: AIRMODES_ROWS_MAX=0 keeps round 5's first form)
-    bool fused_refine = false;       // 64 Msps (round 6): list + rows + refinement in one launch, the rows in LDS (am_k_refine_seg); test builds:
+    bool fused_refine = true;        // 64 Msps (round 6): list + rows + refinement in one launch, the rows in LDS (am_k_refine_seg); test builds:
                                      // AIRMODES_FUSED_REFINE=0 keeps am_k_gather_wg<1> + am_k_refine_late
     DevBuf bbmax;
     am_rows_args rows = {};

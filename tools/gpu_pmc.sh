@@ -14,7 +14,8 @@ for d in ('prof_pmc1','prof_pmc2'):
         for r in csv.DictReader(open(f)):
             acc[r['Kernel_Name'][:40]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in acc.items():
-            if 'am_k_fe' in k:
+            import os
+            if os.environ.get('KFILTER', 'am_k_fe') in k:
                 print(k, {c: round(sum(x)/len(x)) for c,x in v.items()})
                 r0=next(csv.DictReader(open(f)))
                 print({kk:r0[kk] for kk in r0 if kk in ('VGPR_Count','Accum_VGPR_Count','SGPR_Count','LDS_Block_Size','Scratch_Size','Workgroup_Size','Grid_Size')})
