@@ -141,6 +141,7 @@ struct am_ctx {
     uint32_t fe_vspan = 0, fe_nv = 0;  // streaming front end of the resident scan: array coordinates per workgroup, workgroups
     uint32_t fe_lag = 0, fe_wbits = 32;  // ... its bitmap: positions behind (lag), per word
     uint32_t fe_nwg = 0, fe_wpw = 0, fe_nwords = 0;   // ... front-end workgroups, bitmap words per workgroup, words in all
+    uint32_t fe_nlong = 0, fe_wps = 0;    // ... levelled segments (am_launch_fe3): workgroups with fe_wpw words (the others: fe_wps fewer); 0: all alike
     int fe_wgs_per_cu = 0;                // persistent front-end workgroups per CU (0: as many as fit; am_pipe: one fewer)
     DevBuf lb_dc, lb_mark;      // slots of the chained scans (am_chain_prefix): zero at allocation, tagged with lb_epoch
     uint32_t lb_epoch = 0;
@@ -494,8 +495,8 @@ int run_refine(am_ctx *c, const float *bb, const float *avg, uint32_t nseg, uint
 #if defined(AM_TEST_KNOBS)
             if (getenv("AIRMODES_TRACE_SPEC")) fprintf(stderr, "airmodes: am_k_refine_seg, %u segments of %u words, capacity %u\n", c->fe_nwg, c->fe_wpw, M);
 #endif
-            HIPCHK(c, am_launch_refine_seg((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (const float *)c->wgmax.p, c->fe_nwg, c->fe_wpw,
-                                           c->fe_nwords, M, c->fe_lag, c->fe_wbits, c->fe_vspan, c->fe_nv, c->rows, avg, c->thr_lin, end_j,
+            HIPCHK(c, am_launch_refine_seg((uint32_t *)c->bits.p, (uint32_t *)c->blk_cnt.p, (const float *)c->wgmax.p, c->fe_nwg, c->fe_nlong,
+                                           c->fe_wpw, c->fe_wps, c->fe_nwords, M, c->fe_lag, c->fe_wbits, c->fe_vspan, c->fe_nv, c->rows, avg, c->thr_lin, end_j,
                                            (uint32_t *)c->pos.p, (uint32_t *)c->e.p, (uint32_t *)c->tgt.p, (float *)c->inavg.p,
                                            (uint8_t *)c->valid.p, (uint32_t *)c->jump.p, (uint32_t *)c->blk_off.p, c->stream));
             c->jump_ready = true;
@@ -597,7 +598,7 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
         ENSURE(c, c->blk_off, 16 * sizeof(uint32_t));                          // [0]: their total (am_k_gather_wg)
         ENSURE(c, c->avg, (out_n + zero_pad(c->spc_hi)) * sizeof(float));
         ENSURE(c, c->wgmax, ((size_t)ns + 8) * sizeof(float));
-        unsigned nsteps = 0, spw = 1;
+        unsigned nsteps = 0, spw = 1, nlong = 0;
         if (c->poison) {
             // test aid (AIRMODES_POISON=1): whatever the sparse arrays are read for must have been written by this scan
             HIPCHK(c, hipMemsetAsync(bb, 0xFF, out_n * sizeof(float), c->stream));
@@ -621,9 +622,18 @@ int run_front_and_candidates(am_ctx *c, const float *src, uint64_t src_abs0, uin
                                 c->rows_from_iq ? nullptr : bb,
                                 (float *)c->avg.p, j0, j1, c->use_pmf, (float)(1.0 / (double)c->spc),
                                 (float)(1.0 / (double)(AM_CHIPS_AVG * c->spc)), c->thr_lin, (uint32_t *)c->bits.p,
-                                (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream, c->fe_wgs_per_cu));
+                                (uint32_t *)c->blk_cnt.p, (float *)c->wgmax.p, &nsteps, &spw, c->stream, c->fe_wgs_per_cu,
+                                (c->rows_from_iq && c->fused_refine) ? &nlong : nullptr));      // (levelled segments: what am_k_refine_seg can place)
         c->fe_vspan = spw * am_fe4_tile(c->spc);
         c->fe_nv = (nsteps + spw - 1) / spw;
+        c->fe_nlong = 0;
+        c->fe_wps = wps;
+        if (nlong && spw > 1) {
+            // nlong workgroups of spw steps, then workgroups of spw - 1
+            const unsigned rest = nsteps > nlong * spw ? nsteps - nlong * spw : 0u;
+            c->fe_nv = nlong + (rest + (spw - 1) - 1) / (spw - 1);
+            c->fe_nlong = nlong;
+        }
         c->fe_lag = am_fe4_lag(c->spc);
         c->fe_wbits = am_fe4_unit(c->spc);
         c->fe_nwg = c->fe_nv;

@@ -84,7 +84,8 @@ struct am_fe3_args {
     uint32_t *wg_cnt;                     // [grid] candidates a workgroup found (am_k_gather_wg lays the flat list out from these)
     float *wg_max;                        // [grid] largest bb a workgroup formed (+inf if one was not finite)
     unsigned nsteps;                      // steps (= bitmap tiles) of the whole launch
-    unsigned steps_per_wg;
+    unsigned steps_per_wg;                // ... of each of the first n_long workgroups; the others take one fewer (levelled segments)
+    unsigned n_long;
     // steps whose raw samples are all present and 16-byte aligned are loaded without guards: [raw_lo, raw_hi);
     // steps whose tested positions are all wanted need no range mask: [test_lo, test_hi)
     int raw_lo, raw_hi, test_lo, test_hi;
@@ -603,9 +604,14 @@ __global__ void __launch_bounds__(FE3_NT, FE3_WPS) am_k_fe3(am_fe3_args a)
     L.CARRY = reinterpret_cast<uint32_t *>(L.ST + FE3_CR);
     L.TAB = L.CARRY + 2;
     const int tid0 = threadIdx.x;
-    const int sb = (int)(blockIdx.x * a.steps_per_wg);
+    // levelled segments (round 6): the first n_long workgroups take steps_per_wg steps, the others one fewer -- 1 536 segments of 13 or
+    // 14 steps at 64 M samples instead of 1 489 of 14, so that no CU is left with five workgroups
+    const bool longseg = blockIdx.x < a.n_long;
+    const int sb = longseg ? (int)(blockIdx.x * a.steps_per_wg)
+                           : (int)(a.n_long * a.steps_per_wg + (blockIdx.x - a.n_long) * (a.steps_per_wg - 1u));
     if (sb >= (int)a.nsteps) return;
-    const int se = (sb + (int)a.steps_per_wg < (int)a.nsteps) ? sb + (int)a.steps_per_wg : (int)a.nsteps;
+    const int mine = (int)a.steps_per_wg - (longseg ? 0 : 1);
+    const int se = (sb + mine < (int)a.nsteps) ? sb + mine : (int)a.nsteps;
 
     // rings start empty; the first step's chip 0 has no predecessor (its bb is never used); the bb of the first 16
     // chips of a segment is always written (the candidates of the previous segment's tail are not known here)
@@ -696,7 +702,7 @@ static int fe3_wgs_for_device() { return FE3_WG_PER_CU * am_device_cus(); }   //
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps, unsigned *steps_per_wg,
-                         hipStream_t s, int wgs_per_cu)
+                         hipStream_t s, int wgs_per_cu, unsigned *n_long)
 {
     am_fe3_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
@@ -730,9 +736,21 @@ hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1
 #ifdef FE3_FORCE_SPW
     spw = FE3_FORCE_SPW;                                              // tuning builds
 #endif
+    unsigned grid = (a.nsteps + spw - 1) / spw;
+    a.n_long = grid;
+    if (n_long) {
+        // the caller can place segments of two lengths (am_k_refine_seg): as many workgroups as are resident (at least ~4 steps each),
+        // the steps dealt out as evenly as they go
+        unsigned G = a.nsteps / 4u;
+        G = G < 1u ? 1u : (G > resident ? resident : G);
+        const unsigned lo = a.nsteps / G, r = a.nsteps - lo * G;
+        grid = G;
+        if (r == 0) { spw = lo; a.n_long = G; }
+        else { spw = lo + 1u; a.n_long = r; }
+        *n_long = a.n_long;
+    }
     a.steps_per_wg = spw;
     *steps_per_wg = spw;
-    const unsigned grid = (a.nsteps + spw - 1) / spw;
     static std::atomic<bool> attr_done[64];
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -947,12 +947,12 @@ static hipError_t fe4_launch(am_fe4_args &a, unsigned *steps_per_wg, hipStream_t
 hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
-                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu)
+                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu, unsigned *n_long)
 {
     if (!am_fe4_supported(spc)) return hipErrorInvalidValue;
     if (FE4_USE_FE3(spc))
         return am_launch_fe3(iq, src_abs0, src_abs1, out_abs0, out_n, bb_sparse, avg_sparse, j0, j1, use_pmf, s1, sL, thr_lin, bits,
-                             wg_cnt, wg_max, nsteps, steps_per_wg, s, wgs_per_cu);
+                             wg_cnt, wg_max, nsteps, steps_per_wg, s, wgs_per_cu, n_long);
     am_fe4_args a;
     a.iq = iq; a.src_abs0 = src_abs0; a.src_abs1 = src_abs1; a.out_abs0 = out_abs0; a.out_n = out_n;
     a.bb_sparse = bb_sparse; a.avg_sparse = avg_sparse; a.j0 = j0; a.j1 = j1; a.bits = bits; a.wg_cnt = wg_cnt; a.wg_max = wg_max;

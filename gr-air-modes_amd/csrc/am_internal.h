@@ -77,7 +77,9 @@ unsigned am_fe3_steps(long long out_n);
 hipError_t am_launch_fe3(const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
-                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu);
+                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu, unsigned *n_long = nullptr);
+/* (n_long != null: LEVELLED segments -- the first *n_long workgroups take *steps_per_wg steps, the others one fewer, the grid is as
+ * many workgroups as are resident; only a caller whose later kernels can place two segment lengths asks for it: am_k_refine_seg) */
 int am_fe4_supported(int spc);
 unsigned am_fe4_unit(int spc);
 unsigned am_fe4_words(int spc);
@@ -88,7 +90,7 @@ unsigned am_fe4_steps(long long out_n, int spc);
 hipError_t am_launch_fe4(int spc, const float *iq, long long src_abs0, long long src_abs1, long long out_abs0, long long out_n,
                          float *bb_sparse, float *avg_sparse, uint32_t j0, uint32_t j1, int use_pmf, float s1, float sL,
                          float thr_lin, uint32_t *bits, uint32_t *wg_cnt, float *wg_max, unsigned *nsteps,
-                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu);
+                         unsigned *steps_per_wg, hipStream_t s, int wgs_per_cu, unsigned *n_long = nullptr);
 /* (wgs_per_cu: 0 = as many persistent workgroups as are resident at once; n > 0 = at most n per CU -- am_pipe leaves room on
  * every CU for the small kernels of the other batches in flight; honoured by am_k_fe3) */
 /* flat candidate positions from the bitmap, one workgroup per front-end workgroup: workgroup g owns the words
@@ -112,9 +114,10 @@ hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uin
                                uint32_t *total_out, hipStream_t s, const am_rows_args *rows = nullptr);
 /* 64 Msps (round 6): candidate list + bb rows + refinement in ONE launch, one workgroup per front-end workgroup, the rows in LDS
  * (am_refine_seg.hip): what am_launch_gather_wg(rows) + am_launch_refine_late(bb_max) leave in pos / e / tgt / inavg / valid / jump0,
- * bit for bit, without the bb rows ever reaching memory.  rows: the samples (bb_sparse / bb_max are not used) */
-hipError_t am_launch_refine_seg(const uint32_t *bits, const uint32_t *wg_cnt, const float *wg_max, uint32_t nwg, uint32_t words_per_wg,
-                                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t vspan, uint32_t nv,
+ * bit for bit, without the bb rows ever reaching memory.  rows: the samples (bb_sparse / bb_max are not used).  Segments: the first
+ * n_long front-end workgroups tested words_per_wg words each, the others words_per_wg - words_per_step (levelled: am_launch_fe3) */
+hipError_t am_launch_refine_seg(const uint32_t *bits, const uint32_t *wg_cnt, const float *wg_max, uint32_t nwg, uint32_t n_long,
+                                uint32_t words_per_wg, uint32_t words_per_step, uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t vspan, uint32_t nv,
                                 const am_rows_args &rows, const float *avg_sparse, float thr_lin, uint32_t end_j, uint32_t *pos,
                                 uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid, uint32_t *jump0, uint32_t *total_out,
                                 hipStream_t s);

@@ -99,6 +99,7 @@ struct am_rseg_args {
     const uint32_t *bits, *wg_cnt;
     const float *wg_max;
     uint32_t nwg, words_per_wg, nwords, Mcap, vspan, nv, end_j, parts, pw;
+    uint32_t n_long, words_short, vspan_short;   // segments n_long .. : words_short words, vspan_short array coordinates each (levelled front end)
     const float *iq;
     long long src_abs0, src_abs1, out_abs0;
     const float *avg_sparse;
@@ -216,8 +217,9 @@ __global__ void __launch_bounds__(RS_NT, RS_WPS) am_k_refine_seg(am_rseg_args a)
     const int wv = __builtin_amdgcn_readfirstlane(tid0 / AM_WAVE);
     int tid = tid0, lane = tid0 & (AM_WAVE - 1);
     const uint32_t g = blockIdx.x / a.parts, part = blockIdx.x % a.parts;
-    const uint32_t seg_b = g * a.words_per_wg;
-    const uint32_t seg_e = (seg_b + a.words_per_wg < a.nwords) ? seg_b + a.words_per_wg : a.nwords;
+    const uint32_t seg_b = g < a.n_long ? g * a.words_per_wg : a.n_long * a.words_per_wg + (g - a.n_long) * a.words_short;
+    const uint32_t seg_w = g < a.n_long ? a.words_per_wg : a.words_short;
+    const uint32_t seg_e = (seg_b + seg_w < a.nwords) ? seg_b + seg_w : a.nwords;
     const uint32_t pb = seg_b + part * a.pw;                   // this workgroup's words: [pb, pe)
     const uint32_t pe = (pb + a.pw < seg_e) ? pb + a.pw : seg_e;
     const bool writes_total = blockIdx.x == 0;
@@ -588,7 +590,11 @@ __global__ void __launch_bounds__(RS_NT, RS_WPS) am_k_refine_seg(am_rseg_args a)
                 float vb = 0.0f;
                 {
                     const uint32_t p_lo = (wa + G.ga) * 32u, p_hi = (wa + G.gb) * 32u + 13u * (uint32_t)SPC;
-                    uint32_t v0 = (p_lo > 288u ? p_lo - 288u : 0u) / a.vspan, v1 = p_hi / a.vspan;
+                    // (front-end workgroup of an array coordinate: n_long segments of vspan coordinates, then shorter ones)
+                    const uint32_t c_long = a.n_long * a.vspan;
+                    const uint32_t q_lo = p_lo > 288u ? p_lo - 288u : 0u;
+                    uint32_t v0 = q_lo < c_long ? q_lo / a.vspan : a.n_long + (q_lo - c_long) / a.vspan_short;
+                    uint32_t v1 = p_hi < c_long ? p_hi / a.vspan : a.n_long + (p_hi - c_long) / a.vspan_short;
                     v0 = v0 < a.nv ? v0 : a.nv - 1u;
                     v1 = v1 < a.nv ? v1 : a.nv - 1u;
                     for (uint32_t v = v0; v <= v1; ++v) vb = fmaxf(vb, a.wg_max[v]);
@@ -741,8 +747,8 @@ __global__ void __launch_bounds__(RS_NT, RS_WPS) am_k_refine_seg(am_rseg_args a)
 #endif
 }
 
-hipError_t am_launch_refine_seg(const uint32_t *bits, const uint32_t *wg_cnt, const float *wg_max, uint32_t nwg, uint32_t words_per_wg,
-                                uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t vspan, uint32_t nv,
+hipError_t am_launch_refine_seg(const uint32_t *bits, const uint32_t *wg_cnt, const float *wg_max, uint32_t nwg, uint32_t n_long,
+                                uint32_t words_per_wg, uint32_t words_per_step, uint32_t nwords, uint32_t Mcap, uint32_t lag, uint32_t wbits, uint32_t vspan, uint32_t nv,
                                 const am_rows_args &rows, const float *avg_sparse, float thr_lin, uint32_t end_j, uint32_t *pos,
                                 uint32_t *e, uint32_t *tgt, float *inavg, uint8_t *valid, uint32_t *jump0, uint32_t *total_out,
                                 hipStream_t s)
@@ -755,6 +761,11 @@ hipError_t am_launch_refine_seg(const uint32_t *bits, const uint32_t *wg_cnt, co
     a.vspan = vspan; a.nv = nv; a.end_j = end_j; a.iq = rows.iq; a.src_abs0 = rows.src_abs0; a.src_abs1 = rows.src_abs1;
     a.out_abs0 = rows.out_abs0; a.avg_sparse = avg_sparse; a.s1 = rows.s1; a.thr_lin = thr_lin; a.pos = pos; a.e = e; a.tgt = tgt;
     a.jump0 = jump0; a.total_out = total_out; a.inavg = inavg; a.valid = valid;
+    // levelled segments: the first n_long of words_per_wg words, the others one step shorter (n_long = 0 or >= nwg: all alike)
+    a.n_long = (n_long == 0 || n_long > nwg) ? nwg : n_long;
+    if (a.n_long < nwg && (words_per_step == 0 || words_per_step >= words_per_wg)) return hipErrorInvalidValue;
+    a.words_short = a.n_long < nwg ? words_per_wg - words_per_step : words_per_wg;
+    a.vspan_short = a.n_long < nwg ? (uint32_t)((unsigned long long)vspan * a.words_short / words_per_wg) : vspan;
     // shares of a segment: about RS_PW words each, at most RS_MAXPARTS (longer segments: several windows per share)
     a.parts = (words_per_wg + RS_PW - 1) / RS_PW;
     if (a.parts > RS_MAXPARTS) a.parts = RS_MAXPARTS;
