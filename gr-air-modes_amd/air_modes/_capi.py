@@ -168,12 +168,16 @@ class Library(object):
         n = int(p.size)
         if n == 0:
             return []
-        cap = 80 * n
-        buf = C.create_string_buffer(cap)
+        cap = 72 * n + 32                                  # (typical texts take 55-65 bytes; the longest possible one 96)
         offs = np.zeros(n + 1, np.uint64)
         need = C.c_uint64(0)
-        rc = self.L.am_format_messages(p.ctypes.data, n, int(bool(first)), C.addressof(buf), cap, offs.ctypes.data,
-                                       C.byref(need))
+        for _ in range(2):
+            buf = C.create_string_buffer(cap)
+            rc = self.L.am_format_messages(p.ctypes.data, n, int(bool(first)), C.addressof(buf), cap, offs.ctypes.data,
+                                           C.byref(need))
+            if rc != AM_ECAPACITY:
+                break
+            cap = int(need.value)                          # the library says what it takes: once more with exactly that
         if rc < 0:
             raise AirModesError(rc, "am_format_messages")
         raw = buf.raw[:int(offs[n])]

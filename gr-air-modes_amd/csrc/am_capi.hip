@@ -1354,19 +1354,22 @@ static int multi_begin(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint
             if (flags & AM_F_DEVICE_IN) HIPCHK(c, hipMemsetAsync(iq + 2 * a, 0, (b - a) * 2 * sizeof(float), c->stream));
             else memset(iq + 2 * a, 0, (b - a) * 2 * sizeof(float));
         }
-    c->multi_off = off;
-    c->multi_em.assign(k, -1);
-    c->multi_cnt.assign(k, 0);
+    std::vector<int64_t> em_of(k, -1);
     c->tt.clear();
     for (uint32_t j = 0; j < k; j++) {
         uint64_t em;
-        if (flush_limits(c, n[j], &em)) c->multi_em[j] = (int64_t)em;
+        if (flush_limits(c, n[j], &em)) em_of[j] = (int64_t)em;
         const am_time_tag t = {off[j], 0, 0.0};                   // item counts and time restart with every stream
         c->tt.push_back(t);
     }
     ENSURE(c, c->tt_dev, AM_MAX_TIME_TAGS * sizeof(am_time_tag));
     // (a plain copy: the context is idle -- its last scan was collected -- so nothing on its stream still reads the table)
     HIPCHK(c, hipMemcpy(c->tt_dev.p, c->tt.data(), c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice));
+    // the layout is put in force LAST: a failure above leaves the context a plain receiver (a stale layout would make the
+    // next am_process_iq sort its packets into streams that are not there)
+    c->multi_off = off;
+    c->multi_em = em_of;
+    c->multi_cnt.assign(k, 0);
     return AM_OK;
 }
 
@@ -1402,6 +1405,7 @@ int am_submit_multi(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint32_
 int am_multi_counts(am_ctx *c, uint64_t *count, uint32_t k)
 {
     if (!c) return AM_EINVAL;
+    if (c->pend.active) return fail(c, AM_EINVAL, "multi: the submitted scan has not been collected yet (am_collect)");
     if (!count || k != c->multi_cnt.size()) return fail(c, AM_EINVAL, "multi: the last collected scan had another number of streams");
     for (uint32_t j = 0; j < k; j++) count[j] = c->multi_cnt[j];
     return AM_OK;

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "airmodes_hip.h"
+#include "airmodes_hip_debug.h"
 
 #ifndef AM_WITH_TILE_KERNEL
 #define AM_WITH_TILE_KERNEL 0   /* 1 in TEST builds (tests/gpu_variants, tests/emu): the tile kernel am_k_fe2 and the split refinement behind it */

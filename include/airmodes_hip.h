@@ -89,10 +89,6 @@ typedef struct am_tag {
 typedef struct am_ctx am_ctx;
 
 AM_API uint32_t am_abi_version(void);
-/* 0 for the product library.  1 only in the test-only CPU build of the same sources (tests/emu), where device pointers are
- * host pointers: callers that must choose between device-side and host-side message buffers ask this instead of guessing from
- * the library's file name. */
-AM_API int am_is_emulated(void);
 
 /* ---- context = the rx_path hier block ------------------------------------------------
  * Replaces: rx_path.__init__(rate, threshold, queue, use_pmf, use_dcblock)
@@ -265,8 +261,9 @@ AM_API int am_format_message(const am_packet *pkt, int first, char *buf, size_t 
 /* The same for n packets in one call (a binding posts a batch per call instead of crossing the FFI per packet): text k is
  * the NUL-terminated string at buf + offsets[k]; offsets has n + 1 entries, offsets[n] = bytes used.  `first` applies to
  * packet 0 only -- the stream's precision is sticky (slicer_impl.cc:186-194; the ostringstream is a member,
- * slicer_impl.h:43).  AM_ECAPACITY when cap is too small: *need (optional) then holds the bytes required (at most 80 per
- * packet) and nothing beyond cap was written. */
+ * slicer_impl.h:43).  AM_ECAPACITY when cap is too small: *need (optional) then holds the bytes required (a text is at most
+ * 96 bytes with its terminator: 28 hex digits, 6 of the syndrome, two %.10g numbers of up to 16 characters, a 20-digit count of
+ * seconds, separators; typical ones take 55-65) and nothing beyond cap was written. */
 AM_API int am_format_messages(const am_packet *pkts, uint64_t n, int first, char *buf, size_t cap, uint64_t *offsets,
                               uint64_t *need);
 
@@ -330,8 +327,7 @@ AM_API int am_shard_entry2(const am_shard_exit *const *tables, const uint64_t *c
  * in front of the chunk, before the next am_shard_scan_async). */
 AM_API int am_shard_keep_tail(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
 AM_API int am_stream_copy(am_ctx *ctx, void *dst, const void *src, uint64_t nbytes);
-AM_API int am_shard_get_exit(am_ctx *ctx, uint64_t *pos);
-AM_API int am_shard_set_exit(am_ctx *ctx, uint64_t pos);
+/* (am_shard_get_exit / am_shard_set_exit, the exit word of the synchronous fallback: airmodes_hip_debug.h) */
 
 /* The same step without a host round trip in the middle (round 3): the exit table stays on the device.
  * am_shard_scan_async: as am_shard_scan, but everything is only ENQUEUED and the table goes to the device message
@@ -389,29 +385,9 @@ AM_API const float *am_uploader_wait(am_uploader *u, int slot);
 /* last error text of the context (or of am_create when ctx == NULL) */
 AM_API const char *am_last_error(const am_ctx *ctx);
 
-/* timing of the last am_process_iq / am_shard_scan call, measured with HIP events on the
- * context's own stream: device milliseconds for the whole call and for the dominant
- * (front-end + detection) kernel.  Used by bench.py for the roofline line.  Either pointer may be
- * NULL; asking for total_ms may wait a few microseconds for the call's last event (it is queued
- * behind the completion signal the call itself waits for), dominant_kernel_ms never waits. */
-AM_API int am_last_timing(am_ctx *ctx, float *total_ms, float *dominant_kernel_ms);
-
-/* Diagnostic: number of first-stage preamble candidates (positions passing preamble_impl.cc:172-179)
- * the last scan refined and chained.  Negative error code on a null context. */
-AM_API long long am_last_num_candidates(const am_ctx *ctx);
-
-/* Diagnostic: which front-end kernel the last scan ran -- 3 = a streaming kernel (am_k_fe3 at 64 Msps, am_k_fe4 at 2, 4, 8,
- * 10, 16, 20, 32 and 40 Msps: persistent workgroups, LDS rings, sparse bb around candidates), 2 = tile kernel (am_k_fe2, dense bb), 1 = rate-generic kernels, 0 = no scan
- * yet.  Results do not depend on it (test builds can keep the tile kernel; tests compare both). */
-AM_API int am_last_frontend(const am_ctx *ctx);
-
-/* Diagnostic (stage-level parity tests): the refined record of EVERY first-stage candidate of the last scan, in
- * position order -- absolute stream index of the position the first-stage test fired at (preamble_impl.cc:172-179), of
- * the position after the late-peak search (:182-192), the outcome of the quiet-zone test there (:198-209) and, for a
- * candidate, the reference level at that position (what :220 subtracts).  Any pointer may be NULL.  AM_ECAPACITY
- * (*n_out = needed) if cap is too small. */
-AM_API int am_fetch_candidates(am_ctx *ctx, uint64_t *pos, uint64_t *refined, uint8_t *valid, float *inavg, uint64_t cap,
-                        uint64_t *n_out);
+/* Diagnostics, test hooks and the time-shard path's exit word (am_last_timing, am_last_num_candidates, am_last_frontend,
+ * am_fetch_candidates, am_is_emulated, am_shard_get_exit, am_shard_set_exit) are declared in airmodes_hip_debug.h: they are
+ * exported by the same library but are not part of the drop-in surface. */
 
 #ifdef __cplusplus
 }

@@ -11,18 +11,25 @@ import pytest
 import conftest
 
 
-def header_symbols():
-    with open(os.path.join(conftest.ROOT, "include", "airmodes_hip.h")) as f:
+def header_symbols(name="airmodes_hip.h"):
+    with open(os.path.join(conftest.ROOT, "include", name)) as f:
         text = f.read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", text)))
 
 
+# diagnostics and test hooks: exported, declared apart from the drop-in surface (include/airmodes_hip_debug.h)
+DEBUG_SYMBOLS = ["am_fetch_candidates", "am_is_emulated", "am_last_frontend", "am_last_num_candidates", "am_last_timing",
+                 "am_shard_get_exit", "am_shard_set_exit"]
+
+
 def test_library_builds_loads_and_exports_all_symbols():
     subprocess.check_call(["make", "-s", "-C", os.path.join(conftest.ROOT, "gr-air-modes_amd", "csrc")])
     lib = ctypes.CDLL(conftest.HIP_LIB)
-    syms = header_symbols()
-    assert len(syms) >= 20
+    main, debug = header_symbols(), header_symbols("airmodes_hip_debug.h")
+    assert debug == DEBUG_SYMBOLS and not set(main) & set(debug)      # both lists, as the headers state them
+    syms = sorted(main + debug)
+    assert len(main) >= 20
     for s in syms:
         assert hasattr(lib, s), "libairmodes_hip.so does not export %s" % s
     lib.am_abi_version.restype = ctypes.c_uint32
@@ -187,3 +194,21 @@ def test_format_messages_batch_equals_one_by_one():
     need = ctypes.c_uint64(0)
     rc = lib.L.am_format_messages(pk.ctypes.data, 3, 1, ctypes.addressof(buf), 40, offs.ctypes.data, ctypes.byref(need))
     assert rc == -5 and need.value == sum(len(t) + 1 for t in lib.format_messages(pk[:3], True)) and buf.raw[40:] == b"\0" * 24
+
+
+def test_format_messages_longest_texts_fit_after_one_retry():
+    """a text can take up to ~91 bytes (two %.10g numbers of 16 characters, an 11-digit count of seconds); the
+    facade's first buffer is sized for typical texts and the library's `need` pays for the rest."""
+    from air_modes import _capi
+    lib = _capi.Library(conftest.HIP_LIB)
+    p = np.zeros(40, _capi.PACKET_DTYPE)
+    p["data"][:] = 0xAB
+    p["nbytes"] = 14
+    p["crc"] = 0xABCDEF
+    p["ref"] = np.float32(-1.23e-05)
+    p["secs"] = 12345678901
+    p["frac"] = 9.5e-05
+    texts = lib.format_messages(p, first=False)
+    assert len(texts) == 40 and all(t == texts[0] for t in texts)
+    assert texts[0] == lib.format_message(p[0], False)
+    assert (len(texts[0]) + 1) * 40 > 72 * 40 + 32            # (the first buffer was too small: the retry with `need` ran)
