@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the realistic-density and batches-in-flight figures")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (contexts/streams driven by host threads)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 3-batches-in-flight figure (profiling runs)")
+    ap.add_argument("--sustained-steps", type=int, default=2000, help="steps of the extra sustained leg (>= 0.5 s of device work: a sampler "
+                                                                        "of GPU activity sees the device busy); 0 skips it")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
     ap.add_argument("--streams", type=int, default=1, help="K independent streams (receivers) of the workload in ONE scan per step "
                                                            "(am_process_multi): N = 1, value counts all K streams")
@@ -340,6 +342,16 @@ def main():
                 import oracle
                 extra["realistic_density"]["parity"] = bool(np.array_equal(pkr, oracle.demod(iq_r, rate, 7.0, True)))
             run_steps(2, [ctx], 1, d_batches)          # back to the main density (capacity estimate of the context)
+        if mode == "single" and K == 1 and not args.no_extra and args.sustained_steps > 0 and not args.emu:
+            # the timed loop again, long enough (>= 0.5 s of device work) for a sampler of GPU activity to see the device busy: the same
+            # rotating batches, the same call, nothing skipped; the packets of its last step are checked against the first pass's count
+            run_steps(2, [ctx], 1, d_batches)
+            dts, ks_last, pks, fes = timed(args.sustained_steps, [ctx], 1, d_batches)
+            fe_s = float(np.mean(fes)) if fes else 0.0
+            extra["sustained"] = {"steps": args.sustained_steps, "seconds": dts, "value": n * args.sustained_steps / dts, "unit": "samples/s",
+                                  "ms_per_step": dts / args.sustained_steps * 1e3, "kernel_ms": fe_s,
+                                  "roofline_frac": (8.0 * n / (fe_s * 1e-3) / 1e9 / HBM_PEAK_GBS) if fe_s > 0 else 0.0,
+                                  "same_packet_count_as_timed_loop": bool(len(pks) == per_batch[ks_last % nb])}
         if mode == "single" and K == 1 and not args.no_extra:
             # the same step with the batch in HOST memory (a file source): pinned staging, two buffers in flight -- the PCIe copy
             # of batch k+1 overlaps the scan of batch k (am_uploader_*, what modes_rx does).  PCIe bound; reported separately,
@@ -504,6 +516,7 @@ def main():
                        2: "am_k_fe2<%d> (fused |iq|^2 + PMF + reference level + preamble detection)" % spc}.get(fe_kind, "am_k_frontend")
         # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         traffic, traffic_src = None, None
+        rocprof = {}
         tj = os.path.join(ROOT, "profiles", "current_traffic.json")
         if mode in ("single", "sharded") and K == 1 and os.path.exists(tj) and not args.emu:
             with open(tj) as f:
@@ -519,6 +532,24 @@ def main():
                     traffic = t["traffic_bytes"]
                     traffic_src = "profiles/current_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; %s sha %s)" % (
                         t.get("kernel_source", "am_fe4.hip"), sha)
+                    # the second clock: rocprofv3's average duration of the same kernel over the same command (kernel trace)
+                    if t.get("kernel_ms_rocprof"):
+                        rocprof["kernel_ms_rocprof"] = t["kernel_ms_rocprof"]
+                        rocprof["frac_rocprof"] = 8.0 * n_launch / (t["kernel_ms_rocprof"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    # every kernel of a step (per-kernel duration, FETCH x2 + WRITE) and their sum -- valid for the tree they were
+                    # measured on only: one hash over the library's sources
+                    h = hashlib.sha256()
+                    cdir = os.path.join(ROOT, "gr-air-modes_amd", "csrc")
+                    for name in sorted(os.listdir(cdir)):
+                        if name.endswith((".hip", ".h", ".inc")):
+                            with open(os.path.join(cdir, name), "rb") as kf:
+                                h.update(name.encode() + b"\0" + kf.read())
+                    if t.get("path_source_sha16") == h.hexdigest()[:16]:
+                        rocprof["path_traffic_bytes"] = t.get("path_traffic_bytes")
+                        rocprof["path_traffic_over_algorithmic"] = t.get("path_traffic_bytes", 0) / float(8 * n_launch)
+                        rocprof["path_kernel_us_rocprof"] = t.get("path_kernel_us_rocprof")
+                        rocprof["path_launches_per_step"] = t.get("path_launches_per_step")
+                        rocprof["path_kernels"] = t.get("kernels")
                 else:
                     traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
                         t.get("kernel_source", "am_fe4.hip"), t.get("kernel_source_sha16"), sha)
@@ -547,6 +578,7 @@ def main():
                          # algorithmic bytes per step / driver-timed step / HBM peak -- NOT the kernel's fraction
                          "path_frac_of_hbm_peak": 8.0 * K * n / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        res["roofline"].update(rocprof)
         coll = None
         if world > 1:
             coll = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
