@@ -86,6 +86,9 @@ def parse_args():
     ap.add_argument("--sustained-steps", type=int, default=2000, help="steps of the extra sustained leg (>= 0.5 s of device work: a sampler "
                                                                         "of GPU activity sees the device busy); 0 skips it")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="with --force-sharded at N=1: a world-1 process group of this backend, and the receiver goes through its "
+                         "collectives (tail to itself, all_gather_into_tensor of the exit table): RCCL executes the sharded step on one GPU")
     ap.add_argument("--streams", type=int, default=1, help="K independent streams (receivers) of the workload in ONE scan per step "
                                                            "(am_process_multi): N = 1, value counts all K streams")
     ap.add_argument("--replicas", action="store_true", help="N independent receivers, one per GPU (configs[4])")
@@ -112,6 +115,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.emu else "nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == world
+    elif args.force_sharded and args.backend:
+        dist.init_process_group(args.backend, init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1)
     if args.emu:
         dev = torch.device("cpu")
     else:
@@ -407,7 +412,8 @@ def main():
         # undecided tail and the sample count cross the steps (air_modes/sharded.py)
         from air_modes.sharded import ShardedReceiver
         iq = synth.synth_capture(rate, n, lam, seed + rank)[0]
-        rx = ShardedReceiver(ctx, rank, world, n, device=dev)
+        forced = world == 1 and bool(args.backend)
+        rx = ShardedReceiver(ctx, rank, world, n, device=dev, force_collectives=forced)
         rx.chunk.copy_(torch.from_numpy(iq.view(np.float32)))     # resident in HBM before the timed region
         sync()
         fe_ms = []
@@ -434,13 +440,16 @@ def main():
         hs = max(1, rx.host_us["steps"])
         extra["host_dist_us_per_step"] = {"tail_exchange_batch_isend_irecv": rx.host_us["tail_exchange"] / hs,
                                           "exit_table_all_gather_into_tensor": rx.host_us["all_gather"] / hs,
-                                          "steps_counted": rx.host_us["steps"], "rank": rank}
+                                          "steps_counted": rx.host_us["steps"], "rank": rank,
+                                          "through_the_process_group": bool(world > 1 or rx.force),
+                                          "tail_by": ("all_gather (the backend refused a send to itself)" if rx.tail_by_gather else
+                                                      "batch_isend_irecv") if (world > 1 or rx.force) else "device copy (one rank, no group)"}
         # parity, part 1: a short stream through the same N-rank receiver IN TWO STEPS against the oracle over the WHOLE stream
         import oracle
         ns = max(4 * rx.halo, 30000 * spc)
         whole = synth.synth_capture(rate, 2 * world * ns, lam, 4242)[0]
         ctx_s = new_ctx()
-        rx_s = ShardedReceiver(ctx_s, rank, world, ns, device=dev)
+        rx_s = ShardedReceiver(ctx_s, rank, world, ns, device=dev, force_collectives=forced)
         mine = []
         for k in range(2):
             a = (k * world + rank) * ns
@@ -580,7 +589,7 @@ def main():
         }
         res["roofline"].update(rocprof)
         coll = None
-        if world > 1:
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
             coll = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
             if not args.emu and torch.cuda.is_available():
                 try:
@@ -652,7 +661,7 @@ def main():
                     "messages_match_gpu": bool(rmsgs[:len(sub)] == ctx_messages(ctx, sub) and len(sub) > 0)}
         res.update(extra)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1,0 +1,43 @@
+"""RCCL executes the time-sharded step on ONE GPU: a world-1 "nccl" process group, the receiver with
+force_collectives -- the tail exchange (a send / receive to itself inside batch_isend_irecv, or the all_gather fallback where the
+backend refuses that) and the exit table's all_gather_into_tensor really run through the backend, ordered against the context's
+own stream by am_signal_stream / am_wait_for_stream exactly as at world 8.  No scaling claim follows from it: one rank."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_runs_the_sharded_step_at_world_one(hip_lib, oracle_mod):
+    import torch
+    import torch.distributed as dist
+    import synth
+    from air_modes import _capi
+    from air_modes.sharded import ShardedReceiver
+    rate, n, steps = 64e6, 3_000_000, 3
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29731", rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        dev = torch.device("cuda", 0)
+        iq, _ = synth.synth_capture(rate, steps * n, 12000.0, seed=6161)
+        ctx = _capi.Context(rate, 7.0, True, device=0, lib=hip_lib)
+        ctx.set_rx_time(0, 1000, 0.25)
+        ctx.set_rx_time(n + 12345, 2000, 0.5)
+        rx = ShardedReceiver(ctx, 0, 1, n, device=dev, force_collectives=True)
+        assert rx.force and rx.host_free
+        out = []
+        for k in range(steps):
+            rx.chunk.copy_(torch.from_numpy(iq[k * n:(k + 1) * n].copy().view(np.float32)).to(dev))
+            out.append(rx.step(flush=(k == steps - 1)))
+        got = np.concatenate(out)
+        want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25), (n + 12345, 2000, 0.5)])
+        assert len(want) > 100 and np.array_equal(got, want)
+        assert rx.sync_steps == 0                                  # every step host-free: nothing fell back to the host tables
+        assert rx.host_us["all_gather"] > 0.0 and rx.host_us["tail_exchange"] > 0.0
+        print("rccl world 1: tail by %s, host us per step: tail exchange %.1f, all_gather %.1f, rccl %s"
+              % ("all_gather (send to self refused)" if rx.tail_by_gather else "send / receive to itself",
+                 rx.host_us["tail_exchange"] / steps, rx.host_us["all_gather"] / steps, ".".join(map(str, torch.cuda.nccl.version()))))
+        rx.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()

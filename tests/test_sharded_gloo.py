@@ -124,7 +124,7 @@ def test_capacity_overflow_on_one_rank_is_everybodys_redo(emu_lib, oracle_mod):
 STREAM_STEPS = 3
 
 
-def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_rank, dcblock, seed):
+def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_rank, dcblock, seed, force=False):
     for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -139,7 +139,7 @@ def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_r
         ctx = _capi.Context(rate, 7.0, True, use_dcblock=dcblock, lib=lib)
         ctx.set_rx_time(0, 1000, 0.25)
         ctx.set_rx_time(world * n_per_rank + 12345, 2000, 0.5)      # (a tag in the middle of the second step)
-        rx = ShardedReceiver(ctx, rank, world, n_per_rank, small_table=small_table, host_free=host_free)
+        rx = ShardedReceiver(ctx, rank, world, n_per_rank, small_table=small_table, host_free=host_free, force_collectives=force)
         out = []
         for k in range(STREAM_STEPS):
             a = (k * world + rank) * n_per_rank
@@ -147,8 +147,27 @@ def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_r
             out.append(rx.step(flush=(k == STREAM_STEPS - 1)).tobytes())
         ret[rank] = out
         ret["sync_%d" % rank] = rx.sync_steps
+        ret["forced_%d" % rank] = (rx.force, rx.host_us["all_gather"] > 0.0, rx.host_us["tail_exchange"] > 0.0)
     finally:
         dist.destroy_process_group()
+
+
+def test_one_rank_receiver_through_the_process_group(emu_lib, oracle_mod):
+    """force_collectives sends a ONE-rank receiver through the process group as well -- the tail to itself (gloo
+    refuses a send to oneself: the all_gather fallback carries it), the exit table by all_gather_into_tensor -- so that on a box
+    with one GPU the backend ("nccl" there: tests/test_gpu_rccl.py) executes this code.  Three steps == the oracle over the
+    whole capture, no step on the synchronous path."""
+    import synth
+    from air_modes import _capi
+    rate, n_per_rank, seed = 20e6, 150000, 2722
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_stream, args=(1, 29671, ret, 512, True, rate, n_per_rank, False, seed, True), nprocs=1, join=True)
+    got = np.concatenate([np.frombuffer(ret[0][k], _capi.PACKET_DTYPE) for k in range(STREAM_STEPS)])
+    assert ret["sync_0"] == 0 and ret["forced_0"] == (True, True, True)
+    iq, _ = synth.synth_capture(rate, STREAM_STEPS * n_per_rank, 9000.0, seed=seed)
+    want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25), (n_per_rank + 12345, 2000, 0.5)])
+    assert len(want) > 30 and np.array_equal(got, want)
 
 
 @pytest.mark.parametrize("world,small_table,host_free,rate,dcblock", [(2, 512, True, 20e6, False), (3, 512, True, 20e6, False),
