@@ -37,7 +37,7 @@ def same(a, b):
     return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
 
 
-@settings(max_examples=400, deadline=None, derandomize=False, database=None,
+@settings(max_examples=100000, deadline=None, derandomize=False, database=None,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much,
                                  HealthCheck.function_scoped_fixture])
 @given(st.data())
