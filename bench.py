@@ -441,6 +441,8 @@ def main():
         extra["host_dist_us_per_step"] = {"tail_exchange_batch_isend_irecv": rx.host_us["tail_exchange"] / hs,
                                           "exit_table_all_gather_into_tensor": rx.host_us["all_gather"] / hs,
                                           "steps_counted": rx.host_us["steps"], "rank": rank,
+                                          # (the mean includes the backend's first call, which sets its communicator up: the median does not)
+                                          "median_us": {k: (float(np.median(v)) if v else 0.0) for k, v in rx.host_us_steps.items()},
                                           "through_the_process_group": bool(world > 1 or rx.force),
                                           "tail_by": ("all_gather (the backend refused a send to itself)" if rx.tail_by_gather else
                                                       "batch_isend_irecv") if (world > 1 or rx.force) else "device copy (one rank, no group)"}
@@ -660,9 +662,19 @@ def main():
                     # (the reference driver also reports hits past the canonical end of the stream: a prefix match)
                     "messages_match_gpu": bool(rmsgs[:len(sub)] == ctx_messages(ctx, sub) and len(sub) > 0)}
         res.update(extra)
-        print(json.dumps(res))
+    # the JSON line is the LAST thing on stdout: the process group goes first (RCCL prints a version banner through C stdio, which
+    # would otherwise land behind the line when the process exits), every C stream is flushed, then the line
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -81,6 +81,7 @@ class ShardedReceiver(object):
         # host time spent inside the torch.distributed calls of step(), summed over steps (microseconds; bench.py reports
         # them per step beside the no-collective floor of a one-rank receiver)
         self.host_us = {"tail_exchange": 0.0, "all_gather": 0.0, "steps": 0}
+        self.host_us_steps = {"tail_exchange": [], "all_gather": []}     # ... and per step (the first call of a backend sets its communicator up)
         self._alloc(device if device is not None else "cpu")
         # the device-side exchange hands device pointers to kernels: only where the buffers live on the GPU (or where
         # "device memory" is host memory: the CPU emulation the tests run on)
@@ -173,6 +174,7 @@ class ShardedReceiver(object):
                         raise
                     self.tail_by_gather = True           # (one rank, a backend without send-to-self: below)
                 self.host_us["tail_exchange"] += (time.perf_counter() - tc) * 1e6
+                self.host_us_steps["tail_exchange"].append((time.perf_counter() - tc) * 1e6)
         if self.force and self.tail_by_gather and self.k > 0:
             tc = time.perf_counter()
             dist.all_gather_into_tensor(self._halo_view, self._tail, group=self.group)     # world 1: the gathered tensor IS the tail
@@ -206,6 +208,7 @@ class ShardedReceiver(object):
                 tc = time.perf_counter()
                 dist.all_gather_into_tensor(self._agath, self._amsg, group=self.group)
                 self.host_us["all_gather"] += (time.perf_counter() - tc) * 1e6
+                self.host_us_steps["all_gather"].append((time.perf_counter() - tc) * 1e6)
                 if on_gpu:
                     self.ctx.wait_for_stream(cur)            # ... and the resolve step for the collective
                 msgs = self._agath
