@@ -83,6 +83,8 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the realistic-density and batches-in-flight figures")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (contexts/streams driven by host threads)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 3-batches-in-flight figure (profiling runs)")
+    ap.add_argument("--stream-seconds", type=float, default=16.0, help="signal seconds of the pipelined_stream leg (ONE continuing stream, "
+                                                                      "its chunks in flight: am_spipe); 0 skips it")
     ap.add_argument("--sustained-steps", type=int, default=2000, help="steps of the extra sustained leg (>= 0.5 s of device work: a sampler "
                                                                         "of GPU activity sees the device busy); 0 skips it")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
@@ -332,6 +334,59 @@ def main():
                                   "same_packet_counts": counts3 == [per_batch[k % nb] for k in range(PIPE_BATCHES)],
                                   "same_packets_last_batch": bool(np.array_equal(last3, want_last))}
             pipe.close()
+        if mode == "single" and K == 1 and not args.no_extra and not args.no_pipelined and inflight == 1 and args.stream_seconds > 0 \
+                and args.steps >= 3:
+            # ONE continuing stream with four of its consecutive chunks in flight (am_spipe): the reference block is a
+            # streaming block (lib/preamble_impl.cc:139-246) -- chunk k + 1's scan is enqueued before chunk k resolves, the scan
+            # position travels on the device.  The stream: the run's distinct batches one after the other, again and again, each a
+            # 1 s chunk in a buffer of its own (the library copies the tail of the chunk before in front of it: 87 KB).  Parity: the
+            # packets of ALL chunks against the oracle over the WHOLE stream (item counts and time stamps continue across chunks).
+            SP_DEPTH = 4
+            nchunks = max(SP_DEPTH + 1, int(round(args.stream_seconds / secs)))
+            if not args.no_parity:
+                # (the oracle wants the stream in one piece: ~3 x 8 bytes per sample of host memory for its dense arrays)
+                try:
+                    import psutil
+                    fit = int(psutil.virtual_memory().available * 0.5 // (24 * n))
+                    nchunks = max(SP_DEPTH + 1, min(nchunks, fit))
+                except Exception:
+                    pass
+            sp = _capi.StreamPipe(rate, 7.0, True, device=(0 if args.emu else local), depth=SP_DEPTH, lib=lib) if lib is not None \
+                else _capi.StreamPipe(rate, 7.0, True, device=local, depth=SP_DEPTH)
+            front = sp.front()
+            sbufs = []
+            for b in range(nb):
+                tb = torch.zeros(2 * (front + n), dtype=torch.float32, device=dev)
+                tb[2 * front:].copy_(d_batches[b])
+                sbufs.append(tb)
+            sync()
+            chunks = [(sbufs[k % nb].data_ptr() + 8 * front, n) for k in range(nchunks)]
+            sp.run(chunks[:SP_DEPTH + 1])                           # (a short stream first: allocations, capacities)
+            sync()
+            t4 = time.perf_counter()
+            got4 = sp.run(chunks)
+            sync()
+            dt4 = time.perf_counter() - t4
+            all4 = np.concatenate(got4)
+            extra["pipelined_stream"] = {
+                "what": "ONE continuing 64 Msps-class stream, %d chunks of %d samples, %d in flight (am_spipe): scan of chunk k+1 "
+                        "enqueued before chunk k resolves, scan position handed on through a device word" % (nchunks, n, SP_DEPTH),
+                "chunks": nchunks, "chunks_in_flight": SP_DEPTH, "host_threads": 1, "signal_seconds": nchunks * secs,
+                "value": n * nchunks / dt4, "unit": "samples/s", "ms_per_chunk": dt4 / nchunks * 1e3,
+                "path_frac_of_hbm_peak": 8.0 * n * nchunks / dt4 / 1e9 / HBM_PEAK_GBS,
+                "packets": int(len(all4)), "chunks_redone_synchronously": sp.redone(),
+                "last_packet_item_count": int(all4["sample"][-1]) if len(all4) else None}
+            if not args.no_parity:
+                import oracle
+                whole4 = np.concatenate([host_batches[k % nb] for k in range(nchunks)])
+                t5 = time.perf_counter()
+                want4 = oracle.demod(whole4, rate, 7.0, True)
+                extra["pipelined_stream"]["parity_whole_stream_vs_oracle"] = bool(np.array_equal(all4, want4))
+                extra["pipelined_stream"]["oracle_seconds"] = time.perf_counter() - t5
+                del whole4, want4
+            sp.close()
+            del sbufs
+            run_steps(2, [ctx], 1, d_batches)
         if mode == "single" and K == 1 and not args.no_extra and lam != REALISTIC_LAMBDA:
             iq_r = synth.synth_capture(rate, n, REALISTIC_LAMBDA, seed + 7)[0]
             d_r = [torch.from_numpy(iq_r.view(np.float32)).to(dev)]

@@ -19,7 +19,7 @@ AM_F_ZERO_GAPS = 0x20
 AM_F_DEVICE_OUT = 0x4
 AM_F_KEEP_TAGS = 0x8
 AM_F_MORE = 0x10
-ABI_VERSION = 4
+ABI_VERSION = 5
 SHARD_MSG_HEADER = 2          # header entries of a device-side exit-table message (am_shard_scan_async)
 
 AM_OK, AM_EINVAL, AM_ENODEV, AM_ENOMEM, AM_EHIP, AM_ECAPACITY, AM_ENOTSUP = 0, -1, -2, -3, -4, -5, -6
@@ -138,6 +138,21 @@ class Library(object):
         L.am_pipe_last_error.argtypes = [vp]
         L.am_pipe_last_kernel_ms.restype = C.c_float
         L.am_pipe_last_kernel_ms.argtypes = [vp]
+        L.am_spipe_create.restype = vp
+        L.am_spipe_create.argtypes = [C.c_int, C.c_double, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.am_spipe_destroy.argtypes = [vp]
+        L.am_spipe_submit.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+        L.am_spipe_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.am_spipe_in_flight.argtypes = [vp]
+        L.am_spipe_depth.argtypes = [vp]
+        L.am_spipe_front.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.am_spipe_set_rx_time.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_double]
+        L.am_spipe_redone.restype = C.c_uint64
+        L.am_spipe_redone.argtypes = [vp]
+        L.am_spipe_last_error.restype = C.c_char_p
+        L.am_spipe_last_error.argtypes = [vp]
+        L.am_spipe_last_kernel_ms.restype = C.c_float
+        L.am_spipe_last_kernel_ms.argtypes = [vp]
         L.am_fetch_tags.argtypes = [vp, vp, vp, u64, pu64]
         L.am_fetch_candidates.argtypes = [vp, vp, vp, vp, vp, u64, pu64]
         L.am_last_frontend.restype = C.c_int
@@ -624,6 +639,83 @@ class Pipe(object):
 
     def last_kernel_ms(self):
         return float(self.lib.L.am_pipe_last_kernel_ms(self._h))
+
+
+class StreamPipe(object):
+    """am_spipe wrapper: ONE continuing stream with `depth` of its consecutive chunks in flight on one GPU (lib/preamble_impl.cc:
+    139-246 is a streaming block).  Chunks are DEVICE pointers; every chunk but a stream's first needs front() samples of room in
+    front of it in the same allocation (the library copies the previous chunk's tail there unless the stream is contiguous in
+    memory); a chunk and the one submitted before it stay valid until it is collected.  Packets of all chunks in order == one
+    process_iq over the whole stream."""
+
+    def __init__(self, rate, threshold_db=7.0, use_pmf=True, use_dcblock=False, device=-1, depth=3, lib=None):
+        self.lib = lib or default_library()
+        err = C.c_int(0)
+        self._h = self.lib.L.am_spipe_create(int(device), float(rate), float(threshold_db), int(bool(use_pmf)),
+                                             int(bool(use_dcblock)), int(depth), C.byref(err))
+        if not self._h:
+            raise AirModesError(err.value, self.lib.L.am_last_error(None).decode())
+        self._out = np.zeros(4096, PACKET_DTYPE)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.am_spipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != AM_OK:
+            raise AirModesError(rc, self.lib.L.am_spipe_last_error(self._h).decode())
+
+    def in_flight(self):
+        return int(self.lib.L.am_spipe_in_flight(self._h))
+
+    def depth(self):
+        return int(self.lib.L.am_spipe_depth(self._h))
+
+    def front(self):
+        f = C.c_uint64(0)
+        self._chk(self.lib.L.am_spipe_front(self._h, C.byref(f)))
+        return int(f.value)
+
+    def redone(self):
+        return int(self.lib.L.am_spipe_redone(self._h))
+
+    def set_rx_time(self, offset, secs, frac):
+        self._chk(self.lib.L.am_spipe_set_rx_time(self._h, int(offset), int(secs), float(frac)))
+
+    def submit_device(self, ptr, n, flush=False):
+        self._chk(self.lib.L.am_spipe_submit(self._h, int(ptr), int(n), AM_F_DEVICE_IN | (AM_F_FLUSH if flush else 0)))
+
+    def collect(self):
+        got = C.c_uint64(0)
+        rc = self.lib.L.am_spipe_collect(self._h, self._out.ctypes.data, len(self._out), C.byref(got))
+        if rc == AM_ECAPACITY:
+            self._out = np.zeros(int(got.value) + 1024, PACKET_DTYPE)
+            rc = self.lib.L.am_spipe_collect(self._h, self._out.ctypes.data, len(self._out), C.byref(got))
+        self._chk(rc)
+        return self._out[:int(got.value)].copy()
+
+    def last_kernel_ms(self):
+        return float(self.lib.L.am_spipe_last_kernel_ms(self._h))
+
+    def run(self, chunks):
+        """chunks: iterable of (device pointer, samples); the last one ends the stream.  Keeps depth() chunks in flight; returns
+        the packets of every chunk, in order."""
+        chunks = list(chunks)
+        out = []
+        for k, (ptr, n) in enumerate(chunks):
+            if self.in_flight() == self.depth():
+                out.append(self.collect())
+            self.submit_device(ptr, n, flush=(k == len(chunks) - 1))
+        while self.in_flight():
+            out.append(self.collect())
+        return out
 
 
 class Uploader(object):

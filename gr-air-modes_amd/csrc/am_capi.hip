@@ -170,6 +170,7 @@ struct am_ctx {
     DevBuf shard_exit;                  // device word: where the scan left this context's chunk in the last resolved step (0: none)
     const am_entry_src *entry_src = nullptr; // set around chain_finish: the scan's start position is composed on the device (time shards)
     const uint32_t *flag_src = nullptr; // ... and this device word is handed to the host with the completion ticket (pin_scalars[4])
+    const uint64_t *word_src = nullptr; // ... and this 64-bit one (pin_scalars[12..13]: where the scan left the chunk -- am_spipe's books)
 
     // pinned host memory the tail kernels write into directly
     am_packet *pin_packets = nullptr;
@@ -821,7 +822,8 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
         // (am_shard_keep_tail; behind the extraction kernel, which still reads them; complete when the ticket is seen)
         HIPCHK(c, hipMemcpyAsync(c->keep_dst, c->keep_src, c->keep_bytes, hipMemcpyDeviceToDevice, c->stream));
     const uint32_t seq = ++c->ticket_seq;
-    HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, c->flag_src, c->flag_src ? c->pin_scalars + 4 : nullptr));
+    HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, c->flag_src, c->flag_src ? c->pin_scalars + 4 : nullptr,
+                               c->word_src, c->word_src ? reinterpret_cast<uint64_t *>(c->pin_scalars + 12) : nullptr));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));          // end of the device work of this scan (behind the ticket)
     c->total_pending = true;
     if (c->defer && !keep_bursts) {
@@ -2111,6 +2113,331 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     return hand_out(c, out, cap, n_out);
 }
 
+} // extern "C"
+
+/* ---- ONE continuing stream, several of its chunks in flight ---------------------------------------------------
+ * The reference block is a streaming block: general_work() resumes where the last call stopped, for ever (lib/preamble_impl.cc:
+ * 139-246, consume_each at :213,237,244).  am_process_iq does that one chunk at a time -- the host's turn-around and the launch-bound
+ * tail of chunk k in front of the streaming kernel of chunk k + 1.  Here consecutive chunks of ONE stream are in flight on one GPU,
+ * each on a context and a stream of its own, with the time-shard machinery at world 1: chunk k decides the positions
+ * [S_k - H, S_k + n_k - H) from its own samples and the tail of the chunk before it (AM_F_MORE); its scan -- front end, refinement,
+ * block exits, exit table -- does not depend on where the greedy scan enters the chunk and is enqueued at once; its resolve step
+ * takes the entry position ON THE DEVICE from the word in which the chunk before it leaves it (am_entry_src::cur_in), ordered
+ * behind that chunk's resolve by an event.  Nothing waits for the host between two chunks; item counts and time stamps keep counting
+ * (positions are stream-absolute).  A chunk whose exit table did not fit its message, or whose scan met more candidates than the
+ * capacity it was launched for, is flagged in its message header: the chunks behind it (which composed their entry from a word that
+ * was not written) are drained, the chunk is redone on the synchronous path (host tables, am_shard_entry2), and the drained chunks
+ * are submitted again.  Packets of all chunks, concatenated, == am_process_iq over the same cuts == the oracle over the stream. */
+struct am_spipe_slot {
+    am_ctx *c = nullptr;
+    am_shard_exit *msg = nullptr;       // device message of the chunk's scan: header + msg_cap entries
+    hipEvent_t done = nullptr;          // behind the chunk's resolve step
+    const float *iq = nullptr;          // the chunk as submitted
+    uint64_t S = 0, n = 0;
+    bool flush = false, first = false;
+};
+struct am_spipe {
+    std::vector<am_spipe_slot> slot;
+    size_t head = 0, inflight = 0;
+    uint64_t S_next = 0;                // samples of the stream submitted so far
+    bool ended = false;                 // a flushing chunk is in flight: the stream starts over once everything is collected
+    uint64_t hl = 0, H = 0;             // history in front of a position / look-ahead behind it
+    uint32_t msg_cap = 512;
+    uint64_t *zero_dev = nullptr;       // a device word that holds 0: where the scan "left the chunk before" the stream's first
+    uint64_t exit_host = 0;             // where the scan left the last collected chunk (host copy: a redone chunk starts there)
+    const float *prev_iq = nullptr;     // the chunk submitted last
+    uint64_t prev_n = 0;
+    int prev_slot = -1;
+    uint64_t redone = 0;                // chunks that went through the synchronous path
+    std::vector<am_shard_exit> host_tab;
+    const am_ctx *last_fail = nullptr;
+    char err[160] = "";
+};
+
+static int spipe_fail(am_spipe *p, int code, const char *what)
+{
+    p->last_fail = nullptr;
+    snprintf(p->err, sizeof(p->err), "%s", what);
+    return code;
+}
+
+// what the time-shard calls need of chunk (S, n) of the stream: the positions it decides and the samples it hands over
+static void spipe_bounds(const am_spipe *p, const am_spipe_slot &sl, uint64_t *a0, uint64_t *a1, uint64_t *total, const float **ptr)
+{
+    *total = sl.S + sl.n;
+    *a0 = sl.first ? 0 : sl.S - p->H;
+    *a1 = sl.flush ? *total : sl.S + sl.n - p->H;
+    const uint64_t lo = *a0 > p->hl ? *a0 - p->hl : 0;          // first sample the library wants
+    *ptr = sl.iq - (sl.S - lo) * 2;
+}
+
+// enqueue scan + resolve of the chunk in slot k (its fields are filled in); nothing waits
+static int spipe_enqueue(am_spipe *p, size_t k)
+{
+    am_spipe_slot &sl = p->slot[k];
+    am_ctx *c = sl.c;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint64_t a0, a1, total;
+    const float *ptr;
+    spipe_bounds(p, sl, &a0, &a1, &total, &ptr);
+    // the samples in front of the chunk: the tail of the chunk before it, copied there unless the stream is contiguous in memory
+    if (!sl.first && p->prev_iq) {
+        const uint64_t front = p->hl + p->H;
+        const float *src = p->prev_iq + (p->prev_n - front) * 2;
+        float *dst = const_cast<float *>(sl.iq) - front * 2;
+        if (src != dst) HIPCHK(c, hipMemcpyAsync(dst, src, front * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    int rc = shard_scan_core(c, ptr, a0, a1, total, AM_F_DEVICE_IN | (sl.flush ? 0u : AM_F_MORE), nullptr, 0, nullptr, sl.msg, p->msg_cap);
+    if (rc != AM_OK) return rc;
+    // the resolve step: behind the resolve of the chunk before (the word it leaves), entry composed on the device
+    const uint64_t *cur_in = p->zero_dev;
+    if (!sl.first && p->prev_slot >= 0) {
+        am_spipe_slot &pv = p->slot[(size_t)p->prev_slot];
+        if (int rce = ensure_shard_exit(pv.c); rce != AM_OK) return rce;
+        cur_in = (const uint64_t *)pv.c->shard_exit.p;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, pv.done, 0));
+    }
+    c->pending.clear();
+    c->last_tags = 0;
+    if (int rcs = ensure_scalars(c); rcs != AM_OK) return rcs;
+    if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
+    uint32_t *cur0_dev = (uint32_t *)c->scalars.p + 4, *flag_dev = (uint32_t *)c->scalars.p + 5;
+    if (!c->pin_scalars) {
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));
+    }
+    am_ctx::Pending &P = c->pend;
+    P = am_ctx::Pending();
+    uint64_t em = 0;
+    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c, c->shard_total, &em) || em < c->shard_base))) {
+        // nothing to slice: the entry is still composed (the chunk passes the scan position on), one ticket
+        HIPCHK(c, am_launch_shard_entry(sl.msg, 1, 0, p->msg_cap, c->shard_base, cur0_dev, flag_dev, (uint64_t *)c->shard_exit.p, c->stream, cur_in));
+        const uint32_t seq = ++c->ticket_seq;
+        HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, flag_dev, c->pin_scalars + 4, (const uint64_t *)c->shard_exit.p,
+                                   reinterpret_cast<uint64_t *>(c->pin_scalars + 12)));
+        P.active = true; P.scanned = false; P.seq = seq;
+    } else {
+        const uint32_t emax = c->shard_more ? 0xFFFFFFFEu : (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
+        uint32_t fin = 0;
+        const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) / ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
+        am_entry_src es;
+        es.msgs = sl.msg; es.world = 1; es.rank = 0; es.cap = p->msg_cap; es.base_abs = c->shard_base; es.flags = flag_dev;
+        es.exit_out = (uint64_t *)c->shard_exit.p; es.cur_in = cur_in;
+        c->entry_src = &es;
+        c->flag_src = flag_dev;
+        c->word_src = (const uint64_t *)c->shard_exit.p;
+        c->resolving_shard = true;
+        c->defer = true;
+        rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
+        c->defer = false;
+        c->resolving_shard = false;
+        c->entry_src = nullptr;
+        c->flag_src = nullptr;
+        c->word_src = nullptr;
+        if (rc != AM_DEFERRED) return rc == AM_OK ? fail(c, AM_EHIP, "internal: the resolve step was not deferred") : rc;
+        P.active = true;                                        // (chain_finish filled in scanned / seq / M / Mp / n_max)
+    }
+    HIPCHK(c, hipEventRecord(sl.done, c->stream));
+    return AM_OK;
+}
+
+// wait for the chunk in slot k; its packets stay in the context's hand-out list.  *redo: the chunk must go through the synchronous path
+static int spipe_complete(am_spipe *p, size_t k, int *redo, uint64_t *exit_after)
+{
+    am_ctx *c = p->slot[k].c;
+    am_ctx::Pending &P = c->pend;
+    *redo = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, wait_for_ticket(c, P.seq));
+    int rc = AM_OK;
+    if (P.scanned) {
+        uint32_t fin = 0;
+        rc = chain_collect(c, P.M, P.Mp, P.n_max, false, &fin);
+        if (rc == AM_RETRY_EXACT) { *redo = 1; rc = AM_OK; }
+    } else
+        c->tail_synced = true;
+    P.active = false; P.scanned = false;
+    if (rc != AM_OK) return rc;
+    if (c->pin_scalars[4]) *redo = 1;                           // a table that did not fit, a capacity that did not suffice: the header says so
+    if (*redo) c->pending.clear();
+    *exit_after = *reinterpret_cast<volatile uint64_t *>(c->pin_scalars + 12);
+    c->spec_density = (c->shard_end > c->shard_start) ? (double)c->last_M / (double)(c->shard_end - c->shard_start) : 0.0;
+    c->last_tags = c->n_hits;
+    c->last_dom_ms = 0.0f;
+    if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
+    return AM_OK;
+}
+
+extern "C" {
+
+am_spipe *am_spipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err)
+{
+    if (depth < 1 || depth > 16) { if (err) *err = AM_EINVAL; return nullptr; }
+    am_spipe *p = new (std::nothrow) am_spipe();
+    if (!p) { if (err) *err = AM_ENOMEM; return nullptr; }
+    p->slot.resize((size_t)depth);
+    for (int k = 0; k < depth; k++) {
+        am_spipe_slot &sl = p->slot[(size_t)k];
+        sl.c = am_create(device, rate, threshold_db, use_pmf, use_dcblock, err);
+        if (!sl.c) { am_spipe_destroy(p); return nullptr; }
+        if (depth > 1) sl.c->fe_wgs_per_cu = 5;                 // (as am_pipe: room on every CU for the other chunks' small kernels)
+        if (hipMalloc((void **)&sl.msg, ((size_t)AM_SHARD_MSG_HEADER + p->msg_cap) * sizeof(am_shard_exit)) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
+            if (err) *err = AM_ENOMEM;
+            am_spipe_destroy(p);
+            return nullptr;
+        }
+    }
+    uint64_t hl = 0, hr = 0;
+    am_shard_halo(p->slot[0].c, &hl, &hr);
+    p->hl = hl; p->H = hr;
+    if (hipMalloc((void **)&p->zero_dev, 2 * sizeof(uint64_t)) != hipSuccess || hipMemset(p->zero_dev, 0, 2 * sizeof(uint64_t)) != hipSuccess) {
+        if (err) *err = AM_ENOMEM;
+        am_spipe_destroy(p);
+        return nullptr;
+    }
+    p->host_tab.resize((size_t)(241 * (p->slot[0].c->spc_hi) + 8));
+    if (err) *err = AM_OK;
+    return p;
+}
+
+void am_spipe_destroy(am_spipe *p)
+{
+    if (!p) return;
+    for (am_spipe_slot &sl : p->slot) {
+        if (sl.c) { (void)hipSetDevice(sl.c->device); (void)hipStreamSynchronize(sl.c->stream); }
+        if (sl.msg) (void)hipFree(sl.msg);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+        am_destroy(sl.c);
+    }
+    if (p->zero_dev) (void)hipFree(p->zero_dev);
+    delete p;
+}
+
+int am_spipe_depth(const am_spipe *p) { return p ? (int)p->slot.size() : AM_EINVAL; }
+int am_spipe_in_flight(const am_spipe *p) { return p ? (int)p->inflight : AM_EINVAL; }
+uint64_t am_spipe_redone(const am_spipe *p) { return p ? p->redone : 0; }
+
+int am_spipe_front(const am_spipe *p, uint64_t *front)
+{
+    if (!p || !front) return AM_EINVAL;
+    *front = p->hl + p->H;
+    return AM_OK;
+}
+
+int am_spipe_set_rx_time(am_spipe *p, uint64_t offset, uint64_t secs, double frac)
+{
+    if (!p) return AM_EINVAL;
+    if (p->inflight) return spipe_fail(p, AM_EINVAL, "rx_time: collect the chunks in flight first (the tag tables are read by their kernels)");
+    for (am_spipe_slot &sl : p->slot)
+        if (int rc = am_set_rx_time(sl.c, offset, secs, frac); rc != AM_OK) { p->last_fail = sl.c; return rc; }
+    return AM_OK;
+}
+
+int am_spipe_submit(am_spipe *p, const float *iq, uint64_t n, uint32_t flags)
+{
+    if (!p) return AM_EINVAL;
+    if (p->inflight == p->slot.size()) return spipe_fail(p, AM_ECAPACITY, "every context of the pipe has a chunk in flight: collect the oldest one first");
+    if (p->ended) return spipe_fail(p, AM_EINVAL, "the stream was flushed: collect its chunks before the next stream starts");
+    if (!iq || n == 0) return spipe_fail(p, AM_EINVAL, "null or empty chunk");
+    const bool first = p->S_next == 0;
+    const uint64_t front = p->hl + p->H;
+    if (n < front + 1 || n > ((uint64_t)1 << 30)) return spipe_fail(p, AM_EINVAL, "a chunk must hold more samples than am_spipe_front() reports (and fewer than 2^30)");
+    const size_t k = (p->head + p->inflight) % p->slot.size();
+    am_spipe_slot &sl = p->slot[k];
+    sl.iq = iq; sl.S = p->S_next; sl.n = n; sl.flush = (flags & AM_F_FLUSH) != 0; sl.first = first;
+    const int rc = spipe_enqueue(p, k);
+    if (rc != AM_OK) { p->last_fail = sl.c; return rc; }
+    p->inflight++;
+    p->S_next += n;
+    p->prev_iq = iq; p->prev_n = n; p->prev_slot = (int)k;
+    if (sl.flush) p->ended = true;
+    return AM_OK;
+}
+
+int am_spipe_collect(am_spipe *p, am_packet *out, uint64_t cap, uint64_t *n_out)
+{
+    if (!p) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    if (p->inflight == 0) return spipe_fail(p, AM_EINVAL, "no chunk in flight");
+    const size_t k = p->head;
+    am_spipe_slot &sl = p->slot[k];
+    am_ctx *c = sl.c;
+    if (c->pend.active) {
+        int redo = 0;
+        uint64_t leave = 0;
+        int rc = spipe_complete(p, k, &redo, &leave);
+        if (rc != AM_OK) { p->last_fail = c; return rc; }
+        if (redo) {
+            // the chunks behind this one composed their entry from a word that was never written: drain them, redo this chunk with
+            // the tables on the host, submit them again
+            p->redone++;
+            const size_t D = p->slot.size();
+            for (size_t j = 1; j < p->inflight; j++) {
+                int r2 = 0;
+                uint64_t l2 = 0;
+                am_ctx *cj = p->slot[(k + j) % D].c;
+                rc = spipe_complete(p, (k + j) % D, &r2, &l2);
+                cj->pending.clear();
+                if (rc != AM_OK) { p->last_fail = cj; return rc; }
+            }
+            uint64_t a0, a1, total, m = 0;
+            const float *ptr;
+            spipe_bounds(p, sl, &a0, &a1, &total, &ptr);
+            rc = am_shard_scan(c, ptr, a0, a1, total, AM_F_DEVICE_IN | (sl.flush ? 0u : AM_F_MORE), p->host_tab.data(), p->host_tab.size(), &m);
+            if (rc != AM_OK) { p->last_fail = c; return rc; }
+            const am_shard_exit *tabs[1] = {p->host_tab.data()};
+            uint64_t entry = 0;
+            rc = am_shard_entry2(tabs, &m, 1, p->exit_host, &entry, &leave);
+            if (rc != AM_OK) return spipe_fail(p, rc, "am_shard_entry2");
+            uint64_t got = 0;
+            rc = am_shard_resolve(c, entry, nullptr, 0, &got);   // (the packets stay in the context's hand-out list: AM_ECAPACITY is expected)
+            if (rc != AM_OK && rc != AM_ECAPACITY) { p->last_fail = c; return rc; }
+            rc = am_shard_set_exit(c, leave);
+            if (rc != AM_OK) { p->last_fail = c; return rc; }
+            // the chunks behind it, in order, once more (chunk k's own word now holds where the scan left it)
+            const float *piq = sl.iq;
+            uint64_t pn = sl.n;
+            int pslot = (int)k;
+            for (size_t j = 1; j < p->inflight; j++) {
+                const size_t kj = (k + j) % D;
+                p->prev_iq = piq; p->prev_n = pn; p->prev_slot = pslot;
+                rc = spipe_enqueue(p, kj);
+                if (rc != AM_OK) { p->last_fail = p->slot[kj].c; return rc; }
+                piq = p->slot[kj].iq; pn = p->slot[kj].n; pslot = (int)kj;
+            }
+            p->prev_iq = piq; p->prev_n = pn; p->prev_slot = pslot;
+        }
+        p->exit_host = leave;
+    }
+    const int hrc = hand_out(c, out, cap, n_out);
+    if (hrc == AM_ECAPACITY) { p->last_fail = c; return hrc; }  // the packets stay: call again with a larger array
+    p->head = (p->head + 1) % p->slot.size();
+    p->inflight--;
+    if (p->ended && p->inflight == 0) {
+        // the stream is over: the next submit starts a new one at sample 0
+        for (am_spipe_slot &s2 : p->slot) { am_reset(s2.c); (void)am_shard_set_exit(s2.c, 0); }
+        p->S_next = 0; p->ended = false; p->prev_iq = nullptr; p->prev_n = 0; p->prev_slot = -1; p->exit_host = 0;
+    }
+    return hrc;
+}
+
+const char *am_spipe_last_error(const am_spipe *p)
+{
+    if (!p || p->slot.empty()) return g_create_err;
+    return p->last_fail ? p->last_fail->err : p->err;
+}
+
+float am_spipe_last_kernel_ms(const am_spipe *p)
+{
+    if (!p || p->slot.empty()) return 0.0f;
+    const size_t last = (p->head + p->slot.size() - 1) % p->slot.size();
+    return p->slot[last].c->last_dom_ms;
+}
+
+} // extern "C"
+
+extern "C" {
 /* ---- several batches in flight from one host thread ------------------------------------------------------- */
 struct am_pipe {
     std::vector<am_ctx *> sub;

@@ -149,7 +149,7 @@ hipError_t am_launch_exscan_chain(const uint32_t *in, uint32_t *out, uint32_t n,
                                   const uint32_t *Mp = nullptr);   /* *err = 1: the chain gave up; ticket: device counter,
                                   *ticket_base: the value it has when this launch starts (advanced by the grid size) */
 hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s, const uint32_t *count_src = nullptr,
-                            uint32_t *count_dst = nullptr);
+                            uint32_t *count_dst = nullptr, const uint64_t *word_src = nullptr, uint64_t *word_dst = nullptr);
 
 /* ---- optional DC blocker in front of the path (am_dcblock.hip) ---------------------------- */
 #define AM_DC_CHIPS 100              /* rx_path.py:40  dc_blocker_cc(100*spc, False) */
@@ -204,6 +204,7 @@ struct am_entry_src {
     uint64_t base_abs;              // absolute index of the chunk's array coordinate 0
     uint32_t *flags;                // flags[0] = 1: repeat the step
     uint64_t *exit_out;             // where the scan leaves this chunk (absolute): the next step's message carries it
+    const uint64_t *cur_in;         // non-null: where the scan left the chunk BEFORE this one, read when the entry is composed (am_spipe)
 };
 
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
@@ -222,7 +223,7 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 /* device-side am_shard_entry2: `world` messages of AM_SHARD_MSG_HEADER + cap entries; writes the array coordinate at which the
  * scan enters chunk `rank`, the absolute position at which it leaves it, and sets flags[0] if some table did not fit */
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
-                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s);
+                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s, const uint64_t *cur_in = nullptr);
 /* the header of a message without a table: {0, 0}, {*carry, 0} */
 hipError_t am_launch_shard_header(am_shard_exit *header, const uint64_t *carry, hipStream_t s);
 

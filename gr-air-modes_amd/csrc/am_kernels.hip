@@ -1382,10 +1382,13 @@ __device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint16_t
 // ascend: a ballot) -- one thread stepping through a table entry by entry paid a dependent load per entry, and chunk 7 of 8
 // waits for seven tables.
 __device__ __forceinline__ uint64_t am_shard_entry_wave(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank,
-                                                        uint32_t cap, int lane, uint32_t *bad_out, uint64_t *exit_out)
+                                                        uint32_t cap, int lane, uint32_t *bad_out, uint64_t *exit_out,
+                                                        const uint64_t *__restrict__ cur_in = nullptr)
 {
     const size_t stride = (size_t)cap + AM_SHARD_MSG_HEADER;
-    uint64_t cur = msgs[(size_t)(world - 1u) * stride + 1u].pos;             // (every lane reads the same word)
+    // where the scan left the last chunk of the step before: the last rank's header -- or, chunks of ONE stream in flight on one GPU
+    // (am_spipe), the word the chunk before this one leaves it in, read NOW: that chunk's scan was enqueued before the word was written
+    uint64_t cur = cur_in ? *cur_in : msgs[(size_t)(world - 1u) * stride + 1u].pos;             // (every lane reads the same word)
     uint64_t entry = cur;
     uint32_t bad = 0;
     for (uint32_t r = 0; r <= rank; ++r) {
@@ -1436,7 +1439,7 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
         if (threadIdx.x < AM_WAVE) {
             uint32_t bad = 0;
             uint64_t leave = 0;
-            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad, &leave);
+            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad, &leave, es.cur_in);
             if (threadIdx.x == 0) {
                 uint64_t rel = cur > es.base_abs ? cur - es.base_abs : 0;
                 if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
@@ -1950,7 +1953,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     if (lds > AM_CB_WALK_LDS) return hipErrorInvalidValue;   // (more than ~75 000 blocks of 2048 candidates in one scan)
     am_entry_src es;
     if (entry_src) es = *entry_src;
-    else { es.msgs = nullptr; es.world = 0; es.rank = 0; es.cap = 0; es.base_abs = 0; es.flags = nullptr; es.exit_out = nullptr; }
+    else { es.msgs = nullptr; es.world = 0; es.rank = 0; es.cap = 0; es.base_abs = 0; es.flags = nullptr; es.exit_out = nullptr; es.cur_in = nullptr; }
     hipLaunchKernelGGL(am_k_cblk_walk, dim3(1), dim3(1024), lds, s, pos, scratch, reinterpret_cast<const uint16_t *>(scratch + L.off_head), M, L.nblk,
                        L.headw, cur0, scratch + L.off_entry, scalars, Mp, es);
     am_emit_args ea;
@@ -1991,7 +1994,8 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 __global__ void __launch_bounds__(AM_WAVE)
 am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
                  uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags,
-                 uint64_t *__restrict__ exit_out, am_shard_exit *__restrict__ header, const uint64_t *__restrict__ carry)
+                 uint64_t *__restrict__ exit_out, am_shard_exit *__restrict__ header, const uint64_t *__restrict__ carry,
+                 const uint64_t *__restrict__ cur_in)
 {
     if (blockIdx.x != 0) return;
     if (header) {
@@ -2000,7 +2004,7 @@ am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_
     }
     uint32_t bad = 0;
     uint64_t leave = 0;
-    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad, &leave);
+    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad, &leave, cur_in);
     if (threadIdx.x != 0) return;
     uint64_t rel = cur > base_abs ? cur - base_abs : 0;
     if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
@@ -2010,16 +2014,16 @@ am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_
 }
 
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
-                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s)
+                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s, const uint64_t *cur_in)
 {
     hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags, exit_out,
-                       (am_shard_exit *)nullptr, (const uint64_t *)nullptr);
+                       (am_shard_exit *)nullptr, (const uint64_t *)nullptr, cur_in);
     return hipGetLastError();
 }
 hipError_t am_launch_shard_header(am_shard_exit *header, const uint64_t *carry, hipStream_t s)
 {
     hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, (const am_shard_exit *)nullptr, 0u, 0u, 0u, (uint64_t)0,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, header, carry);
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, header, carry, (const uint64_t *)nullptr);
     return hipGetLastError();
 }
 
@@ -2573,15 +2577,18 @@ hipError_t am_launch_extract_slice_iq(const float *iq, long long src_abs0, long 
 // a system-scope fence per workgroup the extraction kernel went 55 -> 111 us, with a device-scope one 55 -> 159 us -- on this
 // part either one writes back an XCD's L2, 1 300 times over.  The launch of its own, 4.2 us + the gap, stays.)
 // (hipStreamWriteValue32 in its place -- a queue packet instead of a dispatch -- measured the same step time, 64 and 2 Msps.)
-__global__ void am_k_ticket(uint32_t *host_word, uint32_t seq, const uint32_t *count_src, uint32_t *count_dst)
+__global__ void am_k_ticket(uint32_t *host_word, uint32_t seq, const uint32_t *count_src, uint32_t *count_dst,
+                            const unsigned long long *word_src, unsigned long long *word_dst)
 {
     if (count_src) *count_dst = *count_src;
+    if (word_src) *word_dst = *word_src;                      // (am_spipe: where the scan left the chunk, for the host's books)
     __hip_atomic_store(host_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 hipError_t am_launch_ticket(uint32_t *host_word, uint32_t seq, hipStream_t s, const uint32_t *count_src,
-                            uint32_t *count_dst)
+                            uint32_t *count_dst, const uint64_t *word_src, uint64_t *word_dst)
 {
-    hipLaunchKernelGGL(am_k_ticket, dim3(1), dim3(1), 0, s, host_word, seq, count_src, count_dst);
+    hipLaunchKernelGGL(am_k_ticket, dim3(1), dim3(1), 0, s, host_word, seq, count_src, count_dst,
+                       reinterpret_cast<const unsigned long long *>(word_src), reinterpret_cast<unsigned long long *>(word_dst));
     return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AM_ABI_VERSION 4
+#define AM_ABI_VERSION 5
 
 /* Export marker.  The library is built with -fvisibility=hidden: only what carries AM_API leaves the
  * shared object (the role AIR_MODES_API plays in the reference: include/gr_air_modes/api.h:27-31,
@@ -161,6 +161,38 @@ AM_API int am_pipe_submit(am_pipe *pipe, const float *iq, uint64_t n_complex, ui
 AM_API int am_pipe_collect(am_pipe *pipe, am_packet *out, uint64_t cap, uint64_t *n_out);
 AM_API const char *am_pipe_last_error(const am_pipe *pipe);
 AM_API float am_pipe_last_kernel_ms(const am_pipe *pipe);   /* dominant-kernel time of the batch collected last */
+
+/* ---- ONE continuing stream with several of its chunks in flight ---------------------------------------------------
+ * The reference's preamble block is a streaming block: general_work() resumes where the last call stopped (lib/preamble_impl.cc:
+ * 139-246; consume_each at :213,237,244).  am_process_iq is that, one chunk at a time.  am_spipe_* keeps `depth` consecutive
+ * chunks of ONE stream in flight on one GPU: a chunk's scan (everything that does not depend on where the greedy scan enters the
+ * chunk) is enqueued when it is submitted, on a context and stream of its own; the position at which the scan enters it travels on
+ * the device, from the word the chunk before it leaves it in -- nothing between two chunks waits for the host.  The packets of all
+ * chunks, concatenated in submission order, are those of one am_process_iq over the whole stream (item counts and time stamps keep
+ * counting).
+ *   am_spipe_front   samples of the stream that must lie IN FRONT of every chunk but the first, in the same allocation (the tail of
+ *                    the chunk before it: reference-level history + the positions it takes over).  Where the stream is not
+ *                    contiguous in memory the library copies them there from the chunk submitted before (device to device, on the
+ *                    chunk's stream): a chunk buffer needs that much writable room in front of it.
+ *   am_spipe_submit  iq: DEVICE pointer to the chunk's n_complex samples (n_complex > front); they, and the chunk submitted before
+ *                    it, must stay valid until the chunk has been collected.  AM_F_FLUSH: the stream's last chunk (end-of-stream
+ *                    rule); the next stream starts once every chunk has been collected.  AM_ECAPACITY: `depth` chunks in flight.
+ *   am_spipe_collect the packets of the oldest chunk in flight.
+ *   am_spipe_redone  chunks that had to take the synchronous path (exit table larger than its message, more candidates than the
+ *                    capacity the scan was launched for): results are the same, the chunks behind such a chunk are scanned twice.
+ *   am_spipe_set_rx_time  as am_set_rx_time (stream-absolute offsets), with no chunk in flight. */
+typedef struct am_spipe am_spipe;
+AM_API am_spipe *am_spipe_create(int device, double rate, float threshold_db, int use_pmf, int use_dcblock, int depth, int *err);
+AM_API void am_spipe_destroy(am_spipe *pipe);
+AM_API int am_spipe_depth(const am_spipe *pipe);
+AM_API int am_spipe_in_flight(const am_spipe *pipe);
+AM_API int am_spipe_front(const am_spipe *pipe, uint64_t *front);
+AM_API int am_spipe_set_rx_time(am_spipe *pipe, uint64_t offset, uint64_t secs, double frac);
+AM_API int am_spipe_submit(am_spipe *pipe, const float *iq, uint64_t n_complex, uint32_t flags);
+AM_API int am_spipe_collect(am_spipe *pipe, am_packet *out, uint64_t cap, uint64_t *n_out);
+AM_API uint64_t am_spipe_redone(const am_spipe *pipe);
+AM_API const char *am_spipe_last_error(const am_spipe *pipe);
+AM_API float am_spipe_last_kernel_ms(const am_spipe *pipe);   /* dominant-kernel time of the chunk collected last */
 
 /* Run the context's device work on the caller's HIP stream (hipStream_t passed as a pointer; NULL: back to the
  * context's own stream).  For callers whose input is produced on a stream of their own -- e.g. halo samples that

@@ -33,7 +33,7 @@ def test_library_builds_loads_and_exports_all_symbols():
     for s in syms:
         assert hasattr(lib, s), "libairmodes_hip.so does not export %s" % s
     lib.am_abi_version.restype = ctypes.c_uint32
-    assert lib.am_abi_version() == 4
+    assert lib.am_abi_version() == 5
     assert lib.am_is_emulated() == 0
     # -fvisibility=hidden + AM_API: the shared object defines the header's entry points and NOTHING else (the reference
     # hides what is not AIR_MODES_API: CMakeLists.txt:65, include/gr_air_modes/api.h:27-31)

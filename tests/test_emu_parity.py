@@ -421,3 +421,37 @@ def test_k_streams_usage_errors(emu_lib):
 def test_streamed_preamble_block_drops_spent_rx_time_tags(emu_lib):
     """5 000 "rx_time" tags through the streamed preamble block (the table holds 4 096 at once)."""
     assert pc.check_streamed_preamble_many_rx_time_tags(emu_lib) > 100
+
+
+@pytest.mark.parametrize("rate,n,lam,depth,contiguous,dc", [(64e6, 1500000, 12000.0, 3, True, False), (64e6, 900000, 20000.0, 2, False, False),
+                                                           (20e6, 700000, 6000.0, 4, False, False), (2e6, 200000, 3000.0, 3, True, False),
+                                                           (4e6, 300000, 3000.0, 1, False, True), (5e6, 300000, 2500.0, 3, True, False)])
+def test_one_stream_with_chunks_in_flight(emu_lib, rate, n, lam, depth, contiguous, dc):
+    """am_spipe: consecutive chunks of ONE stream in flight, the scan position handed from chunk to chunk on the
+    device; random chunk sizes, contiguous and scattered buffers, two rx_time tags, a DC-blocked stream, a rate that is not a
+    multiple of 2 MHz."""
+    rx = [(0, 1000, 0.25), (n // 2 + 12345, 2000, 0.5)]
+    pk, _ = pc.check_stream_pipe(emu_lib, rate, n, lam, seed=int(rate / 1e6) + depth, depth=depth, contiguous=contiguous, dcblock=dc,
+                                 rx_time=rx)
+    assert len(pk) > 10
+
+
+def test_stream_pipe_redoes_chunks_whose_scan_outgrew_its_capacity(emu_lib, monkeypatch):
+    """A chunk whose scan met more candidates than the capacity it was launched for is flagged in its message header: the pipe
+    drains the chunks behind it, redoes it on the synchronous path and submits the others again -- same packets."""
+    monkeypatch.setenv("AIRMODES_SPEC_FLOOR", "0")
+    rate, n = 64e6, 2400000
+    # a quiet first part, dense traffic behind it: the capacity extrapolated from the quiet chunks does not suffice
+    quiet, _ = synth.synth_capture(rate, n // 2, 300.0, 71)
+    busy, _ = synth.synth_capture(rate, n - n // 2, 30000.0, 72)
+    import oracle
+    iq = np.concatenate([quiet, busy])
+    want = oracle.demod(iq, rate, 7.0, True)
+    pipe = _capi.StreamPipe(rate, 7.0, True, depth=3, lib=emu_lib)
+    base = np.ascontiguousarray(iq.view(np.float32))
+    m = n // 8
+    chunks = [(base.ctypes.data + 8 * k * m, m) for k in range(8)]
+    got = np.concatenate(pipe.run(chunks))
+    assert np.array_equal(got, want)
+    assert pipe.redone() >= 1, "no chunk took the synchronous path: the test did not reach it"
+    pipe.close()

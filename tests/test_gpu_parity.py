@@ -516,3 +516,18 @@ def test_slicer_edge_vectors_on_device(lib):
 def test_framer_edge_formats_through_the_production_path_on_device(lib, rate, n, lam):
     """The same formats on the air, through the production extraction + slicing kernels (AM_F_KEEP_TAGS), stage by stage."""
     assert pc.check_framer_edge_formats(lib, rate, n, lam, 617, want_fe=3) > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rate,n,lam,depth,contiguous", [(64e6, 9000000, 20000.0, 4, False), (64e6, 6000000, 2000.0, 3, True),
+                                                         (20e6, 3000000, 6000.0, 2, False), (2e6, 600000, 3000.0, 3, True),
+                                                         (5e6, 900000, 2500.0, 3, False)])
+def test_one_stream_with_chunks_in_flight_on_device(hip_lib, rate, n, lam, depth, contiguous):
+    """am_spipe on the device: consecutive chunks of ONE stream in flight on streams of their own, the scan position
+    handed on through a device word behind an event; random chunk sizes; == the oracle over the whole stream, twice (a second stream
+    through the same pipe)."""
+    import torch
+    rx = [(0, 1000, 0.25), (n // 2 + 12345, 2000, 0.5)]
+    pk, _ = pc.check_stream_pipe(hip_lib, rate, n, lam, seed=int(rate / 1e6) + depth, depth=depth, contiguous=contiguous, rx_time=rx,
+                                 device=torch.device("cuda", 0))
+    assert len(pk) > 10
