@@ -91,11 +91,12 @@ def check_production_stages(lib, rate, n, lam, seed, thr=7.0, pmf=True, want_fe=
     obb, oavg = oracle.frontend(iq, spc, pmf)
     ob, ot = oracle.preamble_scan(obb, oavg, spc, thr, rate)
     assert len(tags) == len(ot), "tag count differs: %d vs %d" % (len(tags), len(ot))
-    assert np.array_equal(tags, ot), "tags differ"
+    # (records compared as bytes: a NaN reference level -- non-finite samples in the fuzz -- is equal to itself here)
+    assert np.ascontiguousarray(tags).tobytes() == np.ascontiguousarray(ot).tobytes(), "tags differ"
     assert np.array_equal(u32(bursts), u32(ob)), "bursts differ"
     want, ntags = oracle.demod(iq, rate, thr, pmf, return_tags=True)
     assert ntags == len(tags)
-    assert np.array_equal(whole, want), "packets differ"
+    assert np.ascontiguousarray(whole).tobytes() == np.ascontiguousarray(want).tobytes(), "packets differ"
     if with_ref and oracle.have_ref():
         rb, rt, _, keep = oracle.ref_preamble_slicer(obb, oavg, spc, thr, rate)
         rb, rt = rb[keep], rt[keep]
