@@ -170,6 +170,7 @@ struct am_ctx {
     DevBuf shard_exit;                  // device word: where the scan left this context's chunk in the last resolved step (0: none)
     const am_entry_src *entry_src = nullptr; // set around chain_finish: the scan's start position is composed on the device (time shards)
     const uint32_t *flag_src = nullptr; // ... and this device word is handed to the host with the completion ticket (pin_scalars[4])
+    hipEvent_t walk_event = nullptr;    // ... recorded behind the block walk (am_spipe: the next chunk's resolve step waits for this, not for the slicing)
     const uint64_t *word_src = nullptr; // ... and this 64-bit one (pin_scalars[12..13]: where the scan left the chunk -- am_spipe's books)
 
     // pinned host memory the tail kernels write into directly
@@ -775,7 +776,7 @@ int chain_finish(am_ctx *c, const float *bb, uint32_t cur0, uint32_t emit_max, u
                                     own_hi, (uint4 *)c->emit_idx.p, n_ptr, (unsigned long long *)c->lb_mark.p,
                                     next_epoch(c), (uint32_t *)c->scalars.p + 11, &c->tk_base[1],
                                     (uint32_t *)c->scalars.p, emit_max == 0xFFFFFFFFu ? 1 : 0, c->stream, Mp,
-                                    c->entry_src, (const float *)c->inavg.p));
+                                    c->entry_src, (const float *)c->inavg.p, c->walk_event));
     const bool keep_dev = keep_bursts || c->keep_tags;       // the bursts and their tags leave the kernel
     if (keep_dev) ENSURE(c, c->bursts, (size_t)n_max * AM_BURST * sizeof(float));
     if (c->pin_cap < n_max) {
@@ -2226,6 +2227,7 @@ static int spipe_enqueue(am_spipe *p, size_t k)
         c->entry_src = &es;
         c->flag_src = flag_dev;
         c->word_src = (const uint64_t *)c->shard_exit.p;
+        c->walk_event = sl.done;
         c->resolving_shard = true;
         c->defer = true;
         rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
@@ -2234,8 +2236,10 @@ static int spipe_enqueue(am_spipe *p, size_t k)
         c->entry_src = nullptr;
         c->flag_src = nullptr;
         c->word_src = nullptr;
+        c->walk_event = nullptr;
         if (rc != AM_DEFERRED) return rc == AM_OK ? fail(c, AM_EHIP, "internal: the resolve step was not deferred") : rc;
         P.active = true;                                        // (chain_finish filled in scanned / seq / M / Mp / n_max)
+        return AM_OK;                                           // (sl.done was recorded behind the block walk)
     }
     HIPCHK(c, hipEventRecord(sl.done, c->stream));
     return AM_OK;

@@ -212,7 +212,8 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint4 *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch, uint32_t *ticket, uint32_t *ticket_base,
                                  uint32_t *scalars, int want_resume,
-                                 hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src, const float *inavg);
+                                 hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src, const float *inavg,
+                                 hipEvent_t after_walk = nullptr);
 /* (emit_idx: one 16-byte record per hit -- candidate index, first-stage position, refined position, reference level -- so that
  * the extraction kernels fetch a hit with one load) */
 /* lead_end (array coordinate): the table is only needed up to the first candidate at or past it */

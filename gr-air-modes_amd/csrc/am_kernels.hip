@@ -1942,7 +1942,7 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
                                  uint32_t emit_max, uint32_t own_lo, uint32_t own_hi, uint4 *emit_idx, uint32_t *n_out,
                                  unsigned long long *slots, uint32_t epoch, uint32_t *ticket, uint32_t *ticket_base,
                                  uint32_t *scalars, int want_resume, hipStream_t s, const uint32_t *Mp, const am_entry_src *entry_src,
-                                 const float *inavg)
+                                 const float *inavg, hipEvent_t after_walk)
 {
     if (M == 0) return hipSuccess;
     const am_chain_layout L = am_chain_layout_of(M);
@@ -1962,6 +1962,8 @@ hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uin
     ea.want_resume = want_resume;
     ea.ticket = ticket; ea.ticket_base = *ticket_base;
     if (hipError_t rc = hipGetLastError(); rc != hipSuccess) return rc;   // (the walk's launch)
+    // (am_spipe: the walk has written where the scan leaves this chunk -- all the next chunk's resolve step waits for)
+    if (after_walk) if (hipError_t rc = hipEventRecord(after_walk, s); rc != hipSuccess) return rc;
     hipLaunchKernelGGL(am_k_cblk_mark, dim3(L.nblk), dim3(AM_CB_THREADS), 0, s, jump0, scratch + L.off_entry, M, ea,
                        Mp);
     const hipError_t rc = hipGetLastError();

@@ -2,8 +2,9 @@
 real library on a real MI355X -- the DPP rotations, EXEC-narrowing compares, packed fp32, v_permlane32_swap, nt loads and wave
 priorities of the streaming kernels exist only there, and fixed seeds are not a fuzz.
 
-Every run draws NEW cases (hypothesis, not derandomised; a failure prints the falsifying example, which `@example` or
-`--hypothesis-seed` reproduces) and is boxed to ~60 s: once the box is spent the remaining examples return at once.
+Every run draws NEW cases (a seed from the operating system, printed with the case number and every draw when a case fails;
+AIRMODES_FUZZ_SEED=<seed> repeats the run) for ~60 s.  (A hypothesis @given was the first form: its engine calls a test that
+stops drawing once a time box is spent "flaky data generation" -- a plain seeded loop keeps the box honest.)
 
 Per case: a rate from 2 .. 64 Msps (whole and fractional samples per chip), a seeded capture with optional NaN / inf / denormal /
 huge stretches, threshold and filter settings, then
@@ -14,11 +15,11 @@ huge stretches, threshold and filter settings, then
   * every first-stage candidate record + tags + bursts of the production scan == the oracle, and the reference's own C++ where
     oracle/_ref travelled (check_production_stages, with_ref), whole-chip rates.
 """
+import os
 import time
 
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
 
 import oracle
 import parity_common as pc
@@ -29,7 +30,6 @@ pytestmark = pytest.mark.gpu
 
 RATES = (2e6, 4e6, 5e6, 6.25e6, 8e6, 10e6, 16e6, 20e6, 32e6, 40e6, 64e6)
 BOX_SECONDS = 60.0
-_t0 = [None]
 _ran = [0]
 
 
@@ -37,29 +37,57 @@ def same(a, b):
     return len(a) == len(b) and np.ascontiguousarray(a).tobytes() == np.ascontiguousarray(b).tobytes()
 
 
-@settings(max_examples=100000, deadline=None, derandomize=False, database=None,
-          suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large, HealthCheck.filter_too_much,
-                                 HealthCheck.function_scoped_fixture])
-@given(st.data())
-def test_random_cases_on_the_device(hip_lib, data):
-    if _t0[0] is None:
-        _t0[0] = time.monotonic()
-    if time.monotonic() - _t0[0] > BOX_SECONDS:
-        return                                                 # the box is spent: the remaining examples cost nothing
+class _Draws(object):
+    """numpy draws with a log (what hypothesis' data.draw(..., label=...) gave the first form of this test)"""
+
+    def __init__(self, rng):
+        self.rng, self.log = rng, []
+
+    def note(self, label, v):
+        self.log.append((label, v))
+        return v
+
+    def choice(self, seq, label):
+        return self.note(label, seq[int(self.rng.integers(0, len(seq)))])
+
+    def integer(self, lo, hi, label):
+        return self.note(label, int(self.rng.integers(lo, hi + 1)))
+
+    def boolean(self, label):
+        return self.note(label, bool(self.rng.integers(0, 2)))
+
+    def integers(self, lo, hi, count, label):
+        return self.note(label, [int(x) for x in self.rng.integers(lo, hi + 1, count)])
+
+
+def test_random_cases_on_the_device(hip_lib):
+    seed0 = int(os.environ.get("AIRMODES_FUZZ_SEED", "0")) or int.from_bytes(os.urandom(8), "little")
+    t0 = time.monotonic()
+    case = 0
+    while time.monotonic() - t0 < BOX_SECONDS:
+        d = _Draws(np.random.default_rng([seed0, case]))
+        try:
+            _one_case(hip_lib, d)
+        except Exception as ex:
+            raise AssertionError("device fuzz: case %d of AIRMODES_FUZZ_SEED=%d failed: %s\ndraws: %s" % (case, seed0, ex, d.log)) from ex
+        case += 1
+        _ran[0] += 1
+
+
+def _one_case(hip_lib, d):
     lib = hip_lib
-    draw = data.draw
-    rate = draw(st.sampled_from(RATES), label="rate")
+    rate = d.choice(RATES, "rate")
     spc = int(rate / 2e6)
     whole = float(rate) == 2e6 * spc
-    n = draw(st.integers(20000 * spc, 45000 * spc), label="n")
-    lam = draw(st.sampled_from((300.0, 3000.0, 20000.0, 60000.0)), label="lambda")
-    thr = draw(st.sampled_from((2.0, 5.0, 7.0, 10.0)), label="threshold")
-    pmf = draw(st.booleans(), label="pmf") or draw(st.booleans(), label="pmf2")
-    seed = draw(st.integers(1, (1 << 30) - 1), label="seed")
+    n = d.integer(20000 * spc, 45000 * spc, "n")
+    lam = d.choice((300.0, 3000.0, 20000.0, 60000.0), "lambda")
+    thr = d.choice((2.0, 5.0, 7.0, 10.0), "threshold")
+    pmf = d.integer(0, 3, "pmf") != 0
+    seed = d.integer(1, (1 << 30) - 1, "seed")
     iq, _ = synth.synth_capture(rate, n, lam, seed)
     iq = np.array(iq)
-    if draw(st.integers(0, 2), label="nonfinite") == 0:
-        k = draw(st.integers(0, n - 700), label="where")
+    if d.integer(0, 2, "nonfinite") == 0:
+        k = d.integer(0, n - 700, "where")
         iq[k:k + 200] *= np.complex64(1e-22)                   # denormals
         iq[k + 300] = np.complex64(complex(np.nan, 1.0))
         iq[k + 400] = np.complex64(complex(np.inf, 0.0))
@@ -68,9 +96,9 @@ def test_random_cases_on_the_device(hip_lib, data):
         want = oracle.demod(iq, rate, thr, pmf)
 
         # 1. the stream in random pieces (1-sample pieces and unaligned cuts among them)
-        ncut = draw(st.integers(0, 5), label="ncut")
-        cuts = sorted(set(draw(st.lists(st.integers(1, n - 1), min_size=ncut, max_size=ncut), label="cuts")))
-        if cuts and draw(st.booleans(), label="one_sample_piece") and cuts[0] + 1 < n:
+        ncut = d.integer(0, 5, "ncut")
+        cuts = sorted(set(d.integers(1, n - 1, ncut, "cuts")))
+        if cuts and d.boolean("one_sample_piece") and cuts[0] + 1 < n:
             cuts = sorted(set(cuts + [cuts[0] + 1]))
         ctx = _capi.Context(rate, thr, pmf, lib=lib)
         parts = [ctx.process_iq(iq[a:b], flush=(b == n)) for a, b in zip([0] + cuts, cuts + [n])]
@@ -83,11 +111,11 @@ def test_random_cases_on_the_device(hip_lib, data):
         assert np.array_equal(pc.u32(bb), pc.u32(obb)) and np.array_equal(pc.u32(avg), pc.u32(oavg)), "bb / reference level differ"
 
         # 3. rx_time tags arriving with their chunks
-        ntag = draw(st.integers(0, 3), label="ntag")
+        ntag = d.integer(0, 3, "ntag")
         if ntag:
-            offs = sorted(draw(st.lists(st.integers(0, n - 1), min_size=ntag, max_size=ntag), label="tag_offsets"))
-            rx = [(int(o), int(draw(st.integers(0, 2_000_000_000), label="secs")),
-                   float(draw(st.sampled_from((0.0, 0.125, 0.5, 0.9999995, 0.75)), label="frac"))) for o in offs]
+            offs = sorted(d.integers(0, n - 1, ntag, "tag_offsets"))
+            rx = [(int(o), d.integer(0, 2_000_000_000, "secs"),
+                   float(d.choice((0.0, 0.125, 0.5, 0.9999995, 0.75), "frac"))) for o in offs]
             want_t = oracle.demod(iq, rate, thr, pmf, rx_time=rx)
             ctx.reset()
             edges = [0] + cuts + [n]
@@ -101,21 +129,20 @@ def test_random_cases_on_the_device(hip_lib, data):
         ctx.reset()
 
         # 4. K independent streams in one scan
-        J = draw(st.integers(2, 5), label="streams")
-        jc = sorted(draw(st.lists(st.integers(0, n), min_size=J - 1, max_size=J - 1), label="stream_cuts"))
+        J = d.integer(2, 5, "streams")
+        jc = sorted(d.integers(0, n, J - 1, "stream_cuts"))
         pieces = [iq[a:b] for a, b in zip([0] + jc, jc + [n])]
-        if draw(st.booleans(), label="stub"):
-            pieces.insert(draw(st.integers(0, len(pieces)), label="stub_at"), iq[:draw(st.integers(0, 200), label="stub_len")])
+        if d.boolean("stub"):
+            pieces.insert(d.integer(0, len(pieces), "stub_at"), iq[:d.integer(0, 200, "stub_len")])
         buf, lens = ctx.multi_pack(pieces)
-        got_k = ctx.process_multi(buf, lens, zero_gaps=draw(st.booleans(), label="zero_gaps"))
+        got_k = ctx.process_multi(buf, lens, zero_gaps=d.boolean("zero_gaps"))
         for j, (g, x) in enumerate(zip(got_k, pieces)):
             assert same(g, oracle.demod(x, rate, thr, pmf)), "stream %d of %d in one scan differs" % (j, len(pieces))
         ctx.close()
 
         # 5. every candidate record, tags and bursts of the production scan; the reference's own C++ where it travelled
-        if whole and draw(st.booleans(), label="stage_level"):
+        if whole and d.boolean("stage_level"):
             pc.check_production_stages(lib, rate, n, lam, seed, thr=thr, pmf=pmf, iq=iq, with_ref=True)
-    _ran[0] += 1
 
 
 def test_the_box_was_used(hip_lib):
