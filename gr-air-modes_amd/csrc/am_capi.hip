@@ -2094,6 +2094,7 @@ int am_shard_resolve_async(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t wo
     am_entry_src es;
     es.msgs = msgs_dev; es.world = world; es.rank = rank; es.cap = (uint32_t)msg_cap; es.base_abs = c->shard_base; es.flags = flag_dev;
     es.exit_out = (uint64_t *)c->shard_exit.p;
+    es.cur_in = nullptr;                                        // (the scan position comes from the last rank's header)
     c->entry_src = &es;
     c->flag_src = flag_dev;
     c->resolving_shard = true;

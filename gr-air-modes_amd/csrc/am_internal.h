@@ -199,12 +199,12 @@ hipError_t am_launch_chain_prepare(const uint32_t *pos, const uint32_t *tgt, uin
                                    int have_succ = 0);   /* have_succ: jump0[] was written by am_k_cand */
 /* where the greedy scan of a time shard starts: composed on the device from everybody's exit tables (am_k_cblk_walk) */
 struct am_entry_src {
-    const am_shard_exit *msgs;      // null: the start position comes from the host
-    uint32_t world, rank, cap;
-    uint64_t base_abs;              // absolute index of the chunk's array coordinate 0
-    uint32_t *flags;                // flags[0] = 1: repeat the step
-    uint64_t *exit_out;             // where the scan leaves this chunk (absolute): the next step's message carries it
-    const uint64_t *cur_in;         // non-null: where the scan left the chunk BEFORE this one, read when the entry is composed (am_spipe)
+    const am_shard_exit *msgs = nullptr;      // null: the start position comes from the host
+    uint32_t world = 0, rank = 0, cap = 0;
+    uint64_t base_abs = 0;          // absolute index of the chunk's array coordinate 0
+    uint32_t *flags = nullptr;      // flags[0] = 1: repeat the step
+    uint64_t *exit_out = nullptr;   // where the scan leaves this chunk (absolute): the next step's message carries it
+    const uint64_t *cur_in = nullptr;   // non-null: where the scan left the chunk BEFORE this one, read when the entry is composed (am_spipe)
 };
 
 hipError_t am_launch_chain_visit(const uint32_t *pos, const uint32_t *jump0, uint32_t M, uint32_t cur0,
