@@ -246,6 +246,53 @@ def main():
         if mode == "single" and K == 1 and not args.no_extra and workload != "64msps" and args.steps >= 3:
             # 2 / 20 Msps: one second of ONE receiver is a small job for the chip (the scan's launches are most of the step); eight
             # receivers' seconds in one scan (am_process_multi: K whole streams in one buffer, zeros between them)
+            # ONE receiver as configs[1] / [4] have it (VERDICT r5 #6a): (a) multi-second scans -- eight seconds of the one stream per
+            # am_process_iq call, the same launches over eight times the samples; (b) the stream in 1 s chunks with four in flight
+            # (am_spipe).  The stream: this run's second of signal eight times over (a valid stream; bursts across the seams included).
+            LONG = 8
+            whole8 = np.tile(host_batches[0], LONG)
+            d8 = torch.from_numpy(whole8.view(np.float32)).to(dev)
+            sync()
+            for _ in range(2):
+                pk8 = ctx.process_iq_device(d8.data_ptr(), LONG * n, flush=True)
+            ks8 = max(5, args.steps // 2)
+            sync()
+            t8 = time.perf_counter()
+            fe8 = []
+            for _ in range(ks8):
+                pk8 = ctx.process_iq_device(d8.data_ptr(), LONG * n, flush=True)
+                fe8.append(ctx.last_dom_ms())
+            sync()
+            dt8 = (time.perf_counter() - t8) / ks8
+            fe_8 = float(np.mean(fe8))
+            one = {"what": "ONE stream, %g s of signal (%d samples) per scan" % (LONG * secs, LONG * n), "value": LONG * n / dt8, "unit": "samples/s",
+                   "ms_per_scan": dt8 * 1e3, "kernel_ms": fe_8,
+                   "roofline_frac": (8.0 * LONG * n / (fe_8 * 1e-3) / 1e9 / HBM_PEAK_GBS) if fe_8 > 0 else 0.0,
+                   "path_frac_of_hbm_peak": 8.0 * LONG * n / dt8 / 1e9 / HBM_PEAK_GBS, "packets_per_scan": int(len(pk8))}
+            sp1 = _capi.StreamPipe(rate, 7.0, True, device=(0 if args.emu else local), depth=4, lib=lib) if lib is not None \
+                else _capi.StreamPipe(rate, 7.0, True, device=local, depth=4)
+            ch8 = [(d8.data_ptr() + 8 * k * n, n) for k in range(LONG)]       # (contiguous in memory: no tail copies)
+            sp1.run(ch8)
+            sync()
+            t9 = time.perf_counter()
+            got9 = None
+            for _ in range(ks8):
+                got9 = sp1.run(ch8)
+            sync()
+            dt9 = (time.perf_counter() - t9) / ks8
+            all9 = np.concatenate(got9)
+            one["chunks_in_flight"] = {"what": "the same stream in %d chunks of %g s, four in flight (am_spipe)" % (LONG, secs),
+                                       "value": LONG * n / dt9, "unit": "samples/s", "ms_per_chunk": dt9 / LONG * 1e3,
+                                       "path_frac_of_hbm_peak": 8.0 * LONG * n / dt9 / 1e9 / HBM_PEAK_GBS,
+                                       "same_packets_as_the_long_scan": bool(all9.tobytes() == pk8.tobytes()),
+                                       "chunks_redone_synchronously": sp1.redone()}
+            sp1.close()
+            if not args.no_parity:
+                import oracle
+                one["parity_vs_oracle_whole_stream"] = bool(np.array_equal(pk8, oracle.demod(whole8, rate, 7.0, True)))
+            extra["one_stream_long_scans"] = one
+            del d8, whole8
+            run_steps(2, [ctx], 1, d_batches)
             KX = 8
             kh, kd, kl, kt = k_streams_setup(KX, 1)
             for _ in range(3):
