@@ -2285,7 +2285,9 @@ am_spipe *am_spipe_create(int device, double rate, float threshold_db, int use_p
         am_spipe_slot &sl = p->slot[(size_t)k];
         sl.c = am_create(device, rate, threshold_db, use_pmf, use_dcblock, err);
         if (!sl.c) { am_spipe_destroy(p); return nullptr; }
-        if (depth > 1) sl.c->fe_wgs_per_cu = 5;                 // (as am_pipe: room on every CU for the other chunks' small kernels)
+        // (am_pipe left one of a CU's six persistent front-end slots free for the other batches' small kernels until round 5; with
+        // am_k_refine_seg behind the front end -- 36 KB of LDS per workgroup -- a fifth of the LDS buys nothing: six, measured,
+        // profiles/r6_tail/ab_5_pipes_fe3_wgs_per_cu.txt)
         if (hipMalloc((void **)&sl.msg, ((size_t)AM_SHARD_MSG_HEADER + p->msg_cap) * sizeof(am_shard_exit)) != hipSuccess ||
             hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) {
             if (err) *err = AM_ENOMEM;
@@ -2461,7 +2463,7 @@ am_pipe *am_pipe_create(int device, double rate, float threshold_db, int use_pmf
         if (!c) { am_pipe_destroy(p); return nullptr; }
         // batches in flight: the streaming kernel of one batch leaves room on every CU (LDS, registers) for the small kernels
         // of the others -- five persistent workgroups per CU instead of six (measured: 285-294 -> 297-302 GS/s at depth 4)
-        if (depth > 1) c->fe_wgs_per_cu = 5;
+        // (round 6: all six persistent front-end workgroups per CU here as well -- see am_spipe_create)
 #if defined(AM_TEST_KNOBS) && !defined(AM_HIP_EMULATION)
         // measurement only (test builds): every context of the pipe on its own share of the CUs (hipExtStreamCreateWithCUMask),
         // so that batches overlap on the CUs instead of in the gaps -- VERDICT r4 #3; result in profiles/r5_fe64
