@@ -871,6 +871,10 @@ hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uin
     am_rows_args ra;
     memset(&ra, 0, sizeof(ra));
     if (rows && rows->iq) {
+#if defined(AM_TEST_KNOBS)
+        // TEST BUILDS ONLY since round 6 (AIRMODES_FUSED_REFINE=0): round 5's arrangement -- this kernel forms the bb rows around the
+        // candidates from the samples and writes them, am_k_refine_late reads them back.  The product library runs am_k_refine_seg
+        // (am_refine_seg.hip: the rows never leave LDS) and does not instantiate these two.
         // (the rows are formed for am_k_fe3's bitmap: a word = one 32-sample chip, lag 288)
         if (wbits != 32 || lag != 288 || !rows->bb_sparse) return hipErrorInvalidValue;
         ra = *rows;
@@ -881,6 +885,9 @@ hipError_t am_launch_gather_wg(const uint32_t *bits, const uint32_t *wg_cnt, uin
             hipLaunchKernelGGL(am_k_gather_wg<2>, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag,
                                wbits, pos, total_out, ra);
         return hipGetLastError();
+#else
+        return hipErrorInvalidValue;                          // (the product path forms the rows in am_k_refine_seg)
+#endif
     }
     hipLaunchKernelGGL(am_k_gather_wg<0>, dim3(nwg), dim3(256), 0, s, bits, wg_cnt, nwg, words_per_wg, nwords, Mcap, lag, wbits, pos,
                        total_out, ra);
