@@ -21,8 +21,8 @@ fi
 AIRMODES_HIP_LIB=$PWD/tests/gpu_variants/libairmodes_hip_knobs.so AIRMODES_FE=2 timeout 120 python bench.py --no-cpu-baseline --no-extra > $OUT/bench_tile_kernel.json 2>/dev/null
 timeout 120 python bench.py --force-sharded --no-cpu-baseline --no-extra > $OUT/bench_force_sharded.json 2>/dev/null
 timeout 200 python bench.py --force-sharded --backend nccl --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1.json
-timeout 120 python bench.py --workload 2msps --no-cpu-baseline --no-extra > $OUT/bench_2msps.json 2>/dev/null
-timeout 120 python bench.py --workload 20msps --no-cpu-baseline --no-extra > $OUT/bench_20msps.json 2>/dev/null
+timeout 400 python bench.py --workload 2msps --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_2msps.json
+timeout 400 python bench.py --workload 20msps --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_20msps.json
 timeout 200 bash tools/gpu_pmc.sh > $OUT/sq_counters.txt 2>&1
 KFILTER=refine_seg timeout 200 bash tools/gpu_pmc.sh > $OUT/sq_counters_refine_seg.txt 2>&1
 for w in 20msps 2msps; do BENCH_ARGS="--workload $w" STEPS=10 timeout 200 bash tools/gpu_kstats.sh > $OUT/kernel_stats_$w.txt 2>&1; done
