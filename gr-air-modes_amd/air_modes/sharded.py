@@ -54,7 +54,7 @@ class ShardedReceiver(object):
     write each step's samples there, no copy inside step()); step() runs one pass and returns this rank's packets."""
 
     def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None, small_table=512, host_free=True,
-                 force_collectives=False):
+                 force_collectives=False, share_stream=True):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -81,7 +81,8 @@ class ShardedReceiver(object):
         # host time spent inside the torch.distributed calls of step(), summed over steps (microseconds; bench.py reports
         # them per step beside the no-collective floor of a one-rank receiver)
         self.host_us = {"tail_exchange": 0.0, "all_gather": 0.0, "steps": 0}
-        self.host_us_steps = {"tail_exchange": [], "all_gather": []}     # ... and per step (the first call of a backend sets its communicator up)
+        self.host_us_steps = {"tail_exchange": [], "all_gather": []}
+        self._wrap_posted = False                         # the ring-closing transfer of the next step is already under way     # ... and per step (the first call of a backend sets its communicator up)
         self._alloc(device if device is not None else "cpu")
         # the device-side exchange hands device pointers to kernels: only where the buffers live on the GPU (or where
         # "device memory" is host memory: the CPU emulation the tests run on)
@@ -96,6 +97,14 @@ class ShardedReceiver(object):
         else:
             ctx.shard_keep_tail(0, 0, 0)
         ctx._keep_owner = id(self)                        # (a context serves one receiver at a time: the newest)
+        # share_stream (round 6): with collectives in the step, the context and torch.distributed work on ONE stream of the receiver's
+        # own -- the collectives are issued with it current -- so that the only stream hops left are the backend's own (its stream
+        # waits for ours, ours for its).  Measured at world 1 under RCCL (profiles/r6_rccl): every hop between the context's stream
+        # and the one the collective was issued from cost 20-60 us, four of them per step.
+        self._tstream = None
+        if bool(share_stream) and self._buf.is_cuda and (self.world > 1 or self.force):
+            self._tstream = torch.cuda.Stream(device=self._buf.device)
+            ctx.set_stream(self._tstream.cuda_stream)
 
     def close(self):
         """The context forgets this receiver's buffers (before the receiver goes away while the context lives on)."""
@@ -103,6 +112,9 @@ class ShardedReceiver(object):
         if ctx is not None and getattr(ctx, "_h", None) and getattr(ctx, "_keep_owner", None) == id(self):
             ctx.shard_keep_tail(0, 0, 0)
             ctx._keep_owner = None
+            if getattr(self, "_tstream", None) is not None:
+                ctx.set_stream(None)                      # (the context's own stream again)
+                self._tstream = None
 
     def __del__(self):
         try:
@@ -132,6 +144,35 @@ class ShardedReceiver(object):
         """Start a new stream at sample 0 (what step(flush=True) does at its end)."""
         self.ctx.reset()
         self.k = 0
+        self._wrap_posted = False
+
+    def _exchange_p2p(self, ops):
+        t0 = time.perf_counter()
+        try:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()              # (RCCL: orders the current stream behind the transfer, the host does not block)
+        except Exception:
+            if not self.force:
+                raise
+            self.tail_by_gather = True                   # (one rank, a backend without send-to-self: the all_gather fallback)
+        dt = (time.perf_counter() - t0) * 1e6
+        self.host_us["tail_exchange"] += dt
+        self.host_us_steps["tail_exchange"].append(dt)
+
+    def _post_wrap(self):
+        """The transfer that closes the ring, for the NEXT step: the last rank's kept tail to rank 0's halo.  Posted right behind this
+        step's resolve (the kept tail is complete: the resolve step's completion was waited for), so that it runs while the host
+        hands the packets out and the caller fills the next chunk -- at world 1 that is the whole tail exchange."""
+        if not (self.world > 1 or (self.force and not self.tail_by_gather)):
+            return
+        ops = []
+        if self.rank == self.world - 1:
+            ops.append(self.dist.P2POp(self.dist.isend, self._tail, 0, self.group))
+        if self.rank == 0:
+            ops.append(self.dist.P2POp(self.dist.irecv, self._halo_view, self.world - 1, self.group))
+        if ops:
+            self._exchange_p2p(ops)
+            self._wrap_posted = not self.tail_by_gather
 
     def _exchange(self, m, last_exit, cap, msg_dev, msgs_dev):
         """all_gather of [count | exit of the step before | first min(count, cap) table entries]; returns the rows (host)."""
@@ -147,34 +188,36 @@ class ShardedReceiver(object):
     def step(self, flush=False):
         """One pass over the samples currently in `chunk`: the next world*n samples of the stream.  flush: they are the
         stream's last (every rank must say so).  Returns this rank's accepted packets."""
+        if self._tstream is not None:
+            # the receiver's stream: behind whoever filled `chunk` on the caller's current stream, then current for the whole step
+            self._tstream.wait_stream(self.torch.cuda.current_stream(self._buf.device))
+            with self.torch.cuda.stream(self._tstream):
+                return self._step(flush)
+        return self._step(flush)
+
+    def _step(self, flush):
         t, dist = self.torch, self.dist
         n, world, rank, halo, H = self.n, self.world, self.rank, self.halo, self.hold
         buf, own = self._buf, self.chunk
         on_gpu = buf.is_cuda
         S0 = self.k * world * n                              # absolute index of the step's first sample
         last = rank == world - 1
-        # 1. the samples in front of the own ones
+        # 1. the samples in front of the own ones.  The transfer that closes the ring -- the last rank's tail of the step BEFORE, to
+        # rank 0 -- was posted at the end of that step (round 6: _post_wrap), off this step's critical path; what is left here are the
+        # transfers inside the step, from every rank to the next
         if world > 1 or (self.force and not self.tail_by_gather):
             ops = []
             if not last:
                 ops.append(dist.P2POp(dist.isend, self._own_tail, rank + 1, self.group))
-            elif self.k > 0:
+            elif self.k > 0 and not self._wrap_posted:
                 ops.append(dist.P2POp(dist.isend, self._tail, 0, self.group))
             if rank > 0:
                 ops.append(dist.P2POp(dist.irecv, self._halo_view, rank - 1, self.group))
-            elif self.k > 0:
+            elif self.k > 0 and not self._wrap_posted:
                 ops.append(dist.P2POp(dist.irecv, self._halo_view, world - 1, self.group))
+            self._wrap_posted = False
             if ops:
-                tc = time.perf_counter()
-                try:
-                    for req in dist.batch_isend_irecv(ops):
-                        req.wait()      # (RCCL: orders the current stream behind the transfer, the host does not block)
-                except Exception:
-                    if not self.force:
-                        raise
-                    self.tail_by_gather = True           # (one rank, a backend without send-to-self: below)
-                self.host_us["tail_exchange"] += (time.perf_counter() - tc) * 1e6
-                self.host_us_steps["tail_exchange"].append((time.perf_counter() - tc) * 1e6)
+                self._exchange_p2p(ops)
         if self.force and self.tail_by_gather and self.k > 0:
             tc = time.perf_counter()
             dist.all_gather_into_tensor(self._halo_view, self._tail, group=self.group)     # world 1: the gathered tensor IS the tail
@@ -183,7 +226,8 @@ class ShardedReceiver(object):
             # one rank: it is its own predecessor (the kept tail goes in front of the chunk on the context's own stream)
             self.ctx.stream_copy(self._halo_view.data_ptr(), self._tail.data_ptr(), halo * 8)
         cur = t.cuda.current_stream(buf.device).cuda_stream if on_gpu else 0
-        if on_gpu and (cur != 0 or world > 1 or self.force):
+        shared = self._tstream is not None               # (the context enqueues on the current stream itself: nothing to order)
+        if on_gpu and not shared and (cur != 0 or world > 1 or self.force):
             # the scan behind the current stream (whoever filled `chunk`, the receive above): the context keeps its own
             # stream, whatever stream is current when step() is called.  (The legacy default stream needs no event: the
             # context's stream is a blocking one, which the runtime orders behind it -- and an event across two idle
@@ -203,13 +247,13 @@ class ShardedReceiver(object):
         if self.host_free:
             self.ctx.shard_scan_async(ptr, a0, a1, total, self._amsg.data_ptr(), self.small_cap, device_in=on_gpu, more=more)
             if world > 1 or self.force:
-                if on_gpu:
+                if on_gpu and not shared:
                     self.ctx.signal_stream(cur)              # the collective waits (on the device) for the table
                 tc = time.perf_counter()
                 dist.all_gather_into_tensor(self._agath, self._amsg, group=self.group)
                 self.host_us["all_gather"] += (time.perf_counter() - tc) * 1e6
                 self.host_us_steps["all_gather"].append((time.perf_counter() - tc) * 1e6)
-                if on_gpu:
+                if on_gpu and not shared:
                     self.ctx.wait_for_stream(cur)            # ... and the resolve step for the collective
                 msgs = self._agath
             else:
@@ -229,6 +273,7 @@ class ShardedReceiver(object):
             self.reset()
         else:
             self.k += 1                                      # (the last rank's tail was kept inside the resolve call)
+            self._post_wrap()
         return pk
 
     def _step_sync(self, ptr, a0, a1, total, more, cap_pk, on_gpu):
