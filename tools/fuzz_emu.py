@@ -134,6 +134,12 @@ def main():
             assert np.concatenate(gt).tobytes() == wt.tobytes() and np.concatenate(gb).tobytes() == wb.tobytes(), \
                 "case %d: the preamble block as a stream differs (cuts %s)" % (case, pc_)
             ctx.close()
+        # ONE continuing stream with several of its chunks in flight (am_spipe, round 6): random chunk sizes, contiguous or scattered
+        # buffers, against the oracle over the whole stream (a capture of its own: the helper draws it from the seed)
+        if n > 12 * (344 * (spc + 1) + (200 * spc if dc else 0)):
+            with np.errstate(all="ignore"):
+                pc.check_stream_pipe(lib, rate, n, lam, seed, depth=int(rng.integers(1, 5)), thr=thr, pmf=pmf, dcblock=dc,
+                                     contiguous=bool(rng.integers(0, 2)))
         print("case %3d ok: %5.0f Msps n=%8d lambda=%6.0f thr=%4.1f pmf=%d dc=%d kind=%d cuts=%s shards=%d packets=%d (%s build)"
               % (case, rate / 1e6, n, lam, thr, pmf, dc, kind, cuts, G, len(want), "rare" if case % 2 else "plain"), flush=True)
 
