@@ -455,3 +455,26 @@ def test_stream_pipe_redoes_chunks_whose_scan_outgrew_its_capacity(emu_lib, monk
     assert np.array_equal(got, want)
     assert pipe.redone() >= 1, "no chunk took the synchronous path: the test did not reach it"
     pipe.close()
+
+
+def test_stream_pipe_passes_the_scan_position_through_silent_chunks(emu_lib):
+    """Chunks without a single candidate (a silent stretch) still hand the scan position on: a burst that straddles the boundary in
+    front of the silence suppresses nothing behind it, the bursts after the silence are found where the oracle finds them."""
+    rate, spc = 64e6, 32
+    a, _ = synth.synth_capture(rate, 700000, 20000.0, 81)
+    quiet = np.zeros(1500000, np.complex64)                     # (exact zeros: not one first-stage candidate)
+    b, _ = synth.synth_capture(rate, 700000, 20000.0, 82)
+    iq = np.concatenate([a, quiet, b])
+    n = len(iq)
+    want = oracle.demod(iq, rate, 7.0, True)
+    assert len(want) > 20 and want["sample"].max() > 2200000
+    base = np.ascontiguousarray(iq.view(np.float32))
+    for depth in (1, 3):
+        pipe = _capi.StreamPipe(rate, 7.0, True, depth=depth, lib=emu_lib)
+        m = 290000                                               # (ten chunks; four of them wholly inside the silence)
+        chunks = [(base.ctypes.data + 8 * k * m, m if k < 9 else n - 9 * m) for k in range(10)]
+        got = pipe.run(chunks)
+        assert sum(1 for g in got if len(g) == 0) >= 4
+        assert np.array_equal(np.concatenate(got), want)
+        assert pipe.redone() == 0
+        pipe.close()

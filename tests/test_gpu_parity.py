@@ -531,3 +531,37 @@ def test_one_stream_with_chunks_in_flight_on_device(hip_lib, rate, n, lam, depth
     pk, _ = pc.check_stream_pipe(hip_lib, rate, n, lam, seed=int(rate / 1e6) + depth, depth=depth, contiguous=contiguous, rx_time=rx,
                                  device=torch.device("cuda", 0))
     assert len(pk) > 10
+
+
+@pytest.mark.gpu
+def test_stream_pipe_silent_chunks_and_redone_chunks_on_device(hip_lib, hip_knobs_lib, monkeypatch):
+    """am_spipe on the device, the two paths a busy capture does not reach: chunks without a single candidate (the scan position is
+    still handed on), and chunks whose scan outgrew the capacity it was launched for (flagged in the message header: the pipe drains
+    the chunks behind, redoes the chunk on the synchronous path, submits the others again)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rate = 64e6
+    a, _ = synth.synth_capture(rate, 2_000_000, 20000.0, 81)
+    b, _ = synth.synth_capture(rate, 2_000_000, 20000.0, 82)
+    iq = np.concatenate([a, np.zeros(4_000_000, np.complex64), b])
+    want = oracle.demod(iq, rate, 7.0, True)
+    base = torch.from_numpy(np.ascontiguousarray(iq.view(np.float32))).to(dev)
+    m = len(iq) // 10
+    chunks = [(base.data_ptr() + 8 * k * m, m) for k in range(10)]
+    pipe = _capi.StreamPipe(rate, 7.0, True, depth=3, lib=hip_lib, device=0)
+    got = pipe.run(chunks)
+    assert sum(1 for g in got if len(g) == 0) >= 3 and np.array_equal(np.concatenate(got), want) and pipe.redone() == 0
+    pipe.close()
+    # a quiet first half, dense traffic behind it, no slack in the capacity estimate: some chunk must be redone
+    monkeypatch.setenv("AIRMODES_SPEC_FLOOR", "0")
+    quiet, _ = synth.synth_capture(rate, 8_000_000, 300.0, 71)
+    busy, _ = synth.synth_capture(rate, 8_000_000, 30000.0, 72)
+    iq2 = np.concatenate([quiet, busy])
+    want2 = oracle.demod(iq2, rate, 7.0, True)
+    base2 = torch.from_numpy(np.ascontiguousarray(iq2.view(np.float32))).to(dev)
+    m2 = len(iq2) // 8
+    pipe2 = _capi.StreamPipe(rate, 7.0, True, depth=3, lib=hip_knobs_lib, device=0)
+    got2 = np.concatenate(pipe2.run([(base2.data_ptr() + 8 * k * m2, m2) for k in range(8)]))
+    assert np.array_equal(got2, want2)
+    assert pipe2.redone() >= 1, "no chunk took the synchronous path: the test did not reach it"
+    pipe2.close()
