@@ -138,6 +138,8 @@ class Library(object):
         L.am_pipe_last_error.argtypes = [vp]
         L.am_pipe_last_kernel_ms.restype = C.c_float
         L.am_pipe_last_kernel_ms.argtypes = [vp]
+        L.am_shard_resolve_submit.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp]
+        L.am_shard_resolve_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         L.am_spipe_create.restype = vp
         L.am_spipe_create.argtypes = [C.c_int, C.c_double, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         L.am_spipe_destroy.argtypes = [vp]
@@ -319,6 +321,21 @@ class Context(object):
         self._chk(rc)
         return self._received(out, got.value), bool(redo.value)
 
+
+    def shard_resolve_submit(self, msgs_ptr, world, rank, msg_cap, cur_in_ptr=0, carry_out_ptr=0):
+        """The resolve step, enqueued only (steps of the time-sharded receiver in flight); shard_resolve_collect completes it."""
+        self._chk(self.lib.L.am_shard_resolve_submit(self._h, C.c_void_p(int(msgs_ptr)), int(world), int(rank), int(msg_cap),
+                                                     C.c_void_p(int(cur_in_ptr) or None), C.c_void_p(int(carry_out_ptr) or None)))
+
+    def shard_resolve_collect(self, capacity=4096):
+        """-> (packets, redo) of the submitted resolve step."""
+        out = self._receive_buffer(int(capacity))
+        got, redo = C.c_uint64(0), C.c_int(0)
+        rc = self.lib.L.am_shard_resolve_collect(self._h, out.ctypes.data, len(out), C.byref(got), C.byref(redo))
+        if rc == AM_ECAPACITY:
+            return self._fetch(int(got.value)), False
+        self._chk(rc)
+        return self._received(out, got.value), bool(redo.value)
     def last_frontend(self):
         """3 = streaming kernel, 2 = tile kernel, 1 = rate-generic kernels, 0 = no scan yet (diagnostic)."""
         return int(self.lib.L.am_last_frontend(self._h))

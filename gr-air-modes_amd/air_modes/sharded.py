@@ -302,3 +302,281 @@ class ShardedReceiver(object):
         pk = self.ctx.shard_resolve(int(entry[rank]), capacity=cap_pk)
         self.ctx.shard_set_exit(int(leave[rank]))
         return pk
+
+
+class PipelinedShardedReceiver(object):
+    """The time-sharded receiver with STEPS IN FLIGHT (round 6).  ShardedReceiver.step() is one step at a time: tail exchange, scan,
+    all-gather of the exit tables, resolve, wait -- and through RCCL every collective is a detour of ~100 us on the step's critical
+    path (measured at world 1: profiles/r6_rccl).  Here the scan and the all-gather of step k + 1 are enqueued BEFORE step k is
+    resolved: the collectives of one step run while the kernels of its neighbours do.
+
+        rx.chunk.copy_(samples of step 0); rx.submit()
+        rx.chunk.copy_(samples of step 1); rx.submit()        # scan + all-gather of step 1; resolve of step 0 enqueued
+        pk0 = rx.collect()                                    # step 0's packets
+        rx.chunk.copy_(samples of step 2); rx.submit(); pk1 = rx.collect(); ...   # collect(j) comes before submit(j + 2)
+
+    What makes it possible: a step's scan never depended on where the greedy scan enters the chunk; the position it starts from --
+    where the scan left the LAST chunk of the step before -- no longer travels in the next step's message (written at scan time,
+    i.e. too early) but stays in a device word every rank keeps for itself: the resolve step composes the entry through ALL ranks'
+    tables (am_shard_resolve_submit: cur_in / carry_out) and leaves the step's final position there.  Two contexts and two halo'd
+    chunk buffers per rank alternate; everything is issued on ONE stream of the receiver's own, the collectives asynchronously, so
+    stream order is all the ordering there is.  A step whose table did not fit its message or whose scan outgrew its capacity is
+    flagged in the headers every rank reads: collect() repeats it on the synchronous path (host tables) on every rank alike; the
+    step scanned behind it stays valid (its resolve is only enqueued once its predecessor is known to be good).
+    Packets of all (step, rank) pairs in order == the single-stream packet list.  Give BOTH contexts the same rx_time tags."""
+
+    def __init__(self, ctxs, rank, world, n_per_rank, group=None, device=None, small_table=512, force_collectives=False):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        if len(ctxs) != 2:
+            raise ValueError("two contexts (same rate, threshold, filters): steps alternate between them")
+        self.ctxs, self.rank, self.world, self.n, self.group = list(ctxs), int(rank), int(world), int(n_per_rank), group
+        ctx = self.ctxs[0]
+        self.force = bool(force_collectives) and self.world == 1 and dist.is_available() and dist.is_initialized()
+        self.tail_by_gather = False
+        self.left, self.hold = ctx.shard_halo()
+        self.halo = self.left + self.hold
+        if self.n < self.halo:
+            raise ValueError("chunk shorter than the halo (%d samples)" % self.halo)
+        spc_hi = max(int(-(-ctx.get_rate() // 2e6)), 1)
+        self.tab_cap = 241 * spc_hi + 4
+        self.small_cap = max(1, min(int(small_table), self.tab_cap))
+        dev = device if device is not None else "cpu"
+        t = torch
+        self._bufs = [t.zeros((self.halo + self.n) * 2, dtype=t.float32, device=dev) for _ in range(2)]
+        emulated = bool(getattr(ctx.lib, "emulated", False))
+        if not (self._bufs[0].is_cuda or emulated):
+            raise ValueError("steps in flight need device buffers (or the CPU emulation): the tables stay on the device")
+        words = 2 * (_capi.SHARD_MSG_HEADER + self.small_cap)
+        self._amsg = [t.zeros(words, dtype=t.int64, device=dev) for _ in range(2)]
+        self._agath = [t.zeros(self.world * words, dtype=t.int64, device=dev) for _ in range(2)]
+        self._carry = t.zeros(2, dtype=t.int64, device=dev)          # [0]: where the scan left the last chunk of the step resolved last
+        self._host_tab = np.zeros(self.tab_cap, _capi.EXIT_DTYPE)
+        self._msg = t.zeros(2 + 2 * self.tab_cap, dtype=t.int64, device=dev)
+        self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
+        self._tstream = None
+        if self._bufs[0].is_cuda:
+            self._tstream = t.cuda.Stream(device=self._bufs[0].device)
+            self._cstream = t.cuda.Stream(device=self._bufs[0].device)
+            self._caller = None
+            for c in self.ctxs:
+                c.set_stream(self._tstream.cuda_stream)
+        for c in self.ctxs:
+            c.shard_keep_tail(0, 0, 0)
+        self.k = 0                       # steps of the current stream submitted so far
+        self._scanned = None             # (k, slot, all-gather work, flush): scanned, its resolve not enqueued yet
+        self._resolved = None            # (k, slot, flush): resolve enqueued, not collected yet
+        self._ended = False
+        self.sync_steps = 0
+        self.host_us = {"tail_exchange": 0.0, "all_gather": 0.0, "steps": 0}
+        self.host_us_steps = {"tail_exchange": [], "all_gather": []}
+
+    # ---- what ShardedReceiver offers too -----------------------------------------------------------------------------------------
+    @property
+    def chunk(self):
+        """This rank's 2*n float32 samples of the NEXT step to submit (write them here, then submit())."""
+        b = self._bufs[self.k % 2]
+        return b[self.halo * 2:]
+
+    def set_rx_time(self, offset, secs, frac):
+        for c in self.ctxs:
+            c.set_rx_time(offset, secs, frac)
+
+    def close(self):
+        for c in getattr(self, "ctxs", []):
+            if getattr(c, "_h", None) and self._tstream is not None:
+                c.set_stream(None)
+        self._tstream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        if self._scanned is not None or self._resolved is not None:
+            raise RuntimeError("collect the steps in flight first")
+        for c in self.ctxs:
+            c.reset()
+        self._carry.zero_()
+        self.k = 0
+        self._ended = False
+
+    def in_flight(self):
+        return (self._scanned is not None) + (self._resolved is not None)
+
+    # ---- one step's geometry --------------------------------------------------------------------------------------------------------
+    def _geometry(self, k, flush):
+        n, world, rank, H = self.n, self.world, self.rank, self.hold
+        S0 = k * world * n
+        last = rank == world - 1
+        a0 = 0 if (k == 0 and rank == 0) else S0 + rank * n - H
+        total = S0 + world * n
+        a1 = total if (flush and last) else S0 + (rank + 1) * n - H
+        b0 = S0 + rank * n - self.halo                      # absolute index of the buffer's first sample
+        lo = max(0, a0 - self.left)
+        return a0, a1, total, (lo - b0) * 8
+
+    def _with_stream(self, fn, *a):
+        if self._tstream is None:
+            return fn(*a)
+        with self.torch.cuda.stream(self._tstream):
+            return fn(*a)
+
+    # ---- submit / collect --------------------------------------------------------------------------------------------------------------
+    def submit(self, flush=False):
+        """Enqueue the step whose samples are in `chunk`: its tail exchange, scan and all-gather -- and the resolve step of the step
+        before it.  flush: the stream's last step (every rank must say so)."""
+        if self._ended:
+            raise RuntimeError("the stream was flushed: collect its steps before the next stream starts")
+        if self._resolved is not None and self._scanned is not None:
+            raise RuntimeError("collect the oldest step first (collect(j) comes before submit(j + 2))")
+        if self._tstream is not None:
+            self._caller = self.torch.cuda.current_stream(self._bufs[0].device)
+            self._tstream.wait_stream(self._caller)
+        self._with_stream(self._submit, bool(flush))
+
+    def _submit(self, flush):
+        t, dist = self.torch, self.dist
+        k, world, rank, halo, n = self.k, self.world, self.rank, self.halo, self.n
+        s = k % 2
+        buf, prev = self._bufs[s], self._bufs[1 - s]
+        halo_view, own_tail, prev_tail = buf[:halo * 2], buf[n * 2:], prev[n * 2:]
+        last = rank == world - 1
+        on_gpu = buf.is_cuda
+        collectives = world > 1 or self.force
+        # 1. the samples in front of the own ones: issued now, waited for (in stream order) in front of the scan
+        reqs = []
+        tc = time.perf_counter()
+        if collectives and not self.tail_by_gather:
+            ops = []
+            if not last:
+                ops.append(dist.P2POp(dist.isend, own_tail, rank + 1, self.group))
+            elif k > 0:
+                ops.append(dist.P2POp(dist.isend, prev_tail, 0, self.group))       # the ring closes: the step before's last chunk
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, halo_view, rank - 1, self.group))
+            elif k > 0:
+                ops.append(dist.P2POp(dist.irecv, halo_view, world - 1, self.group))
+            if ops:
+                try:
+                    reqs = self._issue_p2p(ops)
+                except Exception:
+                    if not self.force:
+                        raise
+                    self.tail_by_gather = True
+        if k > 0 and world == 1 and (not collectives or self.tail_by_gather):
+            if self.force:
+                dist.all_gather_into_tensor(halo_view, prev_tail, group=self.group)        # (world 1: the gathered tensor IS the tail)
+            else:
+                self.ctxs[s].stream_copy(halo_view.data_ptr(), prev_tail.data_ptr(), halo * 8)
+        # 2. the resolve step of the step before (the host runs ahead of the device by it: the scan below is queued behind it when
+        #    collect() returns).  Measured the other way round -- scan first, so that the all-gather hides behind it: the device
+        #    idles while the host enqueues the next step, 0.34 vs 0.29 ms per step (profiles/r6_rccl/steps_in_flight.txt)
+        self._resolve_scanned()
+        # 3. the scan, behind the tail exchange
+        try:
+            for r_ in reqs:
+                r_.wait()
+        except Exception:
+            if not self.force:
+                raise
+            self.tail_by_gather = True
+            dist.all_gather_into_tensor(halo_view, prev_tail, group=self.group)
+        dtt = (time.perf_counter() - tc) * 1e6
+        self.host_us["tail_exchange"] += dtt
+        self.host_us_steps["tail_exchange"].append(dtt)
+        a0, a1, total, off = self._geometry(k, flush)
+        c = self.ctxs[s]
+        c.shard_scan_async(buf.data_ptr() + off, a0, a1, total, self._amsg[s].data_ptr(), self.small_cap, device_in=on_gpu, more=not flush)
+        work = None
+        if collectives:
+            tc = time.perf_counter()
+            work = dist.all_gather_into_tensor(self._agath[s], self._amsg[s], group=self.group, async_op=True)
+            dta = (time.perf_counter() - tc) * 1e6
+            self.host_us["all_gather"] += dta
+            self.host_us_steps["all_gather"].append(dta)
+        self._scanned = (k, s, work, flush)
+        self.host_us["steps"] += 1
+        self.k += 1
+        if flush:
+            self._ended = True
+
+    def _issue_p2p(self, ops):
+        """The tail exchange depends on the caller's samples only, not on what the receiver's stream still has queued (the scan and
+        the resolve of older steps): issued from a stream of its own, so that the backend's wait for "the current stream" is short."""
+        if self._tstream is None:
+            return self.dist.batch_isend_irecv(ops)
+        self._cstream.wait_stream(self._caller)
+        with self.torch.cuda.stream(self._cstream):
+            return self.dist.batch_isend_irecv(ops)
+
+    def _resolve_scanned(self):
+        """The scanned step's resolve, enqueued (behind its all-gather); needs the step before it collected."""
+        if self._scanned is None:
+            return
+        if self._resolved is not None:
+            raise RuntimeError("collect the oldest step first (collect(j) comes before submit(j + 2))")
+        k, s, work, flush = self._scanned
+        if work is not None:
+            work.wait()                                      # (the stream waits; the host does not, with RCCL)
+        msgs = self._agath[s] if (self.world > 1 or self.force) else self._amsg[s]
+        self.ctxs[s].shard_resolve_submit(msgs.data_ptr(), self.world, self.rank, self.small_cap,
+                                          cur_in_ptr=self._carry.data_ptr(), carry_out_ptr=self._carry.data_ptr())
+        self._resolved, self._scanned = (k, s, flush), None
+
+    def collect(self):
+        """The packets of the oldest step in flight."""
+        if self._resolved is None:
+            if self._scanned is None:
+                raise RuntimeError("no step in flight")
+            self._with_stream(self._resolve_scanned)
+        k, s, flush = self._resolved
+        cap_pk = max(64, self.n // 2000 + 64)
+        pk, redo = self.ctxs[s].shard_resolve_collect(capacity=cap_pk)
+        if redo:
+            self.sync_steps += 1
+            pk = self._with_stream(self._redo, k, s, flush, cap_pk)
+        self._resolved = None
+        if flush:
+            self._ended = False
+            if self._scanned is None:
+                self.reset()
+        return pk
+
+    def step(self, flush=False):
+        """submit + collect (no overlap between steps; ShardedReceiver's interface)."""
+        self.submit(flush)
+        return self.collect()
+
+    def _redo(self, k, s, flush, cap_pk):
+        """Step k once more with the tables on the host (am_shard_scan -> all_gather -> am_shard_entry2 -> am_shard_resolve), on every
+        rank alike; the carry of the step before it is still in the device word (a flagged step does not write it)."""
+        t, dist = self.torch, self.dist
+        world, rank = self.world, self.rank
+        c, buf = self.ctxs[s], self._bufs[s]
+        on_gpu = buf.is_cuda
+        a0, a1, total, off = self._geometry(k, flush)
+        L = c.lib.L
+        got = C.c_uint64(0)
+        flags = (_capi.AM_F_DEVICE_IN if on_gpu else 0) | (0 if flush else _capi.AM_F_MORE)
+        rc = L.am_shard_scan(c._h, buf.data_ptr() + off, a0, a1, total, flags, self._host_tab.ctypes.data, self.tab_cap, C.byref(got))
+        c._chk(rc)
+        m = int(got.value)
+        cur_in = int(np.int64(self._carry[0].item()).astype(np.uint64))
+        if world > 1:
+            msg = np.zeros(2 + 2 * self.tab_cap, np.int64)
+            msg[0] = m
+            msg[2:2 + 2 * m] = self._host_tab[:m].view(np.int64)
+            self._msg.copy_(t.from_numpy(msg))
+            dist.all_gather(self._msgs, self._msg, group=self.group)
+            allm = t.stack(self._msgs).cpu().numpy()
+            tables = [allm[r, 2:2 + 2 * int(allm[r, 0])].copy().view(_capi.EXIT_DTYPE) for r in range(world)]
+        else:
+            tables = [self._host_tab[:m].copy()]
+        entry, leave = _capi.shard_entries(c.lib, tables, cur_in=cur_in, with_exits=True)
+        pk = c.shard_resolve(int(entry[rank]), capacity=cap_pk)
+        self._carry[0] = int(np.uint64(leave[world - 1]).astype(np.int64))
+        return pk

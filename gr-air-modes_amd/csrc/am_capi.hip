@@ -2173,6 +2173,89 @@ static void spipe_bounds(const am_spipe *p, const am_spipe_slot &sl, uint64_t *a
     *ptr = sl.iq - (sl.S - lo) * 2;
 }
 
+// The resolve step of the resident chunk, ENQUEUED only (am_spipe, am_shard_resolve_submit): entry position composed on the device
+// from `world` messages -- starting from *cur_in where given --, marking, extraction, slicing, one completion ticket; c->pend says
+// what shard_resolve_complete has to wait for.  walk_done: recorded behind the block walk (or behind the entry kernel of a chunk
+// with nothing to slice): what a later chunk's resolve step has to wait for.
+static int shard_resolve_enqueue(am_ctx *c, const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t msg_cap,
+                                 const uint64_t *cur_in, uint64_t *carry_out, hipEvent_t walk_done)
+{
+    c->pending.clear();
+    c->last_tags = 0;
+    if (int rcs = ensure_scalars(c); rcs != AM_OK) return rcs;
+    if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
+    uint32_t *cur0_dev = (uint32_t *)c->scalars.p + 4, *flag_dev = (uint32_t *)c->scalars.p + 5;
+    if (!c->pin_scalars) {
+        HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));
+    }
+    am_ctx::Pending &P = c->pend;
+    P = am_ctx::Pending();
+    uint64_t em = 0;
+    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c, c->shard_total, &em) || em < c->shard_base))) {
+        // nothing to slice: the entry is still composed (the chunk passes the scan position on), one ticket
+        HIPCHK(c, am_launch_shard_entry(msgs, world, rank, msg_cap, c->shard_base, cur0_dev, flag_dev, (uint64_t *)c->shard_exit.p, c->stream, cur_in,
+                                        carry_out));
+        if (walk_done) HIPCHK(c, hipEventRecord(walk_done, c->stream));
+        if (c->keep_bytes) HIPCHK(c, hipMemcpyAsync(c->keep_dst, c->keep_src, c->keep_bytes, hipMemcpyDeviceToDevice, c->stream));
+        const uint32_t seq = ++c->ticket_seq;
+        HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, flag_dev, c->pin_scalars + 4, (const uint64_t *)c->shard_exit.p,
+                                   reinterpret_cast<uint64_t *>(c->pin_scalars + 12)));
+        P.active = true; P.scanned = false; P.seq = seq;
+        return AM_OK;
+    }
+    const uint32_t emax = c->shard_more ? 0xFFFFFFFEu : (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
+    uint32_t fin = 0;
+    const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) / ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
+    am_entry_src es;
+    es.msgs = msgs; es.world = world; es.rank = rank; es.cap = msg_cap; es.base_abs = c->shard_base; es.flags = flag_dev;
+    es.exit_out = (uint64_t *)c->shard_exit.p; es.cur_in = cur_in; es.carry_out = carry_out;
+    c->entry_src = &es;
+    c->flag_src = flag_dev;
+    c->word_src = (const uint64_t *)c->shard_exit.p;
+    c->walk_event = walk_done;
+    c->resolving_shard = true;
+    c->defer = true;
+    int rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
+    c->defer = false;
+    c->resolving_shard = false;
+    c->entry_src = nullptr;
+    c->flag_src = nullptr;
+    c->word_src = nullptr;
+    c->walk_event = nullptr;
+    if (rc != AM_DEFERRED) return rc == AM_OK ? fail(c, AM_EHIP, "internal: the resolve step was not deferred") : rc;
+    P.active = true;                                            // (chain_finish filled in scanned / seq / M / Mp / n_max)
+    return AM_OK;
+}
+
+// ... and its completion: waits for the ticket; the packets stay in the context's hand-out list.  *redo: a table did not fit its message
+// or a scan outgrew its capacity (every rank reads the same headers: every rank gets the same answer).  *exit_after: where the scan
+// left this chunk
+static int shard_resolve_complete(am_ctx *c, int *redo, uint64_t *exit_after)
+{
+    am_ctx::Pending &P = c->pend;
+    *redo = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, wait_for_ticket(c, P.seq));
+    int rc = AM_OK;
+    if (P.scanned) {
+        uint32_t fin = 0;
+        rc = chain_collect(c, P.M, P.Mp, P.n_max, false, &fin);
+        if (rc == AM_RETRY_EXACT) { *redo = 1; rc = AM_OK; }
+    } else
+        c->tail_synced = true;
+    P.active = false; P.scanned = false;
+    if (rc != AM_OK) return rc;
+    if (c->pin_scalars[4]) *redo = 1;                           // (the header said so)
+    if (*redo) c->pending.clear();
+    if (exit_after) *exit_after = *reinterpret_cast<volatile uint64_t *>(c->pin_scalars + 12);
+    c->spec_density = (c->shard_end > c->shard_start) ? (double)c->last_M / (double)(c->shard_end - c->shard_start) : 0.0;
+    c->last_tags = c->n_hits;
+    c->last_dom_ms = 0.0f;
+    if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
+    return AM_OK;
+}
+
 // enqueue scan + resolve of the chunk in slot k (its fields are filled in); nothing waits
 static int spipe_enqueue(am_spipe *p, size_t k)
 {
@@ -2199,78 +2282,13 @@ static int spipe_enqueue(am_spipe *p, size_t k)
         cur_in = (const uint64_t *)pv.c->shard_exit.p;
         HIPCHK(c, hipStreamWaitEvent(c->stream, pv.done, 0));
     }
-    c->pending.clear();
-    c->last_tags = 0;
-    if (int rcs = ensure_scalars(c); rcs != AM_OK) return rcs;
-    if (int rce = ensure_shard_exit(c); rce != AM_OK) return rce;
-    uint32_t *cur0_dev = (uint32_t *)c->scalars.p + 4, *flag_dev = (uint32_t *)c->scalars.p + 5;
-    if (!c->pin_scalars) {
-        HIPCHK(c, hipHostMalloc((void **)&c->pin_scalars, 16 * sizeof(uint32_t), hipHostMallocCoherent | hipHostMallocMapped));
-        memset(c->pin_scalars, 0, 16 * sizeof(uint32_t));
-    }
-    am_ctx::Pending &P = c->pend;
-    P = am_ctx::Pending();
-    uint64_t em = 0;
-    if (c->chain_M == 0 || (!c->shard_more && (!flush_limits(c, c->shard_total, &em) || em < c->shard_base))) {
-        // nothing to slice: the entry is still composed (the chunk passes the scan position on), one ticket
-        HIPCHK(c, am_launch_shard_entry(sl.msg, 1, 0, p->msg_cap, c->shard_base, cur0_dev, flag_dev, (uint64_t *)c->shard_exit.p, c->stream, cur_in));
-        const uint32_t seq = ++c->ticket_seq;
-        HIPCHK(c, am_launch_ticket(c->pin_scalars + 8, seq, c->stream, flag_dev, c->pin_scalars + 4, (const uint64_t *)c->shard_exit.p,
-                                   reinterpret_cast<uint64_t *>(c->pin_scalars + 12)));
-        P.active = true; P.scanned = false; P.seq = seq;
-    } else {
-        const uint32_t emax = c->shard_more ? 0xFFFFFFFEu : (uint32_t)std::min<uint64_t>(em - c->shard_base, 0xFFFFFFFEu);
-        uint32_t fin = 0;
-        const uint32_t max_hits = (uint32_t)((c->shard_end - c->shard_start + (uint64_t)c->spc) / ((uint64_t)AM_BURST * (uint64_t)c->spc) + 2);
-        am_entry_src es;
-        es.msgs = sl.msg; es.world = 1; es.rank = 0; es.cap = p->msg_cap; es.base_abs = c->shard_base; es.flags = flag_dev;
-        es.exit_out = (uint64_t *)c->shard_exit.p; es.cur_in = cur_in;
-        c->entry_src = &es;
-        c->flag_src = flag_dev;
-        c->word_src = (const uint64_t *)c->shard_exit.p;
-        c->walk_event = sl.done;
-        c->resolving_shard = true;
-        c->defer = true;
-        rc = chain_finish(c, (const float *)c->bb.p, 0, emax, c->shard_base, false, &fin, max_hits);
-        c->defer = false;
-        c->resolving_shard = false;
-        c->entry_src = nullptr;
-        c->flag_src = nullptr;
-        c->word_src = nullptr;
-        c->walk_event = nullptr;
-        if (rc != AM_DEFERRED) return rc == AM_OK ? fail(c, AM_EHIP, "internal: the resolve step was not deferred") : rc;
-        P.active = true;                                        // (chain_finish filled in scanned / seq / M / Mp / n_max)
-        return AM_OK;                                           // (sl.done was recorded behind the block walk)
-    }
-    HIPCHK(c, hipEventRecord(sl.done, c->stream));
-    return AM_OK;
+    return shard_resolve_enqueue(c, sl.msg, 1, 0, p->msg_cap, cur_in, nullptr, sl.done);
 }
 
 // wait for the chunk in slot k; its packets stay in the context's hand-out list.  *redo: the chunk must go through the synchronous path
 static int spipe_complete(am_spipe *p, size_t k, int *redo, uint64_t *exit_after)
 {
-    am_ctx *c = p->slot[k].c;
-    am_ctx::Pending &P = c->pend;
-    *redo = 0;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, wait_for_ticket(c, P.seq));
-    int rc = AM_OK;
-    if (P.scanned) {
-        uint32_t fin = 0;
-        rc = chain_collect(c, P.M, P.Mp, P.n_max, false, &fin);
-        if (rc == AM_RETRY_EXACT) { *redo = 1; rc = AM_OK; }
-    } else
-        c->tail_synced = true;
-    P.active = false; P.scanned = false;
-    if (rc != AM_OK) return rc;
-    if (c->pin_scalars[4]) *redo = 1;                           // a table that did not fit, a capacity that did not suffice: the header says so
-    if (*redo) c->pending.clear();
-    *exit_after = *reinterpret_cast<volatile uint64_t *>(c->pin_scalars + 12);
-    c->spec_density = (c->shard_end > c->shard_start) ? (double)c->last_M / (double)(c->shard_end - c->shard_start) : 0.0;
-    c->last_tags = c->n_hits;
-    c->last_dom_ms = 0.0f;
-    if (c->dom_timed && hipEventElapsedTime(&c->last_dom_ms, c->ev[3], c->ev[1]) != hipSuccess) c->ht[6] += 1.0;
-    return AM_OK;
+    return shard_resolve_complete(p->slot[k].c, redo, exit_after);
 }
 
 extern "C" {
@@ -2427,6 +2445,31 @@ int am_spipe_collect(am_spipe *p, am_packet *out, uint64_t cap, uint64_t *n_out)
         p->S_next = 0; p->ended = false; p->prev_iq = nullptr; p->prev_n = 0; p->prev_slot = -1; p->exit_host = 0;
     }
     return hrc;
+}
+
+int am_shard_resolve_submit(am_ctx *c, const am_shard_exit *msgs_dev, uint32_t world, uint32_t rank, uint64_t msg_cap,
+                            const uint64_t *cur_in_dev, uint64_t *carry_out_dev)
+{
+    if (!c || (world && !msgs_dev) || rank >= world) return AM_EINVAL;
+    if (!c->shard_ready) return fail(c, AM_EINVAL, "am_shard_scan_async has not been called");
+    if (c->pend.active) return fail(c, AM_EINVAL, "a submitted resolve step has not been collected (am_shard_resolve_collect)");
+    if (!device_addressable(msgs_dev) || (cur_in_dev && !device_addressable(cur_in_dev)) || (carry_out_dev && !device_addressable(carry_out_dev)))
+        return fail(c, AM_EINVAL, "am_shard_resolve_submit: a pointer is not device-addressable memory");
+    HIPCHK(c, hipSetDevice(c->device));
+    return shard_resolve_enqueue(c, msgs_dev, world, rank, (uint32_t)msg_cap, cur_in_dev, carry_out_dev, nullptr);
+}
+
+int am_shard_resolve_collect(am_ctx *c, am_packet *out, uint64_t cap, uint64_t *n_out, int *redo)
+{
+    if (!c || !redo) return AM_EINVAL;
+    if (n_out) *n_out = 0;
+    if (!c->pend.active) {                                      // (an AM_ECAPACITY left the packets behind: hand them out now)
+        *redo = 0;
+        return hand_out(c, out, cap, n_out);
+    }
+    if (int rc = shard_resolve_complete(c, redo, nullptr); rc != AM_OK) return rc;
+    if (*redo) return AM_OK;
+    return hand_out(c, out, cap, n_out);
 }
 
 const char *am_spipe_last_error(const am_spipe *p)

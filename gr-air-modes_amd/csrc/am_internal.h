@@ -204,6 +204,7 @@ struct am_entry_src {
     uint64_t base_abs = 0;          // absolute index of the chunk's array coordinate 0
     uint32_t *flags = nullptr;      // flags[0] = 1: repeat the step
     uint64_t *exit_out = nullptr;   // where the scan leaves this chunk (absolute): the next step's message carries it
+    uint64_t *carry_out = nullptr;  // non-null: where the scan leaves the step's LAST chunk (composed through all ranks' tables), for the next step
     const uint64_t *cur_in = nullptr;   // non-null: where the scan left the chunk BEFORE this one, read when the entry is composed (am_spipe)
 };
 
@@ -224,7 +225,8 @@ hipError_t am_launch_chain_exit_table(const uint32_t *pos, const uint32_t *tgt, 
 /* device-side am_shard_entry2: `world` messages of AM_SHARD_MSG_HEADER + cap entries; writes the array coordinate at which the
  * scan enters chunk `rank`, the absolute position at which it leaves it, and sets flags[0] if some table did not fit */
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
-                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s, const uint64_t *cur_in = nullptr);
+                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s, const uint64_t *cur_in = nullptr,
+                                 uint64_t *carry_out = nullptr);
 /* the header of a message without a table: {0, 0}, {*carry, 0} */
 hipError_t am_launch_shard_header(am_shard_exit *header, const uint64_t *carry, hipStream_t s);
 

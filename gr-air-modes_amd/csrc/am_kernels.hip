@@ -1390,15 +1390,20 @@ __device__ __forceinline__ void am_cblk_load_links(uint16_t *lnk, const uint16_t
 // waits for seven tables.
 __device__ __forceinline__ uint64_t am_shard_entry_wave(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank,
                                                         uint32_t cap, int lane, uint32_t *bad_out, uint64_t *exit_out,
-                                                        const uint64_t *__restrict__ cur_in = nullptr)
+                                                        const uint64_t *__restrict__ cur_in = nullptr, uint64_t *carry_out = nullptr)
 {
     const size_t stride = (size_t)cap + AM_SHARD_MSG_HEADER;
-    // where the scan left the last chunk of the step before: the last rank's header -- or, chunks of ONE stream in flight on one GPU
-    // (am_spipe), the word the chunk before this one leaves it in, read NOW: that chunk's scan was enqueued before the word was written
+    // where the scan left the last chunk of the step before: the last rank's header -- or (chunks of ONE stream in flight on one GPU:
+    // am_spipe; steps of the time-sharded receiver in flight: am_shard_resolve_submit) a device word, read NOW: the scan of this
+    // chunk was enqueued before the word was written
     uint64_t cur = cur_in ? *cur_in : msgs[(size_t)(world - 1u) * stride + 1u].pos;             // (every lane reads the same word)
-    uint64_t entry = cur;
+    uint64_t entry = cur, leave = cur;
     uint32_t bad = 0;
-    for (uint32_t r = 0; r <= rank; ++r) {
+    // carry_out: the composition runs through ALL chunks of the step, not only up to the own one: where the scan leaves the step's
+    // last chunk is what the next step starts from -- every rank works it out for itself, from the same tables (round 6: the carry no
+    // longer travels in the next step's message, which is written before this step is resolved when steps are in flight)
+    const uint32_t r_end = carry_out ? world : rank + 1u;
+    for (uint32_t r = 0; r < r_end; ++r) {
         const am_shard_exit *m = msgs + (size_t)r * stride;
         const uint64_t n = m[0].pos;
         if (n > cap || m[0].exit != 0) { bad = 1; break; }
@@ -1415,11 +1420,13 @@ __device__ __forceinline__ uint64_t am_shard_entry_wave(const am_shard_exit *__r
                 break;
             }
         }                                                                     // (no candidate left: the scan passes through)
+        if (r == rank) leave = cur;
     }
-    for (uint32_t r = rank + 1u + (uint32_t)lane; r < world && !bad; r += AM_WAVE)   // (every rank must take the same decision)
+    for (uint32_t r = r_end + (uint32_t)lane; r < world && !bad; r += AM_WAVE)   // (every rank must take the same decision)
         if (msgs[(size_t)r * stride].pos > cap || msgs[(size_t)r * stride].exit != 0) bad = 1;
     *bad_out = __ballot(bad != 0u) != 0ull ? 1u : 0u;
-    *exit_out = cur;
+    *exit_out = leave;
+    if (carry_out && lane == 0 && !*bad_out) *carry_out = cur;
     return entry;
 }
 
@@ -1446,7 +1453,7 @@ am_k_cblk_walk(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ ex
         if (threadIdx.x < AM_WAVE) {
             uint32_t bad = 0;
             uint64_t leave = 0;
-            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad, &leave, es.cur_in);
+            const uint64_t cur = am_shard_entry_wave(es.msgs, es.world, es.rank, es.cap, (int)threadIdx.x, &bad, &leave, es.cur_in, es.carry_out);
             if (threadIdx.x == 0) {
                 uint64_t rel = cur > es.base_abs ? cur - es.base_abs : 0;
                 if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
@@ -2004,7 +2011,7 @@ __global__ void __launch_bounds__(AM_WAVE)
 am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_t rank, uint32_t cap,
                  uint64_t base_abs, uint32_t *__restrict__ cur0_out, uint32_t *__restrict__ flags,
                  uint64_t *__restrict__ exit_out, am_shard_exit *__restrict__ header, const uint64_t *__restrict__ carry,
-                 const uint64_t *__restrict__ cur_in)
+                 const uint64_t *__restrict__ cur_in, uint64_t *__restrict__ carry_out)
 {
     if (blockIdx.x != 0) return;
     if (header) {
@@ -2013,7 +2020,7 @@ am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_
     }
     uint32_t bad = 0;
     uint64_t leave = 0;
-    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad, &leave, cur_in);
+    const uint64_t cur = am_shard_entry_wave(msgs, world, rank, cap, (int)(threadIdx.x & (AM_WAVE - 1)), &bad, &leave, cur_in, carry_out);
     if (threadIdx.x != 0) return;
     uint64_t rel = cur > base_abs ? cur - base_abs : 0;
     if (rel > 0xFFFFFFF0ull) rel = 0xFFFFFFF0ull;
@@ -2023,16 +2030,18 @@ am_k_shard_entry(const am_shard_exit *__restrict__ msgs, uint32_t world, uint32_
 }
 
 hipError_t am_launch_shard_entry(const am_shard_exit *msgs, uint32_t world, uint32_t rank, uint32_t cap, uint64_t base_abs,
-                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s, const uint64_t *cur_in)
+                                 uint32_t *cur0_out, uint32_t *flags, uint64_t *exit_out, hipStream_t s, const uint64_t *cur_in,
+                                 uint64_t *carry_out)
 {
     hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, msgs, world, rank, cap, base_abs, cur0_out, flags, exit_out,
-                       (am_shard_exit *)nullptr, (const uint64_t *)nullptr, cur_in);
+                       (am_shard_exit *)nullptr, (const uint64_t *)nullptr, cur_in, carry_out);
     return hipGetLastError();
 }
 hipError_t am_launch_shard_header(am_shard_exit *header, const uint64_t *carry, hipStream_t s)
 {
     hipLaunchKernelGGL(am_k_shard_entry, dim3(1), dim3(AM_WAVE), 0, s, (const am_shard_exit *)nullptr, 0u, 0u, 0u, (uint64_t)0,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, header, carry, (const uint64_t *)nullptr);
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, header, carry, (const uint64_t *)nullptr,
+                       (uint64_t *)nullptr);
     return hipGetLastError();
 }
 

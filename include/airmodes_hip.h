@@ -383,6 +383,17 @@ AM_API int am_shard_resolve_async(am_ctx *ctx, const am_shard_exit *msgs_dev, ui
  * enqueued so far (the counterpart of am_wait_for_stream) */
 AM_API int am_signal_stream(am_ctx *ctx, void *hip_stream);
 
+/* The resolve step in two halves (round 6: STEPS of the time-sharded receiver in flight -- the scan and the all-gather of step k + 1
+ * are enqueued before step k is resolved, so that the collectives of one step hide behind the kernels of the next).
+ * am_shard_resolve_submit only enqueues; am_shard_resolve_collect waits for the step's one completion ticket and hands the packets
+ * out (*redo as am_shard_resolve_async).  cur_in_dev (device word, may be NULL): where the scan left the LAST chunk of the step
+ * before, read when the entry is composed -- instead of the last rank's message header, which was written before that step was
+ * resolved.  carry_out_dev (device word, may be NULL, may be the same word): where the scan leaves THIS step's last chunk, composed
+ * by every rank for itself from everybody's tables -- the next step's cur_in. */
+AM_API int am_shard_resolve_submit(am_ctx *ctx, const am_shard_exit *msgs_dev, uint32_t world, uint32_t rank, uint64_t msg_cap,
+                                   const uint64_t *cur_in_dev, uint64_t *carry_out_dev);
+AM_API int am_shard_resolve_collect(am_ctx *ctx, am_packet *out, uint64_t cap, uint64_t *n_out, int *redo);
+
 /* ---- resampling in front of the path (python/radio.py:49-53) ------------------------------------------------
  * modes_radio resamples anything slower than 4 Msps to 4 Msps with pfb.arb_resampler_ccf before rx_path.  GNU Radio's
  * block and tap design are not in the reference tree (parity unpinned); this is the package's own 32-phase x 8-tap

@@ -91,3 +91,12 @@ def test_replicas_with_k_streams_each(emu_lib):
     d = run_bench("--gpus", "2", "--replicas", "--streams", "2", "--seconds", "0.008", "--no-cpu-baseline")
     assert d["n_gpus"] == 2 and d["parity"] is True and d["config"]["streams_per_scan"] == 2
     assert "x 2 streams per scan" in d["config"]["parallelism"] and "4 independent streams" in d["config"]["workload"]
+
+
+def test_gpus_2_steps_in_flight(emu_lib):
+    """--steps-in-flight: the time-sharded loop through PipelinedShardedReceiver (two contexts per rank, the scan of step k + 1
+    queued before step k is collected); same line, same parity verdicts."""
+    d = run_bench("--gpus", "2", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline", "--steps-in-flight", "--steps", "4")
+    assert d["n_gpus"] == 2 and d["sharded_steps_in_flight"] is True
+    assert d["parity"] is True and d["parity_detail"]["short_stream_two_steps_all_ranks"] is True and d["parity_detail"]["rank0_full_size"] is True
+    assert d["sharded_sync_steps"] == 0 and d["roofline"]["kernel_ms"] > 0

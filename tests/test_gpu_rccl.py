@@ -41,3 +41,48 @@ def test_rccl_runs_the_sharded_step_at_world_one(hip_lib, oracle_mod):
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("through_rccl", [True, False])
+def test_steps_in_flight_at_world_one(hip_lib, oracle_mod, through_rccl):
+    """PipelinedShardedReceiver on the device: step k + 1's tail exchange, scan and all-gather enqueued before step k is resolved --
+    through a world-1 "nccl" group (asynchronous all_gather_into_tensor / batch_isend_irecv on the receiver's own stream) and
+    without a group (the floor).  Six steps, twice == the oracle over the whole stream; a density jump in the second stream makes
+    a flagged step (repeated on the synchronous path while its successor is scanned)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import synth
+    from air_modes import _capi
+    from air_modes.sharded import PipelinedShardedReceiver
+    rate, n, steps = 64e6, 3_000_000, 6
+    if through_rccl:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29733", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        ctxs = [_capi.Context(rate, 7.0, True, device=0, lib=hip_lib) for _ in range(2)]
+        rx = PipelinedShardedReceiver(ctxs, 0, 1, n, device=dev, force_collectives=through_rccl)
+        assert rx.force == through_rccl
+        for lams in ([12000.0] * steps, [300.0, 300.0, 300.0, 40000.0, 300.0, 12000.0]):
+            iq = np.concatenate([synth.synth_capture(rate, n, lam, seed=6200 + k)[0] for k, lam in enumerate(lams)])
+            tags = [(0, 1000, 0.25), (n + 12345, 2000, 0.5)]
+            for tg in tags:
+                rx.set_rx_time(*tg)
+            out = []
+            for k in range(steps):
+                rx.chunk.copy_(torch.from_numpy(iq[k * n:(k + 1) * n].copy().view(np.float32)).to(dev))
+                rx.submit(flush=(k == steps - 1))
+                if k > 0:
+                    out.append(rx.collect())
+            out.append(rx.collect())
+            want = oracle_mod.demod(iq, rate, rx_time=tags)
+            got = np.concatenate(out)
+            assert len(want) > 100 and got.tobytes() == want.tobytes(), (len(got), len(want), lams)
+            print("steps in flight (%s): %d packets, %d steps on the synchronous path so far"
+                  % ("rccl world 1" if through_rccl else "no group", len(got), rx.sync_steps))
+        rx.close()
+        for c in ctxs:
+            c.close()
+    finally:
+        if through_rccl:
+            dist.destroy_process_group()

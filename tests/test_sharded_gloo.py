@@ -198,3 +198,96 @@ def test_time_sharded_receiver_is_a_stream(emu_lib, oracle_mod, world, small_tab
     edges = [k * world * n_per_rank for k in range(1, STREAM_STEPS)]
     assert dcblock or any(any(int(s) < e <= int(s) + 240 * spc for e in edges) for s in want["sample"]), "no burst across a step boundary"
     assert np.array_equal(got, want)
+
+
+PIPE_STEPS = 5
+
+
+def _worker_pipelined(rank, world, port, ret, small_table, rate, n_per_rank, dcblock, seed, force, lam_by_step):
+    for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from air_modes import _capi
+    from air_modes.sharded import PipelinedShardedReceiver
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        if lam_by_step is not None:
+            os.environ["AIRMODES_SPEC_FLOOR"] = "8"
+        iq = _pipe_capture(rate, world, n_per_rank, seed, lam_by_step)
+        lib = _capi.Library(conftest.EMU_LIB)
+        ctxs = [_capi.Context(rate, 7.0, True, use_dcblock=dcblock, lib=lib) for _ in range(2)]
+        rx = PipelinedShardedReceiver(ctxs, rank, world, n_per_rank, small_table=small_table, force_collectives=force)
+        out = []
+        for stream in range(2):                                   # (two streams through the same receiver: a flush resets it)
+            rx.set_rx_time(0, 1000, 0.25)
+            rx.set_rx_time(world * n_per_rank + 12345, 2000, 0.5)
+            for k in range(PIPE_STEPS):
+                a = (k * world + rank) * n_per_rank
+                rx.chunk.copy_(torch.from_numpy(iq[a:a + n_per_rank].copy().view(np.float32)))
+                rx.submit(flush=(k == PIPE_STEPS - 1))
+                if k > 0:
+                    out.append(rx.collect().tobytes())
+                    assert rx.in_flight() == 1
+            out.append(rx.collect().tobytes())
+            assert rx.in_flight() == 0 and rx.k == 0
+        ret[rank] = out
+        ret["sync_%d" % rank] = rx.sync_steps
+        ret["forced_%d" % rank] = (rx.force, rx.host_us["all_gather"] > 0.0)
+    finally:
+        dist.destroy_process_group()
+
+
+def _pipe_capture(rate, world, n_per_rank, seed, lam_by_step):
+    import synth
+    if lam_by_step is None:
+        return synth.synth_capture(rate, PIPE_STEPS * world * n_per_rank, 9000.0, seed=seed)[0]
+    step = world * n_per_rank
+    parts = [synth.synth_capture(rate, step, lam, seed=seed + k)[0] for k, lam in enumerate(lam_by_step)]
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("world,small_table,rate,dcblock,force", [(1, 512, 20e6, False, True), (1, 512, 20e6, False, False),
+                                                                  (2, 512, 20e6, False, False), (3, 512, 4e6, True, False),
+                                                                  (2, 1, 20e6, False, False), (8, 512, 4e6, False, False)])
+def test_steps_in_flight_are_the_same_stream(emu_lib, oracle_mod, world, small_table, rate, dcblock, force):
+    """PipelinedShardedReceiver: the scan + all-gather of step k + 1 enqueued before step k is resolved; the position the scan
+    starts a step from lives in a device word the resolve steps hand on (cur_in / carry_out of am_shard_resolve_submit).  Five
+    steps, twice (the flush resets the receiver) == the oracle over the whole capture; with one-entry messages every step is
+    flagged and repeated on the synchronous path -- with its successor already scanned."""
+    from air_modes import _capi
+    n_per_rank, seed = (150000, 2722) if rate == 20e6 else (60000, 2720)
+    port = 29711 + world + (7 if small_table == 1 else 0) + (20 if force else 0) + (40 if dcblock else 0)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_pipelined, args=(world, port, ret, small_table, rate, n_per_rank, dcblock, seed, force, None), nprocs=world, join=True)
+    syncs = [ret["sync_%d" % r] for r in range(world)]
+    # (one-entry messages: every step whose table has more than one entry on some rank is flagged -- all but a few)
+    assert len(set(syncs)) == 1 and (syncs[0] >= PIPE_STEPS if small_table == 1 else syncs[0] == 0), syncs
+    if force:
+        assert ret["forced_0"] == (True, True)
+    iq = _pipe_capture(rate, world, n_per_rank, seed, None)
+    want = oracle_mod.demod(iq, rate, use_dcblock=dcblock, rx_time=[(0, 1000, 0.25), (world * n_per_rank + 12345, 2000, 0.5)])
+    assert len(want) > 50
+    for stream in range(2):
+        got = np.concatenate([np.frombuffer(ret[r][stream * PIPE_STEPS + k], _capi.PACKET_DTYPE)
+                              for k in range(PIPE_STEPS) for r in range(world)])
+        assert got.tobytes() == want.tobytes(), (stream, len(got), len(want))
+
+
+def test_a_flagged_step_in_flight_is_everybodys_redo(emu_lib, oracle_mod):
+    """A quiet sky, then ONE busy step (the scan outgrows the capacity extrapolated from the quiet one on every rank that meets it),
+    then quiet again: the busy step is repeated synchronously by every rank while its successor is already scanned; the packets
+    stay the single-stream packets."""
+    from air_modes import _capi
+    world, rate, n_per_rank = 2, 20e6, 150000
+    lam = [300.0, 300.0, 30000.0, 300.0, 3000.0]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_pipelined, args=(world, 29791, ret, 512, rate, n_per_rank, False, 41, False, lam), nprocs=world, join=True)
+    syncs = [ret["sync_%d" % r] for r in range(world)]
+    assert len(set(syncs)) == 1 and syncs[0] >= 1, syncs
+    iq = _pipe_capture(rate, world, n_per_rank, 41, lam)
+    want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25), (world * n_per_rank + 12345, 2000, 0.5)])
+    got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for k in range(PIPE_STEPS) for r in range(world)])
+    assert len(want) > 50 and got.tobytes() == want.tobytes()
