@@ -132,6 +132,8 @@ class Library(object):
         L.am_pipe_destroy.argtypes = [vp]
         L.am_pipe_submit.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
         L.am_pipe_collect.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.am_pipe_submit_multi.argtypes = [vp, vp, u32, vp, u32]
+        L.am_pipe_multi_counts.argtypes = [vp, vp, u32]
         L.am_pipe_in_flight.argtypes = [vp]
         L.am_pipe_depth.argtypes = [vp]
         L.am_pipe_last_error.restype = C.c_char_p
@@ -652,7 +654,24 @@ class Pipe(object):
             if self._held:
                 self._held.popleft()
         self._chk(rc)
-        return self._out[:int(got.value)].copy()
+        return Context._received(self._out, got.value)
+
+    def submit_multi_device(self, ptr, lengths, zero_gaps=False):
+        """K whole streams, packed on the device (Context.multi_pack's layout), as ONE scan in flight (am_pipe_submit_multi)."""
+        n = np.ascontiguousarray(lengths, np.uint64)
+        flags = AM_F_DEVICE_IN | (AM_F_ZERO_GAPS if zero_gaps else 0)
+        self._chk(self.lib.L.am_pipe_submit_multi(self._h, int(ptr), n.size, n.ctypes.data, flags))
+        self._held.append(("multi", n.size))
+
+    def collect_multi(self):
+        """The oldest scan in flight, submitted by submit_multi_device: K packet arrays."""
+        k = self._held[0][1] if self._held and isinstance(self._held[0], tuple) else 0
+        pk = self.collect()
+        cnt = np.zeros(k, np.uint64)
+        self._chk(self.lib.L.am_pipe_multi_counts(self._h, cnt.ctypes.data, cnt.size))
+        edges = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        assert int(edges[-1]) == len(pk)
+        return [pk[edges[j]:edges[j + 1]] for j in range(k)]
 
     def last_kernel_ms(self):
         return float(self.lib.L.am_pipe_last_kernel_ms(self._h))
@@ -716,7 +735,7 @@ class StreamPipe(object):
             self._out = np.zeros(int(got.value) + 1024, PACKET_DTYPE)
             rc = self.lib.L.am_spipe_collect(self._h, self._out.ctypes.data, len(self._out), C.byref(got))
         self._chk(rc)
-        return self._out[:int(got.value)].copy()
+        return Context._received(self._out, got.value)
 
     def last_kernel_ms(self):
         return float(self.lib.L.am_spipe_last_kernel_ms(self._h))

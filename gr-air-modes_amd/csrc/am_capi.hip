@@ -117,6 +117,7 @@ struct am_ctx {
     // tt_dev mirrors them on the device for the extraction kernel
     std::vector<am_time_tag> tt;
     DevBuf tt_dev;
+    am_time_tag *pin_tt = nullptr;   // pinned staging copy of the K streams' tags (multi_begin)
 
     // stream state (absolute sample indices)
     // K independent streams in one scan (am_process_multi): where stream j starts in the scanned buffer, the last position it may
@@ -1039,6 +1040,7 @@ void am_destroy(am_ctx *c)
     if (c->pin_tags) (void)hipHostFree(c->pin_tags);
     if (c->pin_scalars) (void)hipHostFree(c->pin_scalars);
     if (c->pin_exit) (void)hipHostFree(c->pin_exit);
+    if (c->pin_tt) (void)hipHostFree(c->pin_tt);
     for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->ev_wait) (void)hipEventDestroy(c->ev_wait);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1366,8 +1368,12 @@ static int multi_begin(am_ctx *c, float *iq, uint32_t k, const uint64_t *n, uint
         c->tt.push_back(t);
     }
     ENSURE(c, c->tt_dev, AM_MAX_TIME_TAGS * sizeof(am_time_tag));
-    // (a plain copy: the context is idle -- its last scan was collected -- so nothing on its stream still reads the table)
-    HIPCHK(c, hipMemcpy(c->tt_dev.p, c->tt.data(), c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice));
+    // The context is idle -- its last scan was collected -- so nothing on its stream still reads the table or the staging copy.
+    // Not a plain hipMemcpy: that one waits for the OTHER contexts' scans in flight (measured: am_pipe_submit_multi took a whole
+    // scan's time, 360-410 us, on the host: tools/gpu_kstream_host_share.py)
+    if (!c->pin_tt) HIPCHK(c, hipHostMalloc((void **)&c->pin_tt, AM_MAX_TIME_TAGS * sizeof(am_time_tag), hipHostMallocDefault));
+    memcpy(c->pin_tt, c->tt.data(), c->tt.size() * sizeof(am_time_tag));
+    HIPCHK(c, hipMemcpyAsync(c->tt_dev.p, c->pin_tt, c->tt.size() * sizeof(am_time_tag), hipMemcpyHostToDevice, c->stream));
     // the layout is put in force LAST: a failure above leaves the context a plain receiver (a stale layout would make the
     // next am_process_iq sort its packets into streams that are not there)
     c->multi_off = off;
@@ -2554,6 +2560,32 @@ int am_pipe_submit(am_pipe *p, const float *iq, uint64_t n, uint32_t flags)
     const int rc = am_submit_iq(c, iq, n, flags | AM_F_FLUSH);
     if (rc == AM_OK) p->inflight++;
     else p->last_fail = c;
+    return rc;
+}
+
+// K whole streams in ONE scan of the pipe's next free context (am_submit_multi); collected like any other batch, the packets stream by
+// stream; am_pipe_multi_counts then says how many each stream of the scan collected LAST got.
+int am_pipe_submit_multi(am_pipe *p, float *iq, uint32_t k, const uint64_t *n, uint32_t flags)
+{
+    if (!p) return AM_EINVAL;
+    if (p->inflight == p->sub.size()) {
+        p->last_fail = nullptr;
+        snprintf(p->err, sizeof(p->err), "every context of the pipe has a batch in flight: collect the oldest one first");
+        return AM_ECAPACITY;
+    }
+    am_ctx *c = p->sub[(p->head + p->inflight) % p->sub.size()];
+    const int rc = am_submit_multi(c, iq, k, n, flags);
+    if (rc == AM_OK) p->inflight++;
+    else p->last_fail = c;
+    return rc;
+}
+
+int am_pipe_multi_counts(am_pipe *p, uint64_t *count, uint32_t k)
+{
+    if (!p || p->sub.empty()) return AM_EINVAL;
+    am_ctx *c = p->sub[(p->head + p->sub.size() - 1) % p->sub.size()];   // the batch collected last
+    const int rc = am_multi_counts(c, count, k);
+    if (rc != AM_OK) p->last_fail = c;
     return rc;
 }
 

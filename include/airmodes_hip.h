@@ -159,6 +159,11 @@ AM_API int am_pipe_in_flight(const am_pipe *pipe);
 AM_API int am_pipe_submit(am_pipe *pipe, const float *iq, uint64_t n_complex, uint32_t flags);
 /* packets of the OLDEST batch in flight; AM_EINVAL when there is none */
 AM_API int am_pipe_collect(am_pipe *pipe, am_packet *out, uint64_t cap, uint64_t *n_out);
+/* K whole streams in ONE scan of the next free context (am_submit_multi's arguments); am_pipe_collect hands the packets out stream by
+ * stream, am_pipe_multi_counts the number each stream of the scan collected LAST got.  (rx_path.py:35: one receiver chain per
+ * stream -- here eight of them share a scan, and several scans are in flight behind one handle.) */
+AM_API int am_pipe_submit_multi(am_pipe *pipe, float *iq, uint32_t k, const uint64_t *n_complex, uint32_t flags);
+AM_API int am_pipe_multi_counts(am_pipe *pipe, uint64_t *count, uint32_t k);
 AM_API const char *am_pipe_last_error(const am_pipe *pipe);
 AM_API float am_pipe_last_kernel_ms(const am_pipe *pipe);   /* dominant-kernel time of the batch collected last */
 

@@ -361,6 +361,33 @@ def check_multi_streams(lib, rate, lengths, lam, seed, thr=7.0, pmf=True):
     assert all(g.tobytes() == w.tobytes() for g, w in zip(gb, wb)) and len(gb) == len(wb)
     assert ctx.process_iq(streams[0], flush=True).tobytes() == want[0].tobytes()
     ctx2.close()
+    # scans of K streams in flight behind ONE handle (am_pipe_submit_multi / am_pipe_collect / am_pipe_multi_counts): the two
+    # layouts alternately, three in flight, mixed with a plain single-stream batch
+    emulated = bool(getattr(lib, "emulated", False))
+    if emulated:
+        keep = [np.ascontiguousarray(bufa), np.ascontiguousarray(bufb), np.ascontiguousarray(streams[0]).view(np.float32)]
+        ptrs = [k.ctypes.data for k in keep]
+    else:
+        import torch
+        keep = [torch.from_numpy(np.ascontiguousarray(x).view(np.float32).copy()).cuda() for x in (bufa, bufb, streams[0])]
+        ptrs = [k.data_ptr() for k in keep]
+    pipe = _capi.Pipe(rate, thr, pmf, device=(-1 if emulated else 0), depth=3, lib=lib)
+    order = [0, 1, 2, 0, 1, 1, 0]
+    outs = []
+    for i, which in enumerate(order):
+        if pipe.in_flight() == pipe.depth():
+            outs.append(pipe.collect_multi() if isinstance(pipe._held[0], tuple) else [pipe.collect()])
+        if which == 2:
+            pipe.submit_device(ptrs[2], len(streams[0]))
+        else:
+            pipe.submit_multi_device(ptrs[which], (na, nb_)[which])
+    while pipe.in_flight():
+        outs.append(pipe.collect_multi() if isinstance(pipe._held[0], tuple) else [pipe.collect()])
+    assert len(outs) == len(order)
+    for which, got_ in zip(order, outs):
+        w_ = (want[:half], wb, want[:1])[which]
+        assert len(got_) == len(w_) and all(g.tobytes() == w.tobytes() for g, w in zip(got_, w_)), "scan of layout %d in the pipe differs" % which
+    pipe.close()
     ctx.close()
     return sum(len(w) for w in want)
 
