@@ -1,8 +1,9 @@
-# kernel timeline of the time-sharded step through a world-1 RCCL group:   gpurun -- 'bash tools/gpu_step_timeline.sh'   (BENCH_ARGS: extra flags)
+# kernel timeline of three steps under rocprofv3 --kernel-trace:   gpurun -- 'bash tools/gpu_step_timeline.sh'
+# (default: the time-sharded step through a world-1 RCCL group; BENCH_ARGS="" = the plain single-GPU step; durations and gaps under the tracer are inflated)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/steptl
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-extra --force-sharded --backend nccl ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-extra ${BENCH_ARGS---force-sharded --backend nccl} > $OUT/bench.json 2> $OUT/bench.err
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import csv, glob
