@@ -585,8 +585,16 @@ def main():
                 dist.barrier()
             dt = time.perf_counter() - t0
         else:
-            rx = ShardedReceiver(ctx, rank, world, n, device=dev, force_collectives=forced)
-            rx.chunk.copy_(torch.from_numpy(iq.view(np.float32)))     # resident in HBM before the timed region
+            # three distinct seconds of signal in three halo'd buffers, used in turn (1.5 GB per rank: the 256 MiB Infinity Cache
+            # cannot serve a step's samples from the step before -- VERDICT r5 weak #6); `iq` is the first of them
+            NBUF = 2 if args.emu else 3
+            rx = ShardedReceiver(ctx, rank, world, n, device=dev, force_collectives=forced, buffers=NBUF)
+            for b in range(NBUF):
+                rx._select(b)
+                x = iq if b == 0 else synth.synth_capture(rate, n, lam, seed + rank + 1000 * b)[0]
+                rx.chunk.copy_(torch.from_numpy(x.view(np.float32)))     # resident in HBM before the timed region
+            rx._select(0)
+            extra["sharded_distinct_chunk_buffers"] = NBUF
             sync()
             for _ in range(max(args.warmup, 2)):
                 pk = rx.step()
@@ -651,6 +659,7 @@ def main():
             rx.chunk.copy_(torch.from_numpy(iq.view(np.float32)))
         else:
             rx.reset()
+            rx._select(0)                                     # (the buffer that holds `iq`)
         pk0 = rx.step(flush=True)
         parity_rank0 = None
         if rank == 0:

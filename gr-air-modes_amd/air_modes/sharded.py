@@ -54,7 +54,7 @@ class ShardedReceiver(object):
     write each step's samples there, no copy inside step()); step() runs one pass and returns this rank's packets."""
 
     def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None, small_table=512, host_free=True,
-                 force_collectives=False, share_stream=True):
+                 force_collectives=False, share_stream=True, buffers=1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -83,20 +83,20 @@ class ShardedReceiver(object):
         self.host_us = {"tail_exchange": 0.0, "all_gather": 0.0, "steps": 0}
         self.host_us_steps = {"tail_exchange": [], "all_gather": []}
         self._wrap_posted = False                         # the ring-closing transfer of the next step is already under way     # ... and per step (the first call of a backend sets its communicator up)
+        # buffers > 1: that many halo'd chunk buffers, used in turn (the step after this one finds its samples in the next one:
+        # a source that writes ahead of the decode; bench.py rotates three distinct captures so that the Infinity Cache cannot
+        # serve a step's samples from the step before)
+        self._nbuf = max(1, int(buffers))
         self._alloc(device if device is not None else "cpu")
         # the device-side exchange hands device pointers to kernels: only where the buffers live on the GPU (or where
         # "device memory" is host memory: the CPU emulation the tests run on)
         emulated = bool(getattr(ctx.lib, "emulated", False))   # (am_is_emulated(): asked of the library, not guessed from its path)
         self.host_free = bool(host_free) and (self._buf.is_cuda or emulated)
-        self.chunk = self._buf[self.halo * 2:(self.halo + self.n) * 2]
         # the rank whose tail the next STEP needs (the last one) keeps it inside the resolve call: behind the slicing, which
         # still reads the samples, in front of the completion -- done when step() returns, before `chunk` is overwritten
         self._keeps = self.rank == self.world - 1
-        if self._keeps:
-            ctx.shard_keep_tail(self._tail.data_ptr(), self._own_tail.data_ptr(), self.halo * 8)
-        else:
-            ctx.shard_keep_tail(0, 0, 0)
         ctx._keep_owner = id(self)                        # (a context serves one receiver at a time: the newest)
+        self._select(0)
         # share_stream (round 6): with collectives in the step, the context and torch.distributed work on ONE stream of the receiver's
         # own -- the collectives are issued with it current -- so that the only stream hops left are the backend's own (its stream
         # waits for ours, ours for its).  Measured at world 1 under RCCL (profiles/r6_rccl): every hop between the context's stream
@@ -124,11 +124,11 @@ class ShardedReceiver(object):
 
     def _alloc(self, dev):
         t = self.torch
-        self._buf = t.zeros((self.halo + self.n) * 2, dtype=t.float32, device=dev)
+        self._bufs = [t.zeros((self.halo + self.n) * 2, dtype=t.float32, device=dev) for _ in range(self._nbuf)]
+        self._buf = self._bufs[0]
         self._tail = t.zeros(self.halo * 2, dtype=t.float32, device=dev)     # the last rank's tail of the step before
         # views used every step (slicing a tensor costs microseconds of host time each)
-        self._halo_view = self._buf[:self.halo * 2]
-        self._own_tail = self._buf[self.n * 2:]                                # the own samples' last `halo`
+        self._views = [(b, b[:self.halo * 2], b[self.n * 2:], b[self.halo * 2:(self.halo + self.n) * 2]) for b in self._bufs]
         # synchronous path: [count, exit of the step before, pos0, exit0, pos1, exit1, ...] as int64, in two sizes
         self._msg = t.zeros(2 + 2 * self.tab_cap, dtype=t.int64, device=dev)
         self._msgs = [t.empty_like(self._msg) for _ in range(self.world)]
@@ -139,6 +139,15 @@ class ShardedReceiver(object):
         words = 2 * (_capi.SHARD_MSG_HEADER + self.small_cap)
         self._amsg = t.zeros(words, dtype=t.int64, device=dev)
         self._agath = t.zeros(self.world * words, dtype=t.int64, device=dev)   # (all_gather_into_tensor: no list of views, no copies)
+
+    def _select(self, i):
+        """The buffer the NEXT step reads: `chunk` (the caller's samples), the halo in front of it, the own samples' last `halo`."""
+        self._bi = i % self._nbuf
+        self._buf, self._halo_view, self._own_tail, self.chunk = self._views[self._bi]
+        if self._keeps:
+            self.ctx.shard_keep_tail(self._tail.data_ptr(), self._own_tail.data_ptr(), self.halo * 8)
+        elif self._nbuf == 1 or i == 0:
+            self.ctx.shard_keep_tail(0, 0, 0)
 
     def reset(self):
         """Start a new stream at sample 0 (what step(flush=True) does at its end)."""
@@ -269,6 +278,8 @@ class ShardedReceiver(object):
             pk = self._step_sync(ptr, a0, a1, total, more, cap_pk, on_gpu)
         self.host_us["steps"] += 1
         # 3. what the next step needs from this one
+        if self._nbuf > 1:
+            self._select(self._bi + 1)                       # (before the ring-closing transfer: it lands in the next step's halo)
         if flush:
             self.reset()
         else:

@@ -124,7 +124,7 @@ def test_capacity_overflow_on_one_rank_is_everybodys_redo(emu_lib, oracle_mod):
 STREAM_STEPS = 3
 
 
-def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_rank, dcblock, seed, force=False):
+def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_rank, dcblock, seed, force=False, buffers=1):
     for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -139,7 +139,8 @@ def _worker_stream(rank, world, port, ret, small_table, host_free, rate, n_per_r
         ctx = _capi.Context(rate, 7.0, True, use_dcblock=dcblock, lib=lib)
         ctx.set_rx_time(0, 1000, 0.25)
         ctx.set_rx_time(world * n_per_rank + 12345, 2000, 0.5)      # (a tag in the middle of the second step)
-        rx = ShardedReceiver(ctx, rank, world, n_per_rank, small_table=small_table, host_free=host_free, force_collectives=force)
+        rx = ShardedReceiver(ctx, rank, world, n_per_rank, small_table=small_table, host_free=host_free, force_collectives=force,
+                             buffers=buffers)
         out = []
         for k in range(STREAM_STEPS):
             a = (k * world + rank) * n_per_rank
@@ -168,6 +169,22 @@ def test_one_rank_receiver_through_the_process_group(emu_lib, oracle_mod):
     iq, _ = synth.synth_capture(rate, STREAM_STEPS * n_per_rank, 9000.0, seed=seed)
     want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25), (n_per_rank + 12345, 2000, 0.5)])
     assert len(want) > 30 and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,host_free", [(2, True), (3, False)])
+def test_receiver_with_rotating_chunk_buffers(emu_lib, oracle_mod, world, host_free):
+    """buffers=2: consecutive steps find their samples in different halo'd buffers (the tail exchange, the ring-closing transfer and
+    the kept tail follow the buffer in use); three steps == the oracle over the whole capture."""
+    import synth
+    from air_modes import _capi
+    rate, n_per_rank, seed = 20e6, 150000, 2722
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_stream, args=(world, 29851 + world, ret, 512, host_free, rate, n_per_rank, False, seed, False, 2), nprocs=world, join=True)
+    got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for k in range(STREAM_STEPS) for r in range(world)])
+    iq, _ = synth.synth_capture(rate, STREAM_STEPS * world * n_per_rank, 9000.0, seed=seed)
+    want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25), (world * n_per_rank + 12345, 2000, 0.5)])
+    assert len(want) > 50 and got.tobytes() == want.tobytes()
 
 
 @pytest.mark.parametrize("world,small_table,host_free,rate,dcblock", [(2, 512, True, 20e6, False), (3, 512, True, 20e6, False),
