@@ -54,7 +54,7 @@ class ShardedReceiver(object):
     write each step's samples there, no copy inside step()); step() runs one pass and returns this rank's packets."""
 
     def __init__(self, ctx, rank, world, n_per_rank, group=None, device=None, small_table=512, host_free=True,
-                 force_collectives=False, share_stream=True, buffers=1):
+                 force_collectives=False, share_stream=True, buffers=1, lookahead=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -87,6 +87,12 @@ class ShardedReceiver(object):
         # a source that writes ahead of the decode; bench.py rotates three distinct captures so that the Infinity Cache cannot
         # serve a step's samples from the step before)
         self._nbuf = max(1, int(buffers))
+        # lookahead (round 6): ONE collective per step.  The all-gather that carries the exit tables also carries the samples the NEXT
+        # step needs in front of its chunks -- every rank appends the last `halo` samples of its next chunk (the last rank: of its
+        # current one, which closes the ring) -- so the next step starts with a device copy instead of a send / receive.  Needs the
+        # next step's samples in the next buffer when step(ahead=True) is called (buffers >= 2; a one-rank receiver needs nothing).
+        self.lookahead = bool(lookahead)
+        self._halo_ready = False
         self._alloc(device if device is not None else "cpu")
         # the device-side exchange hands device pointers to kernels: only where the buffers live on the GPU (or where
         # "device memory" is host memory: the CPU emulation the tests run on)
@@ -139,6 +145,16 @@ class ShardedReceiver(object):
         words = 2 * (_capi.SHARD_MSG_HEADER + self.small_cap)
         self._amsg = t.zeros(words, dtype=t.int64, device=dev)
         self._agath = t.zeros(self.world * words, dtype=t.int64, device=dev)   # (all_gather_into_tensor: no list of views, no copies)
+        if self.lookahead:
+            ext = words + self.halo                      # (halo complex samples = halo int64 words)
+            self._words = words
+            self._amsg_x = t.zeros(ext, dtype=t.int64, device=dev)
+            self._amsg_x_tail = self._amsg_x[words:].view(t.float32)
+            self._agath_x = t.zeros(self.world * ext, dtype=t.int64, device=dev)
+            rows = self._agath_x.view(self.world, ext)
+            self._gathered_tables = rows[:, :words]
+            self._gathered_tails = [rows[r, words:].view(t.float32) for r in range(self.world)]
+            self._tables_dense = self._agath.view(self.world, words)
 
     def _select(self, i):
         """The buffer the NEXT step reads: `chunk` (the caller's samples), the halo in front of it, the own samples' last `halo`."""
@@ -149,11 +165,17 @@ class ShardedReceiver(object):
         elif self._nbuf == 1 or i == 0:
             self.ctx.shard_keep_tail(0, 0, 0)
 
+    @property
+    def chunk_ahead(self):
+        """buffers >= 2: where the samples of the step AFTER the next one to run go (written before step(ahead=True))."""
+        return self._views[(self._bi + 1) % self._nbuf][3]
+
     def reset(self):
         """Start a new stream at sample 0 (what step(flush=True) does at its end)."""
         self.ctx.reset()
         self.k = 0
         self._wrap_posted = False
+        self._halo_ready = False
 
     def _exchange_p2p(self, ops):
         t0 = time.perf_counter()
@@ -194,17 +216,18 @@ class ShardedReceiver(object):
         self.dist.all_gather(msgs_dev, msg_dev, group=self.group)
         return self.torch.stack(msgs_dev).cpu().numpy()
 
-    def step(self, flush=False):
+    def step(self, flush=False, ahead=False):
         """One pass over the samples currently in `chunk`: the next world*n samples of the stream.  flush: they are the
-        stream's last (every rank must say so).  Returns this rank's accepted packets."""
+        stream's last (every rank must say so).  ahead (with lookahead=True, every rank alike): the NEXT step's samples are
+        already in the next buffer.  Returns this rank's accepted packets."""
         if self._tstream is not None:
             # the receiver's stream: behind whoever filled `chunk` on the caller's current stream, then current for the whole step
             self._tstream.wait_stream(self.torch.cuda.current_stream(self._buf.device))
             with self.torch.cuda.stream(self._tstream):
-                return self._step(flush)
-        return self._step(flush)
+                return self._step(flush, ahead)
+        return self._step(flush, ahead)
 
-    def _step(self, flush):
+    def _step(self, flush, ahead=False):
         t, dist = self.torch, self.dist
         n, world, rank, halo, H = self.n, self.world, self.rank, self.halo, self.hold
         buf, own = self._buf, self.chunk
@@ -214,7 +237,13 @@ class ShardedReceiver(object):
         # 1. the samples in front of the own ones.  The transfer that closes the ring -- the last rank's tail of the step BEFORE, to
         # rank 0 -- was posted at the end of that step (round 6: _post_wrap), off this step's critical path; what is left here are the
         # transfers inside the step, from every rank to the next
-        if world > 1 or (self.force and not self.tail_by_gather):
+        look = self.lookahead and self.host_free and (world > 1 or self.force)
+        prefetched = look and self._halo_ready
+        self._halo_ready = False
+        if prefetched:
+            # the samples in front of the own ones travelled with the last step's exit tables
+            self._halo_view.copy_(self._gathered_tails[(rank - 1) % world])
+        elif world > 1 or (self.force and not self.tail_by_gather):
             ops = []
             if not last:
                 ops.append(dist.P2POp(dist.isend, self._own_tail, rank + 1, self.group))
@@ -227,7 +256,9 @@ class ShardedReceiver(object):
             self._wrap_posted = False
             if ops:
                 self._exchange_p2p(ops)
-        if self.force and self.tail_by_gather and self.k > 0:
+        if prefetched:
+            pass
+        elif self.force and self.tail_by_gather and self.k > 0:
             tc = time.perf_counter()
             dist.all_gather_into_tensor(self._halo_view, self._tail, group=self.group)     # world 1: the gathered tensor IS the tail
             self.host_us["tail_exchange"] += (time.perf_counter() - tc) * 1e6
@@ -254,12 +285,23 @@ class ShardedReceiver(object):
         cap_pk = max(64, n // 2000 + 64)
         pk = None
         if self.host_free:
-            self.ctx.shard_scan_async(ptr, a0, a1, total, self._amsg.data_ptr(), self.small_cap, device_in=on_gpu, more=more)
+            carry_tails = look and ((ahead and not flush and self._nbuf > 1) or world == 1) and not flush
+            amsg = self._amsg_x if look else self._amsg
+            self.ctx.shard_scan_async(ptr, a0, a1, total, amsg.data_ptr(), self.small_cap, device_in=on_gpu, more=more)
             if world > 1 or self.force:
+                if carry_tails:
+                    # what the next step needs in front of its chunks: the last rank's tail of THIS step (the ring closes), everybody
+                    # else's tail of the NEXT one
+                    self._amsg_x_tail.copy_(self._own_tail if last else self._views[(self._bi + 1) % self._nbuf][2])
                 if on_gpu and not shared:
                     self.ctx.signal_stream(cur)              # the collective waits (on the device) for the table
                 tc = time.perf_counter()
-                dist.all_gather_into_tensor(self._agath, self._amsg, group=self.group)
+                if look:
+                    dist.all_gather_into_tensor(self._agath_x, self._amsg_x, group=self.group)
+                    self._tables_dense.copy_(self._gathered_tables)      # (the resolve step reads the tables at their own stride)
+                    self._halo_ready = carry_tails
+                else:
+                    dist.all_gather_into_tensor(self._agath, self._amsg, group=self.group)
                 self.host_us["all_gather"] += (time.perf_counter() - tc) * 1e6
                 self.host_us_steps["all_gather"].append((time.perf_counter() - tc) * 1e6)
                 if on_gpu and not shared:
@@ -284,7 +326,8 @@ class ShardedReceiver(object):
             self.reset()
         else:
             self.k += 1                                      # (the last rank's tail was kept inside the resolve call)
-            self._post_wrap()
+            if not self._halo_ready:
+                self._post_wrap()
         return pk
 
     def _step_sync(self, ptr, a0, a1, total, more, cap_pk, on_gpu):

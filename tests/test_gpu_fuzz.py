@@ -148,4 +148,5 @@ def _one_case(hip_lib, d):
 def test_the_box_was_used(hip_lib):
     """(runs after the fuzz in file order) a box that ran no case at all -- an import error swallowed, a library that refuses every
     call -- would be a silent pass"""
+    print("device fuzz: %d random cases inside the %g s box" % (_ran[0], BOX_SECONDS))
     assert _ran[0] >= 5, "only %d random cases ran inside the %g s box" % (_ran[0], BOX_SECONDS)

@@ -86,3 +86,35 @@ def test_steps_in_flight_at_world_one(hip_lib, oracle_mod, through_rccl):
     finally:
         if through_rccl:
             dist.destroy_process_group()
+
+
+def test_one_collective_per_step_through_rccl(hip_lib, oracle_mod):
+    """ShardedReceiver(lookahead=True) at world 1 through RCCL: the all_gather_into_tensor of the exit table carries the tail that
+    closes the ring; no send / receive at all.  Four steps over three rotating buffers == the oracle over the whole stream."""
+    import torch
+    import torch.distributed as dist
+    import synth
+    from air_modes import _capi
+    from air_modes.sharded import ShardedReceiver
+    rate, n, steps = 64e6, 3_000_000, 4
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29735", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        iq, _ = synth.synth_capture(rate, steps * n, 12000.0, seed=6363)
+        ctx = _capi.Context(rate, 7.0, True, device=0, lib=hip_lib)
+        ctx.set_rx_time(0, 1000, 0.25)
+        rx = ShardedReceiver(ctx, 0, 1, n, device=dev, force_collectives=True, buffers=3, lookahead=True)
+        rx.chunk.copy_(torch.from_numpy(iq[:n].copy().view(np.float32)).to(dev))
+        out = []
+        for k in range(steps):
+            if k + 1 < steps:
+                rx.chunk_ahead.copy_(torch.from_numpy(iq[(k + 1) * n:(k + 2) * n].copy().view(np.float32)).to(dev))
+            out.append(rx.step(flush=(k == steps - 1), ahead=(k + 1 < steps)))
+        want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25)])
+        got = np.concatenate(out)
+        assert len(want) > 100 and got.tobytes() == want.tobytes()
+        assert rx.sync_steps == 0 and len(rx.host_us_steps["tail_exchange"]) == 0 and len(rx.host_us_steps["all_gather"]) == steps
+        rx.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()

@@ -308,3 +308,69 @@ def test_a_flagged_step_in_flight_is_everybodys_redo(emu_lib, oracle_mod):
     want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25), (world * n_per_rank + 12345, 2000, 0.5)])
     got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for k in range(PIPE_STEPS) for r in range(world)])
     assert len(want) > 50 and got.tobytes() == want.tobytes()
+
+
+LOOK_STEPS = 5
+
+
+def _worker_lookahead(rank, world, port, ret, rate, n_per_rank, seed, force, skip_ahead_at):
+    for p in (os.path.join(conftest.ROOT, "gr-air-modes_amd"), os.path.join(conftest.ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import synth
+    from air_modes import _capi
+    from air_modes.sharded import ShardedReceiver
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        iq, _ = synth.synth_capture(rate, LOOK_STEPS * world * n_per_rank, 9000.0, seed=seed)
+        lib = _capi.Library(conftest.EMU_LIB)
+        ctx = _capi.Context(rate, 7.0, True, lib=lib)
+        ctx.set_rx_time(0, 1000, 0.25)
+        rx = ShardedReceiver(ctx, rank, world, n_per_rank, force_collectives=force, buffers=2, lookahead=True)
+
+        def samples(k):
+            a = (k * world + rank) * n_per_rank
+            return torch.from_numpy(iq[a:a + n_per_rank].copy().view(np.float32))
+        rx.chunk.copy_(samples(0))
+        out, ahead_before = [], False
+        for k in range(LOOK_STEPS):
+            ahead = k + 1 < LOOK_STEPS and k != skip_ahead_at
+            if ahead:
+                rx.chunk_ahead.copy_(samples(k + 1))
+            elif k > 0 and not ahead_before:
+                pass
+            out.append(rx.step(flush=(k == LOOK_STEPS - 1), ahead=ahead).tobytes())
+            if not ahead and k + 1 < LOOK_STEPS:
+                rx.chunk.copy_(samples(k + 1))            # (the source was late: the next step exchanges its tails itself)
+            ahead_before = ahead
+        ret[rank] = out
+        ret["sync_%d" % rank] = rx.sync_steps
+        ret["p2p_%d" % rank] = len(rx.host_us_steps["tail_exchange"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,force,skip", [(1, True, -1), (2, False, -1), (3, False, 2), (8, False, 1)])
+def test_one_collective_per_step_with_lookahead(emu_lib, oracle_mod, world, force, skip):
+    """lookahead=True: the all-gather of the exit tables carries the next step's tails (the last rank's current one closes the ring):
+    a step then starts with a device copy, no send / receive.  Five steps == the oracle over the whole capture; a step whose
+    successor was not resident (ahead=False) is followed by a step that exchanges its tails the old way."""
+    import synth
+    from air_modes import _capi
+    rate, n_per_rank, seed = (20e6, 150000, 2722) if world < 8 else (4e6, 60000, 2720)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_lookahead, args=(world, 29871 + world, ret, rate, n_per_rank, seed, force, skip), nprocs=world, join=True)
+    got = np.concatenate([np.frombuffer(ret[r][k], _capi.PACKET_DTYPE) for k in range(LOOK_STEPS) for r in range(world)])
+    iq, _ = synth.synth_capture(rate, LOOK_STEPS * world * n_per_rank, 9000.0, seed=seed)
+    want = oracle_mod.demod(iq, rate, rx_time=[(0, 1000, 0.25)])
+    assert len(want) > 50 and got.tobytes() == want.tobytes()
+    assert all(ret["sync_%d" % r] == 0 for r in range(world))
+    # send / receive calls: none when every step was prefetched (world 1: none at all); one step's worth after the late source
+    calls = [ret["p2p_%d" % r] for r in range(world)]
+    first = 0 if world == 1 else 1                        # (step 0 of a stream has no gather before it)
+    if skip < 0:
+        assert max(calls) == first, calls
+    else:
+        assert first + 1 <= max(calls) <= first + 2, calls
