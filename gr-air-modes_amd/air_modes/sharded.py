@@ -31,6 +31,8 @@ Per step:
                      rank's header), the entry position of the own chunk is composed from all tables by a kernel, the
                      chain is marked from there, hits are extracted and sliced, and where the scan leaves the own
                      chunk stays in a device word for the next step's header.  ONE completion wait per step.
+  lookahead=True (round 6): steps 1 and 3 are ONE collective -- every rank appends to its message the tail the NEXT step needs
+  (of its next chunk; the last rank: of its current one), and the next step starts with a device copy out of the gathered buffer.
   A step whose table does not fit the message, or whose scan met more candidates than the capacity it was launched
   for (both are flagged in the message header, so every rank takes the same decision without another collective), is
   repeated on the synchronous path (am_shard_scan -> host tables -> am_shard_entry2 -> am_shard_resolve; `sync_steps`
