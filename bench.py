@@ -91,7 +91,7 @@ def parse_args():
                     help="time-sharded mode: tails by send / receive + exit tables by all-gather (two collectives per step) instead of the "
                          "default, ShardedReceiver(lookahead=True): the all-gather of the exit tables carries the next step's tails -- one "
                          "collective per step; needs the next step's samples resident, which they are here (three rotating buffers).  "
-                         "RCCL at world 1: 0.367 vs 0.541 ms per step (profiles/r6_rccl/lookahead.txt)")
+                         "RCCL at world 1: 0.351 vs 0.541 ms per step (profiles/r6_rccl/lookahead.txt)")
     ap.add_argument("--steps-in-flight", action="store_true",
                     help="time-sharded mode: PipelinedShardedReceiver (step k + 1 scanned before step k is resolved) instead of one step "
                          "at a time; measured at world 1: 0.287 vs 0.293 ms without a group, 0.547 vs 0.528 ms through RCCL "

@@ -95,6 +95,7 @@ class ShardedReceiver(object):
         # next step's samples in the next buffer when step(ahead=True) is called (buffers >= 2; a one-rank receiver needs nothing).
         self.lookahead = bool(lookahead)
         self._halo_ready = False
+        self._halo_copied = False
         self._alloc(device if device is not None else "cpu")
         # the device-side exchange hands device pointers to kernels: only where the buffers live on the GPU (or where
         # "device memory" is host memory: the CPU emulation the tests run on)
@@ -243,8 +244,10 @@ class ShardedReceiver(object):
         prefetched = look and self._halo_ready
         self._halo_ready = False
         if prefetched:
-            # the samples in front of the own ones travelled with the last step's exit tables
-            self._halo_view.copy_(self._gathered_tails[(rank - 1) % world])
+            # the samples in front of the own ones travelled with the last step's exit tables (with more than one buffer they were
+            # copied into place right behind that all-gather, in the shadow of the resolve kernels)
+            if not self._halo_copied:
+                self._halo_view.copy_(self._gathered_tails[(rank - 1) % world])
         elif world > 1 or (self.force and not self.tail_by_gather):
             ops = []
             if not last:
@@ -302,6 +305,9 @@ class ShardedReceiver(object):
                     dist.all_gather_into_tensor(self._agath_x, self._amsg_x, group=self.group)
                     self._tables_dense.copy_(self._gathered_tables)      # (the resolve step reads the tables at their own stride)
                     self._halo_ready = carry_tails
+                    self._halo_copied = carry_tails and self._nbuf > 1
+                    if self._halo_copied:
+                        self._views[(self._bi + 1) % self._nbuf][1].copy_(self._gathered_tails[(rank - 1) % world])
                 else:
                     dist.all_gather_into_tensor(self._agath, self._amsg, group=self.group)
                 self.host_us["all_gather"] += (time.perf_counter() - tc) * 1e6
