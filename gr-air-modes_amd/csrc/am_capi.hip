@@ -727,11 +727,13 @@ int chain_collect(am_ctx *c, uint32_t M, const uint32_t *Mp, uint32_t n_max, boo
     if (n_emit > n_max) return fail(c, AM_EHIP, "internal: more hits than the spacing bound allows");
     c->n_hits = n_emit;
     if (!keep_bursts) {
+        const double TC = am_now_us();
         for (uint32_t i = 0; i < n_emit; i++) {
             if (!c->pin_packets[i].reserved[0]) continue;      // rejected: only this flag was written
             c->pending.push_back(c->pin_packets[i]);
             c->pending.back().reserved[0] = 0;
         }
+        c->ht[7] += am_now_us() - TC;
         if (!c->keep_tags) return AM_OK;
     }
     c->h_tags.assign(c->pin_tags, c->pin_tags + n_emit);
@@ -1026,8 +1028,8 @@ void am_destroy(am_ctx *c)
     if (!c) return;
 #if defined(AM_TEST_KNOBS)
     if (getenv("AIRMODES_HOST_TRACE") && c->ht_n)
-        fprintf(stderr, "airmodes host trace over %u calls (us/call): setup %.1f, front end + refinement enqueue %.1f, chain + tail incl. sync %.1f (of which waiting %.1f), timing + hand-over %.1f, whole call %.1f, event-not-ready %.0f\n",
-                c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6]);
+        fprintf(stderr, "airmodes host trace over %u calls (us/call): setup %.1f, front end + refinement enqueue %.1f, chain + tail incl. sync %.1f (of which waiting %.1f), timing + hand-over %.1f, whole call %.1f, event-not-ready %.0f; accepted packets out of pinned memory %.1f\n",
+                c->ht_n, c->ht[0] / c->ht_n, c->ht[1] / c->ht_n, c->ht[2] / c->ht_n, c->ht[5] / c->ht_n, c->ht[3] / c->ht_n, c->ht[4] / c->ht_n, c->ht[6], c->ht[7] / c->ht_n);
 #endif
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->pb_bb, &c->pb_avg, &c->bbmax, &c->carry, &c->carry2, &c->src, &c->bb, &c->avg, &c->cand_seg, &c->inavg, &c->dcount, &c->off_local, &c->blk_tot2, &c->blk_base2,
