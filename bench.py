@@ -766,7 +766,9 @@ def main():
                     traffic_src = "profiles/current_traffic.json is stale: measured on %s sha %s, this is %s" % (
                         t.get("kernel_source", "am_fe4.hip"), t.get("kernel_source_sha16"), sha)
         par = {"single": "single GPU" if K == 1 else "single GPU, %d independent streams per scan (am_process_multi)" % K, "replicas": "%d independent receivers%s, one per GPU, no collective" % (world, "" if K == 1 else " x %d streams per scan" % K),
-               "sharded": "time-chunk shards x%d of one continuing stream, RCCL tail exchange + scan exit-table all-gather" % world}[mode]
+               "sharded": ("time-chunk shards x%d of one continuing stream, " % world) + (
+                   "ONE all-gather per step (exit tables + the next step's tails)" if extra.get("sharded_one_collective_per_step")
+                   else "RCCL tail exchange + scan exit-table all-gather")}[mode]
         res = {
             "metric": "complex samples/sec demodulated (IQ -> Mode-S packet list)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
