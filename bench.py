@@ -92,10 +92,12 @@ def parse_args():
                          "default, ShardedReceiver(lookahead=True): the all-gather of the exit tables carries the next step's tails -- one "
                          "collective per step; needs the next step's samples resident, which they are here (three rotating buffers).  "
                          "RCCL at world 1: 0.351 vs 0.541 ms per step (profiles/r6_rccl/lookahead.txt)")
-    ap.add_argument("--steps-in-flight", action="store_true",
-                    help="time-sharded mode: PipelinedShardedReceiver (step k + 1 scanned before step k is resolved) instead of one step "
-                         "at a time; measured at world 1: 0.287 vs 0.293 ms without a group, 0.547 vs 0.528 ms through RCCL "
-                         "(profiles/r6_rccl/steps_in_flight.txt) -- not the default")
+    ap.add_argument("--steps-in-flight", action="store_true", help="(the default in the time-sharded mode since round 6; kept for old command lines)")
+    ap.add_argument("--no-steps-in-flight", action="store_true",
+                    help="time-sharded mode: one step at a time (ShardedReceiver.step) instead of PipelinedShardedReceiver (step k + 1 is "
+                         "scanned before step k is resolved; one in-stream all-gather per step carries the exit tables and the next "
+                         "step's tails).  The timed region fills and drains the pipeline.  World 1 through RCCL, 200 steps: 0.302 vs "
+                         "0.349 ms per step; without a group 0.283 vs 0.305 (profiles/r6_rccl/steps_in_flight.txt)")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="with --force-sharded at N=1: a world-1 process group of this backend, and the receiver goes through its "
@@ -553,7 +555,7 @@ def main():
         from air_modes.sharded import ShardedReceiver, PipelinedShardedReceiver
         iq = synth.synth_capture(rate, n, lam, seed + rank)[0]
         forced = world == 1 and bool(args.backend)
-        in_flight = bool(args.steps_in_flight)
+        in_flight = not args.no_steps_in_flight
         fe_ms = []
         pk = None
         npk_steps = 0

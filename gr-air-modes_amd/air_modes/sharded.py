@@ -367,24 +367,28 @@ class ShardedReceiver(object):
 
 
 class PipelinedShardedReceiver(object):
-    """The time-sharded receiver with STEPS IN FLIGHT (round 6).  ShardedReceiver.step() is one step at a time: tail exchange, scan,
-    all-gather of the exit tables, resolve, wait -- and through RCCL every collective is a detour of ~100 us on the step's critical
-    path (measured at world 1: profiles/r6_rccl).  Here the scan and the all-gather of step k + 1 are enqueued BEFORE step k is
-    resolved: the collectives of one step run while the kernels of its neighbours do.
+    """The time-sharded receiver with STEPS IN FLIGHT (round 6).  ShardedReceiver.step() is one step at a time: the host waits for a
+    step's completion ticket before it enqueues the next one, and the device idles meanwhile (~70 us per step through the Python
+    side).  Here step k + 1 is scanned BEFORE step k is collected:
 
         rx.chunk.copy_(samples of step 0); rx.submit()
-        rx.chunk.copy_(samples of step 1); rx.submit()        # scan + all-gather of step 1; resolve of step 0 enqueued
-        pk0 = rx.collect()                                    # step 0's packets
+        rx.chunk.copy_(samples of step 1); rx.submit()        # all-gather + resolve of step 0, then the scan of step 1: all enqueued
+        pk0 = rx.collect()                                    # step 0's packets (the scan of step 1 is queued behind them)
         rx.chunk.copy_(samples of step 2); rx.submit(); pk1 = rx.collect(); ...   # collect(j) comes before submit(j + 2)
 
     What makes it possible: a step's scan never depended on where the greedy scan enters the chunk; the position it starts from --
     where the scan left the LAST chunk of the step before -- no longer travels in the next step's message (written at scan time,
     i.e. too early) but stays in a device word every rank keeps for itself: the resolve step composes the entry through ALL ranks'
     tables (am_shard_resolve_submit: cur_in / carry_out) and leaves the step's final position there.  Two contexts and two halo'd
-    chunk buffers per rank alternate; everything is issued on ONE stream of the receiver's own, the collectives asynchronously, so
-    stream order is all the ordering there is.  A step whose table did not fit its message or whose scan outgrew its capacity is
-    flagged in the headers every rank reads: collect() repeats it on the synchronous path (host tables) on every rank alike; the
-    step scanned behind it stays valid (its resolve is only enqueued once its predecessor is known to be good).
+    chunk buffers per rank alternate.  ONE collective per step, issued synchronously on the receiver's own stream (stream order is
+    all the ordering there is; nothing hops between streams): the all-gather of step k's exit tables is issued when step k + 1 is
+    submitted, so that it also carries what step k + 1 needs in front of its chunks -- every rank's tail of the chunk it has just
+    been handed, the last rank's tail of step k (the ring closes).  A stream's first step, and a step submitted after the caller
+    drained the pipeline, exchange their tails by send / receive.  A step whose table did not fit its message or whose scan outgrew
+    its capacity is flagged in the headers every rank reads: collect() repeats it on the synchronous path (host tables) on every
+    rank alike; the step scanned behind it stays valid (its resolve is only enqueued once its predecessor is known to be good).
+    Measured at world 1, 200 steps of 64 M samples: 0.302 ms per step through RCCL (one step at a time: 0.349), 0.283 without a
+    group (0.305) -- profiles/r6_rccl/steps_in_flight.txt.
     Packets of all (step, rank) pairs in order == the single-stream packet list.  Give BOTH contexts the same rx_time tags."""
 
     def __init__(self, ctxs, rank, world, n_per_rank, group=None, device=None, small_table=512, force_collectives=False):
@@ -411,8 +415,14 @@ class PipelinedShardedReceiver(object):
         if not (self._bufs[0].is_cuda or emulated):
             raise ValueError("steps in flight need device buffers (or the CPU emulation): the tables stay on the device")
         words = 2 * (_capi.SHARD_MSG_HEADER + self.small_cap)
-        self._amsg = [t.zeros(words, dtype=t.int64, device=dev) for _ in range(2)]
-        self._agath = [t.zeros(self.world * words, dtype=t.int64, device=dev) for _ in range(2)]
+        ext = words + self.halo                           # a message: header + table, then `halo` complex samples (int64 words)
+        self._amsg = [t.zeros(ext, dtype=t.int64, device=dev) for _ in range(2)]
+        self._amsg_tail = [m[words:].view(t.float32) for m in self._amsg]
+        self._agath_x = [t.zeros(self.world * ext, dtype=t.int64, device=dev) for _ in range(2)]
+        self._gathered_tables = [g.view(self.world, ext)[:, :words] for g in self._agath_x]
+        self._gathered_tails = [[g.view(self.world, ext)[r, words:].view(t.float32) for r in range(self.world)] for g in self._agath_x]
+        self._agath = t.zeros(self.world * words, dtype=t.int64, device=dev)     # the tables at the stride the resolve step reads
+        self._tables_dense = self._agath.view(self.world, words)
         self._carry = t.zeros(2, dtype=t.int64, device=dev)          # [0]: where the scan left the last chunk of the step resolved last
         self._host_tab = np.zeros(self.tab_cap, _capi.EXIT_DTYPE)
         self._msg = t.zeros(2 + 2 * self.tab_cap, dtype=t.int64, device=dev)
@@ -420,14 +430,13 @@ class PipelinedShardedReceiver(object):
         self._tstream = None
         if self._bufs[0].is_cuda:
             self._tstream = t.cuda.Stream(device=self._bufs[0].device)
-            self._cstream = t.cuda.Stream(device=self._bufs[0].device)
             self._caller = None
             for c in self.ctxs:
                 c.set_stream(self._tstream.cuda_stream)
         for c in self.ctxs:
             c.shard_keep_tail(0, 0, 0)
         self.k = 0                       # steps of the current stream submitted so far
-        self._scanned = None             # (k, slot, all-gather work, flush): scanned, its resolve not enqueued yet
+        self._scanned = None             # (k, slot, flush): scanned; its all-gather and resolve step not enqueued yet
         self._resolved = None            # (k, slot, flush): resolve enqueued, not collected yet
         self._ended = False
         self.sync_steps = 0
@@ -509,95 +518,97 @@ class PipelinedShardedReceiver(object):
         last = rank == world - 1
         on_gpu = buf.is_cuda
         collectives = world > 1 or self.force
-        # 1. the samples in front of the own ones: issued now, waited for (in stream order) in front of the scan
-        reqs = []
-        tc = time.perf_counter()
-        if collectives and not self.tail_by_gather:
-            ops = []
-            if not last:
-                ops.append(dist.P2POp(dist.isend, own_tail, rank + 1, self.group))
-            elif k > 0:
-                ops.append(dist.P2POp(dist.isend, prev_tail, 0, self.group))       # the ring closes: the step before's last chunk
-            if rank > 0:
-                ops.append(dist.P2POp(dist.irecv, halo_view, rank - 1, self.group))
-            elif k > 0:
-                ops.append(dist.P2POp(dist.irecv, halo_view, world - 1, self.group))
-            if ops:
+        # 1. the step before: ITS all-gather only now, so that it can carry what THIS step needs in front of its chunks (every rank's
+        #    tail of the chunk it has just been handed; the last rank's tail of the step before, which closes the ring) -- one
+        #    collective per step, issued synchronously on the receiver's stream: stream order is the only ordering, nothing hops --
+        #    then its resolve step, queued in front of this step's scan (the host runs ahead of the device by it)
+        prefetched = self._gather_and_resolve(s)
+        # 2. no step before this one in flight (a stream's first step, or the caller drained the pipeline): the tails travel alone
+        if not prefetched and (k > 0 or world > 1):
+            tc = time.perf_counter()
+            if collectives and not self.tail_by_gather:
+                ops = []
+                if not last:
+                    ops.append(dist.P2POp(dist.isend, own_tail, rank + 1, self.group))
+                elif k > 0:
+                    ops.append(dist.P2POp(dist.isend, prev_tail, 0, self.group))       # the ring closes: the step before's last chunk
+                if rank > 0:
+                    ops.append(dist.P2POp(dist.irecv, halo_view, rank - 1, self.group))
+                elif k > 0:
+                    ops.append(dist.P2POp(dist.irecv, halo_view, world - 1, self.group))
                 try:
-                    reqs = self._issue_p2p(ops)
+                    for r_ in (dist.batch_isend_irecv(ops) if ops else []):
+                        r_.wait()
                 except Exception:
                     if not self.force:
                         raise
                     self.tail_by_gather = True
-        if k > 0 and world == 1 and (not collectives or self.tail_by_gather):
-            if self.force:
-                dist.all_gather_into_tensor(halo_view, prev_tail, group=self.group)        # (world 1: the gathered tensor IS the tail)
-            else:
-                self.ctxs[s].stream_copy(halo_view.data_ptr(), prev_tail.data_ptr(), halo * 8)
-        # 2. the resolve step of the step before (the host runs ahead of the device by it: the scan below is queued behind it when
-        #    collect() returns).  Measured the other way round -- scan first, so that the all-gather hides behind it: the device
-        #    idles while the host enqueues the next step, 0.34 vs 0.29 ms per step (profiles/r6_rccl/steps_in_flight.txt)
-        self._resolve_scanned()
-        # 3. the scan, behind the tail exchange
-        try:
-            for r_ in reqs:
-                r_.wait()
-        except Exception:
-            if not self.force:
-                raise
-            self.tail_by_gather = True
-            dist.all_gather_into_tensor(halo_view, prev_tail, group=self.group)
-        dtt = (time.perf_counter() - tc) * 1e6
-        self.host_us["tail_exchange"] += dtt
-        self.host_us_steps["tail_exchange"].append(dtt)
+            if k > 0 and world == 1 and (not collectives or self.tail_by_gather):
+                if self.force:
+                    dist.all_gather_into_tensor(halo_view, prev_tail, group=self.group)    # (world 1: the gathered tensor IS the tail)
+                else:
+                    self.ctxs[s].stream_copy(halo_view.data_ptr(), prev_tail.data_ptr(), halo * 8)
+            dtt = (time.perf_counter() - tc) * 1e6
+            self.host_us["tail_exchange"] += dtt
+            self.host_us_steps["tail_exchange"].append(dtt)
+        # 3. the scan
         a0, a1, total, off = self._geometry(k, flush)
-        c = self.ctxs[s]
-        c.shard_scan_async(buf.data_ptr() + off, a0, a1, total, self._amsg[s].data_ptr(), self.small_cap, device_in=on_gpu, more=not flush)
-        work = None
-        if collectives:
-            tc = time.perf_counter()
-            work = dist.all_gather_into_tensor(self._agath[s], self._amsg[s], group=self.group, async_op=True)
-            dta = (time.perf_counter() - tc) * 1e6
-            self.host_us["all_gather"] += dta
-            self.host_us_steps["all_gather"].append(dta)
-        self._scanned = (k, s, work, flush)
+        tc = time.perf_counter()
+        self.ctxs[s].shard_scan_async(buf.data_ptr() + off, a0, a1, total, self._amsg[s].data_ptr(), self.small_cap,
+                                      device_in=on_gpu, more=not flush)
+        self.host_us_steps.setdefault("scan_enqueue", []).append((time.perf_counter() - tc) * 1e6)
+        self._scanned = (k, s, flush)
         self.host_us["steps"] += 1
         self.k += 1
         if flush:
             self._ended = True
 
-    def _issue_p2p(self, ops):
-        """The tail exchange depends on the caller's samples only, not on what the receiver's stream still has queued (the scan and
-        the resolve of older steps): issued from a stream of its own, so that the backend's wait for "the current stream" is short."""
-        if self._tstream is None:
-            return self.dist.batch_isend_irecv(ops)
-        self._cstream.wait_stream(self._caller)
-        with self.torch.cuda.stream(self._cstream):
-            return self.dist.batch_isend_irecv(ops)
-
-    def _resolve_scanned(self):
-        """The scanned step's resolve, enqueued (behind its all-gather); needs the step before it collected."""
+    def _gather_and_resolve(self, next_slot):
+        """The scanned step's all-gather and resolve step, enqueued.  next_slot: the buffer of the step submitted right now (None: no
+        successor yet -- collect() drains) -- its halo is filled from what the gather brings.  Returns whether it was."""
         if self._scanned is None:
-            return
+            return False
         if self._resolved is not None:
             raise RuntimeError("collect the oldest step first (collect(j) comes before submit(j + 2))")
-        k, s, work, flush = self._scanned
-        if work is not None:
-            work.wait()                                      # (the stream waits; the host does not, with RCCL)
-        msgs = self._agath[s] if (self.world > 1 or self.force) else self._amsg[s]
-        self.ctxs[s].shard_resolve_submit(msgs.data_ptr(), self.world, self.rank, self.small_cap,
+        t, dist = self.torch, self.dist
+        k, s, flush = self._scanned
+        world, rank, halo, n = self.world, self.rank, self.halo, self.n
+        last = rank == world - 1
+        carry = next_slot is not None and not flush
+        msgs = self._amsg[s]
+        if world > 1 or self.force:
+            tc = time.perf_counter()
+            if carry:
+                self._amsg_tail[s].copy_((self._bufs[s] if last else self._bufs[next_slot])[n * 2:])
+            dist.all_gather_into_tensor(self._agath_x[s], self._amsg[s], group=self.group)
+            self._tables_dense.copy_(self._gathered_tables[s])
+            if carry:
+                self._bufs[next_slot][:halo * 2].copy_(self._gathered_tails[s][(rank - 1) % world])
+            dta = (time.perf_counter() - tc) * 1e6
+            self.host_us["all_gather"] += dta
+            self.host_us_steps["all_gather"].append(dta)
+            msgs = self._agath
+        elif carry:
+            # one rank, no group: it is its own predecessor
+            self.ctxs[s].stream_copy(self._bufs[next_slot].data_ptr(), self._bufs[s].data_ptr() + n * 8, halo * 8)
+        tc = time.perf_counter()
+        self.ctxs[s].shard_resolve_submit(msgs.data_ptr(), world, rank, self.small_cap,
                                           cur_in_ptr=self._carry.data_ptr(), carry_out_ptr=self._carry.data_ptr())
+        self.host_us_steps.setdefault("resolve_enqueue", []).append((time.perf_counter() - tc) * 1e6)
         self._resolved, self._scanned = (k, s, flush), None
+        return carry
 
     def collect(self):
         """The packets of the oldest step in flight."""
         if self._resolved is None:
             if self._scanned is None:
                 raise RuntimeError("no step in flight")
-            self._with_stream(self._resolve_scanned)
+            self._with_stream(self._gather_and_resolve, None)
         k, s, flush = self._resolved
         cap_pk = max(64, self.n // 2000 + 64)
+        tc = time.perf_counter()
         pk, redo = self.ctxs[s].shard_resolve_collect(capacity=cap_pk)
+        self.host_us_steps.setdefault("collect_wait_and_fetch", []).append((time.perf_counter() - tc) * 1e6)
         if redo:
             self.sync_steps += 1
             pk = self._with_stream(self._redo, k, s, flush, cap_pk)

@@ -93,10 +93,13 @@ def test_replicas_with_k_streams_each(emu_lib):
     assert "x 2 streams per scan" in d["config"]["parallelism"] and "4 independent streams" in d["config"]["workload"]
 
 
-def test_gpus_2_steps_in_flight(emu_lib):
-    """--steps-in-flight: the time-sharded loop through PipelinedShardedReceiver (two contexts per rank, the scan of step k + 1
-    queued before step k is collected); same line, same parity verdicts."""
-    d = run_bench("--gpus", "2", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline", "--steps-in-flight", "--steps", "4")
-    assert d["n_gpus"] == 2 and d["sharded_steps_in_flight"] is True
+@pytest.mark.parametrize("flags,in_flight,one", [((), True, False), (("--no-steps-in-flight",), False, True),
+                                                 (("--no-steps-in-flight", "--no-lookahead"), False, False)])
+def test_gpus_2_forms_of_the_sharded_step(emu_lib, flags, in_flight, one):
+    """The time-sharded loop's three forms: steps in flight (PipelinedShardedReceiver, the default: two contexts per rank, the scan
+    of step k + 1 queued before step k is collected), one step at a time with one collective per step, and with two; same line,
+    same parity verdicts."""
+    d = run_bench("--gpus", "2", "--workload", "20msps", "--seconds", "0.01", "--no-cpu-baseline", "--steps", "4", *flags)
+    assert d["n_gpus"] == 2 and d["sharded_steps_in_flight"] is in_flight and d["sharded_one_collective_per_step"] is one
     assert d["parity"] is True and d["parity_detail"]["short_stream_two_steps_all_ranks"] is True and d["parity_detail"]["rank0_full_size"] is True
     assert d["sharded_sync_steps"] == 0 and d["roofline"]["kernel_ms"] > 0

@@ -21,8 +21,9 @@ fi
 AIRMODES_HIP_LIB=$PWD/tests/gpu_variants/libairmodes_hip_knobs.so AIRMODES_FE=2 timeout 120 python bench.py --no-cpu-baseline --no-extra > $OUT/bench_tile_kernel.json 2>/dev/null
 timeout 120 python bench.py --force-sharded --no-cpu-baseline --no-extra > $OUT/bench_force_sharded.json 2>/dev/null
 timeout 200 python bench.py --force-sharded --backend nccl --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1.json
-timeout 200 python bench.py --force-sharded --backend nccl --no-lookahead --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1_two_collectives.json
-timeout 200 python bench.py --force-sharded --backend nccl --steps-in-flight --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1_steps_in_flight.json
+timeout 200 python bench.py --force-sharded --backend nccl --steps 200 --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1_200_steps.json
+timeout 200 python bench.py --force-sharded --backend nccl --no-steps-in-flight --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1_one_step_at_a_time.json
+timeout 200 python bench.py --force-sharded --backend nccl --no-steps-in-flight --no-lookahead --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" > $OUT/bench_force_sharded_nccl_world1_two_collectives.json
 timeout 400 python bench.py --workload 2msps --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_2msps.json
 timeout 400 python bench.py --workload 20msps --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_20msps.json
 timeout 200 bash tools/gpu_pmc.sh > $OUT/sq_counters.txt 2>&1
