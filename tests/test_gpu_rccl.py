@@ -43,8 +43,8 @@ def test_rccl_runs_the_sharded_step_at_world_one(hip_lib, oracle_mod):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("through_rccl", [True, False])
-def test_steps_in_flight_at_world_one(hip_lib, oracle_mod, through_rccl):
+@pytest.mark.parametrize("through_rccl,small_table", [(True, 512), (False, 512), (True, 1)])
+def test_steps_in_flight_at_world_one(hip_lib, oracle_mod, through_rccl, small_table):
     """PipelinedShardedReceiver on the device: step k + 1's tail exchange, scan and all-gather enqueued before step k is resolved --
     through a world-1 "nccl" group (asynchronous all_gather_into_tensor / batch_isend_irecv on the receiver's own stream) and
     without a group (the floor).  Six steps, twice == the oracle over the whole stream; a density jump in the second stream makes
@@ -61,7 +61,9 @@ def test_steps_in_flight_at_world_one(hip_lib, oracle_mod, through_rccl):
     try:
         dev = torch.device("cuda", 0)
         ctxs = [_capi.Context(rate, 7.0, True, device=0, lib=hip_lib) for _ in range(2)]
-        rx = PipelinedShardedReceiver(ctxs, 0, 1, n, device=dev, force_collectives=through_rccl)
+        # small_table = 1: a message holds ONE table entry -- nearly every step is flagged in its header and repeated on the
+        # synchronous path (host tables) while its successor is already scanned: the redo path on the device
+        rx = PipelinedShardedReceiver(ctxs, 0, 1, n, device=dev, force_collectives=through_rccl, small_table=small_table)
         assert rx.force == through_rccl
         for lams in ([12000.0] * steps, [300.0, 300.0, 300.0, 40000.0, 300.0, 12000.0]):
             iq = np.concatenate([synth.synth_capture(rate, n, lam, seed=6200 + k)[0] for k, lam in enumerate(lams)])
@@ -80,6 +82,7 @@ def test_steps_in_flight_at_world_one(hip_lib, oracle_mod, through_rccl):
             assert len(want) > 100 and got.tobytes() == want.tobytes(), (len(got), len(want), lams)
             print("steps in flight (%s): %d packets, %d steps on the synchronous path so far"
                   % ("rccl world 1" if through_rccl else "no group", len(got), rx.sync_steps))
+        assert (rx.sync_steps >= steps) if small_table == 1 else (rx.sync_steps <= 2)
         rx.close()
         for c in ctxs:
             c.close()
