@@ -213,6 +213,90 @@ def run_stream_shards(lib, rate, iq, W, K, thr=7.0, pmf=True, dcblock=False):
     return np.concatenate(out)
 
 
+def run_stream_shards_in_flight(lib, rate, iq, W, K, thr=7.0, pmf=True, dcblock=False, small_cap=512, rx_time=()):
+    """The same receiver with STEPS IN FLIGHT and the tables on the device, W ranks in ONE process: what
+    air_modes/sharded.py::PipelinedShardedReceiver does over torch.distributed, through the C ABI alone.  Every rank has two
+    contexts (steps alternate) and a carry word of its own; a step's messages lie side by side in one buffer (the all-gather is
+    the layout); step k + 1 is scanned on every rank BEFORE step k is resolved; am_shard_resolve_submit composes the entry through
+    all ranks' tables from the rank's carry word (cur_in) and leaves the step's last exit there (carry_out).  A flagged step (redo)
+    is repeated on the synchronous path by every rank, with its successor already scanned.  Returns (packets in (step, rank)
+    order, steps redone)."""
+    m = len(iq) // (W * K)
+    assert m * W * K == len(iq)
+    emulated = bool(getattr(lib, "emulated", False))
+    ctxs = [[_capi.Context(rate, thr, pmf, use_dcblock=dcblock, device=(-1 if emulated else 0), lib=lib) for _ in range(2)] for _ in range(W)]
+    for pair in ctxs:
+        for c in pair:
+            for tag in rx_time:
+                c.set_rx_time(*tag)
+    hl, H = ctxs[0][0].shard_halo()
+    assert m >= hl + H
+    words = 2 * (_capi.SHARD_MSG_HEADER + small_cap)
+    f32 = np.ascontiguousarray(iq).view(np.float32)
+    if emulated:
+        dev_iq, base = f32, f32.ctypes.data
+        msgs = [np.zeros(W * words, np.int64) for _ in range(2)]
+        carry = [np.zeros(2, np.int64) for _ in range(W)]
+        ptr = lambda a: a.ctypes.data
+        rd = lambda a: int(np.int64(a[0]).astype(np.uint64))
+
+        def wr(a, v):
+            a[0] = np.uint64(v).astype(np.int64)
+    else:
+        import torch
+        dev_iq = torch.from_numpy(f32.copy()).cuda()
+        base = dev_iq.data_ptr()
+        msgs = [torch.zeros(W * words, dtype=torch.int64, device="cuda") for _ in range(2)]
+        carry = [torch.zeros(2, dtype=torch.int64, device="cuda") for _ in range(W)]
+        ptr = lambda a: a.data_ptr()
+        rd = lambda a: int(np.int64(a[0].item()).astype(np.uint64))
+
+        def wr(a, v):
+            a[0] = int(np.uint64(v).astype(np.int64))
+
+    def geometry(k, r):
+        S0, flush = k * W * m, k == K - 1
+        total = S0 + W * m
+        a0 = 0 if (k == 0 and r == 0) else S0 + r * m - H
+        a1 = total if (flush and r == W - 1) else S0 + (r + 1) * m - H
+        return a0, a1, total, max(0, a0 - hl), S0 + (r + 1) * m, flush
+
+    def scan(k):
+        for r in range(W):
+            a0, a1, total, lo, hi, flush = geometry(k, r)
+            ctxs[r][k % 2].shard_scan_async(base + 8 * lo, a0, a1, total, ptr(msgs[k % 2]) + 8 * r * words, small_cap, device_in=True, more=not flush)
+
+    out, redone = [], 0
+    scan(0)
+    for k in range(K):
+        if k + 1 < K:
+            scan(k + 1)                                      # ... before step k is resolved
+        if not emulated:
+            torch.cuda.synchronize()                         # (every rank has streams of its own here: the tables of all are complete)
+        for r in range(W):
+            ctxs[r][k % 2].shard_resolve_submit(ptr(msgs[k % 2]), W, r, small_cap, cur_in_ptr=ptr(carry[r]), carry_out_ptr=ptr(carry[r]))
+        got = [ctxs[r][k % 2].shard_resolve_collect(capacity=max(64, m // 2000 + 64)) for r in range(W)]
+        flags = [g[1] for g in got]
+        assert len(set(flags)) == 1, "the ranks disagree about repeating step %d: %s" % (k, flags)
+        if flags[0]:
+            redone += 1
+            cur = rd(carry[0])
+            assert all(rd(carry[r]) == cur for r in range(W)), "a flagged step moved a carry word"
+            tables = []
+            for r in range(W):
+                a0, a1, total, lo, hi, flush = geometry(k, r)
+                tables.append(ctxs[r][k % 2].shard_scan(iq[lo:hi], a0, a1, total, more=not flush))
+            entry, leave = _capi.shard_entries(lib, tables, cur_in=cur, with_exits=True)
+            got = [(ctxs[r][k % 2].shard_resolve(int(entry[r])), False) for r in range(W)]
+            for r in range(W):
+                wr(carry[r], int(leave[W - 1]))
+        out.extend(g[0] for g in got)
+    for pair in ctxs:
+        for c in pair:
+            c.close()
+    return np.concatenate(out), redone
+
+
 def check_stream_sharded(lib, rate, iq, W, K, thr=7.0, pmf=True, want=None, dcblock=False):
     if want is None:
         want = oracle.demod(iq, rate, thr, pmf, use_dcblock=dcblock)

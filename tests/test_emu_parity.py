@@ -478,3 +478,16 @@ def test_stream_pipe_passes_the_scan_position_through_silent_chunks(emu_lib):
         assert np.array_equal(np.concatenate(got), want)
         assert pipe.redone() == 0
         pipe.close()
+
+
+@pytest.mark.parametrize("rate,W,K,m,small_cap,lam", [(20e6, 3, 4, 120000, 512, 9000.0), (4e6, 5, 3, 50000, 512, 6000.0),
+                                                      (20e6, 2, 4, 150000, 1, 9000.0), (64e6, 2, 3, 420000, 512, 15000.0)])
+def test_steps_in_flight_over_w_ranks_in_one_process(emu_lib, rate, W, K, m, small_cap, lam):
+    """am_shard_resolve_submit / _collect with cur_in / carry_out over W ranks' tables: every rank composes the step's entry and its
+    last exit by itself; step k + 1 scanned before step k is resolved; one-entry messages flag (nearly) every step."""
+    iq, _ = synth.synth_capture(rate, W * K * m, lam, seed=int(rate / 1e5) + W)
+    tags = [(0, 1000, 0.25), (W * m + 777, 2000, 0.5)]
+    got, redone = pc.run_stream_shards_in_flight(emu_lib, rate, iq, W, K, small_cap=small_cap, rx_time=tags)
+    want = oracle.demod(iq, rate, rx_time=tags)
+    assert len(want) > 20 and got.tobytes() == want.tobytes()
+    assert (redone >= K - 1) if small_cap == 1 else (redone == 0)

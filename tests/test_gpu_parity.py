@@ -565,3 +565,17 @@ def test_stream_pipe_silent_chunks_and_redone_chunks_on_device(hip_lib, hip_knob
     assert np.array_equal(got2, want2)
     assert pipe2.redone() >= 1, "no chunk took the synchronous path: the test did not reach it"
     pipe2.close()
+
+
+@pytest.mark.parametrize("rate,W,K,m,small_cap,lam", [(64e6, 3, 4, 2_000_000, 512, 12000.0), (20e6, 4, 3, 900_000, 512, 9000.0),
+                                                      (64e6, 2, 4, 2_500_000, 1, 12000.0), (2e6, 3, 3, 200_000, 512, 3000.0)])
+def test_steps_in_flight_over_w_ranks_on_device(hip_lib, oracle_mod, rate, W, K, m, small_cap, lam):
+    """am_shard_resolve_submit / _collect with cur_in / carry_out over W ranks' device tables on the GPU (W ranks in one process, two
+    contexts each): every rank composes the step's entry and its last exit by itself; one-entry messages flag nearly every step."""
+    import synth
+    iq, _ = synth.synth_capture(rate, W * K * m, lam, seed=int(rate / 1e5) + W)
+    tags = [(0, 1000, 0.25), (W * m + 777, 2000, 0.5)]
+    got, redone = pc.run_stream_shards_in_flight(hip_lib, rate, iq, W, K, small_cap=small_cap, rx_time=tags)
+    want = oracle_mod.demod(iq, rate, rx_time=tags)
+    assert len(want) > 50 and got.tobytes() == want.tobytes()
+    assert (redone >= K - 1) if small_cap == 1 else (redone == 0)

@@ -105,6 +105,9 @@ def main():
             with np.errstate(all="ignore"):
                 want2 = want if m * W * K == n else oracle.demod(iq[:m * W * K], rate, thr, pmf, use_dcblock=dc)
             assert same(got, want2), "case %d: streamed shards differ (%d vs %d packets, W=%d K=%d)" % (case, len(got), len(want2), W, K)
+            # ... with steps in flight and the tables on the device (am_shard_resolve_submit / _collect, a carry word per rank)
+            got, _ = pc.run_stream_shards_in_flight(lib, rate, iq[:m * W * K], W, K, thr, pmf, dc, small_cap=int(rng.choice([1, 8, 512])))
+            assert same(got, want2), "case %d: shards with steps in flight differ (%d vs %d packets, W=%d K=%d)" % (case, len(got), len(want2), W, K)
         if not dc:
             # K streams in one scan (am_process_multi): the capture cut into independent streams, an empty one and a stub among them
             J = int(rng.integers(2, 6))
