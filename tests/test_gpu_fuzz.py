@@ -13,7 +13,8 @@ huge stretches, threshold and filter settings, then
   * random rx_time tags handed over with their chunks == the oracle;
   * the capture as K independent streams (empty ones, stubs) in ONE scan == the oracle on every stream;
   * every first-stage candidate record + tags + bursts of the production scan == the oracle, and the reference's own C++ where
-    oracle/_ref travelled (check_production_stages, with_ref), whole-chip rates.
+    oracle/_ref travelled (check_production_stages, with_ref), whole-chip rates;
+  * the stream over W ranks' device tables with steps in flight (run_stream_shards_in_flight) == the oracle.
 """
 import os
 import time
@@ -143,6 +144,15 @@ def _one_case(hip_lib, d):
         # 5. every candidate record, tags and bursts of the production scan; the reference's own C++ where it travelled
         if whole and d.boolean("stage_level"):
             pc.check_production_stages(lib, rate, n, lam, seed, thr=thr, pmf=pmf, iq=iq, with_ref=True)
+
+        # 6. the stream over W ranks' device tables with steps in flight (am_shard_resolve_submit / _collect, a carry word per rank)
+        if d.boolean("shards_in_flight"):
+            W, K = d.integer(1, 4, "ranks"), d.integer(2, 4, "steps")
+            m = n // (W * K)
+            if m > 344 * (spc + 1):
+                part = iq[:m * W * K]
+                got, _ = pc.run_stream_shards_in_flight(lib, rate, part, W, K, thr, pmf, small_cap=d.choice((1, 8, 512), "message_entries"))
+                assert same(got, want if m * W * K == n else oracle.demod(part, rate, thr, pmf)), "shards with steps in flight differ"
 
 
 def test_the_box_was_used(hip_lib):
