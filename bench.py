@@ -568,6 +568,8 @@ def main():
                 b[rx.halo * 2:].copy_(torch.from_numpy(iq.view(np.float32)))     # resident in HBM before the timed region
             sync()
 
+            marks = []                                       # host clock when a step's packets came back (timed region)
+
             def run_in_flight(steps, timed):
                 nonlocal pk, npk_steps
                 for k in range(steps):
@@ -575,10 +577,12 @@ def main():
                     if k > 0:
                         pk = rx.collect()
                         if timed:
+                            marks.append(time.perf_counter())
                             npk_steps += len(pk)
                             fe_ms.append(ctxs[(rx.k - 2) % 2].last_dom_ms())
                 pk = rx.collect()
                 if timed:
+                    marks.append(time.perf_counter())
                     npk_steps += len(pk)
                     fe_ms.append(ctxs[(rx.k - 1) % 2].last_dom_ms())
             run_in_flight(max(args.warmup, 2), False)
@@ -619,6 +623,11 @@ def main():
                 dist.barrier()
             dt = time.perf_counter() - t0
         extra["sharded_steps_in_flight"] = in_flight
+        if in_flight and len(marks) >= 4:
+            # between the first and the last-but-one step's packets the pipeline is full: the period of a step in steady state (the
+            # timed region above also pays for filling and draining it, ~0.8 ms once; `value` is quoted on the whole region)
+            extra["sharded_steady_state"] = {"ms_per_step": (marks[-2] - marks[0]) / (len(marks) - 2) * 1e3,
+                                             "steps": len(marks) - 2, "what": "host clock between the returns of collect(0) and collect(K - 2)"}
         extra["sharded_one_collective_per_step"] = (not args.no_lookahead) and not in_flight
         inflight, nb, per_batch = 1, 1, [len(pk)]
         extra["sharded_sync_steps"] = rx.sync_steps
