@@ -96,8 +96,8 @@ def parse_args():
     ap.add_argument("--no-steps-in-flight", action="store_true",
                     help="time-sharded mode: one step at a time (ShardedReceiver.step) instead of PipelinedShardedReceiver (step k + 1 is "
                          "scanned before step k is resolved; one in-stream all-gather per step carries the exit tables and the next "
-                         "step's tails).  The timed region fills and drains the pipeline.  World 1 through RCCL, 200 steps: 0.302 vs "
-                         "0.349 ms per step; without a group 0.283 vs 0.305 (profiles/r6_rccl/steps_in_flight.txt)")
+                         "step's tails).  The timed region fills and drains the pipeline.  World 1 through RCCL: 0.310 vs "
+                         "0.349-0.360 ms per step; without a group 0.289 vs 0.305-0.313 (profiles/r6_rccl/steps_in_flight.txt)")
     ap.add_argument("--force-sharded", action="store_true", help="N=1 through the time-sharded code path (overhead check)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="with --force-sharded at N=1: a world-1 process group of this backend, and the receiver goes through its "

@@ -384,11 +384,11 @@ class PipelinedShardedReceiver(object):
     all the ordering there is; nothing hops between streams): the all-gather of step k's exit tables is issued when step k + 1 is
     submitted, so that it also carries what step k + 1 needs in front of its chunks -- every rank's tail of the chunk it has just
     been handed, the last rank's tail of step k (the ring closes).  A stream's first step, and a step submitted after the caller
-    drained the pipeline, exchange their tails by send / receive.  A step whose table did not fit its message or whose scan outgrew
+    drained the pipeline, exchange their tails by an all-gather of their own (in-stream as well: no send / receive anywhere).  A step whose table did not fit its message or whose scan outgrew
     its capacity is flagged in the headers every rank reads: collect() repeats it on the synchronous path (host tables) on every
     rank alike; the step scanned behind it stays valid (its resolve is only enqueued once its predecessor is known to be good).
-    Measured at world 1, 200 steps of 64 M samples: 0.302 ms per step through RCCL (one step at a time: 0.349), 0.283 without a
-    group (0.305) -- profiles/r6_rccl/steps_in_flight.txt.
+    Measured at world 1, 64 M samples per step: 0.310 ms per step through RCCL at 12 steps, 0.295 over 200 (one step at a time:
+    0.349-0.360); 0.289 without a group (0.305-0.313) -- profiles/r6_rccl/steps_in_flight.txt.
     Packets of all (step, rank) pairs in order == the single-stream packet list.  Give BOTH contexts the same rx_time tags."""
 
     def __init__(self, ctxs, rank, world, n_per_rank, group=None, device=None, small_table=512, force_collectives=False):
@@ -421,6 +421,9 @@ class PipelinedShardedReceiver(object):
         self._agath_x = [t.zeros(self.world * ext, dtype=t.int64, device=dev) for _ in range(2)]
         self._gathered_tables = [g.view(self.world, ext)[:, :words] for g in self._agath_x]
         self._gathered_tails = [[g.view(self.world, ext)[r, words:].view(t.float32) for r in range(self.world)] for g in self._agath_x]
+        self._tail_msg = t.zeros(self.halo * 2, dtype=t.float32, device=dev)     # tails alone (a stream's first step, after a drain)
+        self._tails_x = t.zeros(self.world * self.halo * 2, dtype=t.float32, device=dev)
+        self._tails_rows = [self._tails_x[r * self.halo * 2:(r + 1) * self.halo * 2] for r in range(self.world)]
         self._agath = t.zeros(self.world * words, dtype=t.int64, device=dev)     # the tables at the stride the resolve step reads
         self._tables_dense = self._agath.view(self.world, words)
         self._carry = t.zeros(2, dtype=t.int64, device=dev)          # [0]: where the scan left the last chunk of the step resolved last
@@ -523,31 +526,18 @@ class PipelinedShardedReceiver(object):
         #    collective per step, issued synchronously on the receiver's stream: stream order is the only ordering, nothing hops --
         #    then its resolve step, queued in front of this step's scan (the host runs ahead of the device by it)
         prefetched = self._gather_and_resolve(s)
-        # 2. no step before this one in flight (a stream's first step, or the caller drained the pipeline): the tails travel alone
+        # 2. no step before this one in flight (a stream's first step, or the caller drained the pipeline): the tails travel alone --
+        #    by an all-gather of their own, in-stream like the other one (a send / receive would run on the backend's stream: two
+        #    hops; measured ~0.2 ms once per drain through RCCL)
         if not prefetched and (k > 0 or world > 1):
             tc = time.perf_counter()
-            if collectives and not self.tail_by_gather:
-                ops = []
-                if not last:
-                    ops.append(dist.P2POp(dist.isend, own_tail, rank + 1, self.group))
-                elif k > 0:
-                    ops.append(dist.P2POp(dist.isend, prev_tail, 0, self.group))       # the ring closes: the step before's last chunk
-                if rank > 0:
-                    ops.append(dist.P2POp(dist.irecv, halo_view, rank - 1, self.group))
-                elif k > 0:
-                    ops.append(dist.P2POp(dist.irecv, halo_view, world - 1, self.group))
-                try:
-                    for r_ in (dist.batch_isend_irecv(ops) if ops else []):
-                        r_.wait()
-                except Exception:
-                    if not self.force:
-                        raise
-                    self.tail_by_gather = True
-            if k > 0 and world == 1 and (not collectives or self.tail_by_gather):
-                if self.force:
-                    dist.all_gather_into_tensor(halo_view, prev_tail, group=self.group)    # (world 1: the gathered tensor IS the tail)
-                else:
-                    self.ctxs[s].stream_copy(halo_view.data_ptr(), prev_tail.data_ptr(), halo * 8)
+            if collectives:
+                self._tail_msg.copy_(prev_tail if (last and k > 0) else own_tail)
+                dist.all_gather_into_tensor(self._tails_x, self._tail_msg, group=self.group)
+                if rank > 0 or k > 0:
+                    halo_view.copy_(self._tails_rows[(rank - 1) % world])
+            elif k > 0:
+                self.ctxs[s].stream_copy(halo_view.data_ptr(), prev_tail.data_ptr(), halo * 8)   # one rank, no group
             dtt = (time.perf_counter() - tc) * 1e6
             self.host_us["tail_exchange"] += dtt
             self.host_us_steps["tail_exchange"].append(dtt)
