@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra 3-batches-in-flight figure (profiling runs)")
     ap.add_argument("--stream-seconds", type=float, default=16.0, help="signal seconds of the pipelined_stream leg (ONE continuing stream, "
                                                                       "its chunks in flight: am_spipe); 0 skips it")
-    ap.add_argument("--sustained-steps", type=int, default=2000, help="steps of the extra sustained leg (>= 0.5 s of device work: a sampler "
+    ap.add_argument("--sustained-steps", type=int, default=8000, help="steps of the extra sustained leg (>= 0.5 s of device work: a sampler "
                                                                         "of GPU activity sees the device busy); 0 skips it")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="time-sharded mode: tails by send / receive + exit tables by all-gather (two collectives per step) instead of the "
